@@ -1,0 +1,97 @@
+// msj_build.hpp - fold a generic robot description (rb_robot_desc) into the
+// constants of the ball-joint closed form (msj_math.hpp), or say why the
+// robot is not of that class.  Host code, fp64 until the final cast.
+#pragma once
+#include <cmath>
+#include <string>
+
+#include "../../include/roboy_sim.h"
+#include "msj_math.hpp"
+
+namespace rb {
+
+// true when the description is "one body on an x-y-z ball joint at the base
+// origin, via-points only on the base and on that body"
+inline bool msj_class(const rb_robot_desc *d, std::string &why) {
+    if (d->n_q != 3) { why = "n_q != 3"; return false; }
+    for (int i = 0; i < 3; ++i) {
+        if (d->parent[i] != i - 1) { why = "joints are not a serial chain"; return false; }
+        for (int a = 0; a < 3; ++a) {
+            if (d->origin[3 * i + a] != 0.0) { why = "joint origins are not co-located at the base origin"; return false; }
+            if (std::fabs(d->axis[3 * i + a] - (a == i ? 1.0 : 0.0)) > 1e-12) { why = "joint axes are not x, y, z"; return false; }
+        }
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (d->mass[i] != 0.0) { why = "virtual links 0/1 carry mass"; return false; }
+        for (int a = 0; a < 6; ++a)
+            if (d->inertia[6 * i + a] != 0.0) { why = "virtual links 0/1 carry inertia"; return false; }
+    }
+    for (int k = 0; k < d->n_t; ++k) {
+        const int v0 = d->vp_offset[k], v1 = d->vp_offset[k + 1];
+        if (v1 - v0 < 2) { why = "tendon with fewer than two via-points"; return false; }
+        bool on_body = false;
+        for (int v = v0; v < v1; ++v) {
+            const int link = d->vp_link[v];
+            if (link != -1 && link != 2) { why = "via-point on a virtual link"; return false; }
+            if (link == 2) on_body = true;
+            else if (on_body) { why = "tendon returns from the body to the base"; return false; }
+        }
+        if (d->vp_link[v0] != -1 || !on_body) { why = "tendon does not run base -> body"; return false; }
+    }
+    return true;
+}
+
+template <typename T, int NT>
+int msj_build(const rb_robot_desc *d, double step_size, int nsub, MsjConst<T, NT> *out, std::string &err) {
+    if (!msj_class(d, err)) return RB_EUNSUPPORTED;
+    if (d->n_t != NT) { err = "tendon count does not match this kernel instance"; return RB_EUNSUPPORTED; }
+    MsjConst<T, NT> &c = *out;
+    auto seglen = [&](int va, int vb) {
+        double s = 0.0;
+        for (int a = 0; a < 3; ++a) { const double t = d->vp_pos[3 * vb + a] - d->vp_pos[3 * va + a]; s += t * t; }
+        return std::sqrt(s);
+    };
+    for (int k = 0; k < NT; ++k) {
+        const int v0 = d->vp_offset[k], v1 = d->vp_offset[k + 1];
+        int vb = v0;
+        while (d->vp_link[vb] == -1) ++vb;   // first body via-point
+        const int va = vb - 1;               // last base via-point
+        double lc = 0.0;
+        for (int v = v0; v + 1 < v1; ++v)
+            if (v != va) lc += seglen(v, v + 1);
+        const double moving0 = seglen(va, vb);   // R = I in the zero pose
+        if (moving0 < 1e-6) { err = "degenerate tendon segment"; return RB_EINVAL; }
+        const double l0 = lc + moving0;
+        for (int a = 0; a < 3; ++a) { c.A[k][a] = T(d->vp_pos[3 * va + a]); c.B[k][a] = T(d->vp_pos[3 * vb + a]); }
+        c.lc[k] = T(lc); c.l0[k] = T(l0); c.inv_l0[k] = T(1.0 / l0);
+        c.fmax[k] = T(d->f_max[k]);
+        c.inv_vl0[k] = T(1.0 / (d->v_max * l0));
+    }
+    const double m = d->mass[2];
+    const double *cm = d->com + 6, *ic = d->inertia + 12;
+    const double c2 = cm[0] * cm[0] + cm[1] * cm[1] + cm[2] * cm[2];
+    c.IO[0] = T(ic[0] + m * (c2 - cm[0] * cm[0]));
+    c.IO[1] = T(ic[1] + m * (c2 - cm[1] * cm[1]));
+    c.IO[2] = T(ic[2] + m * (c2 - cm[2] * cm[2]));
+    c.IO[3] = T(ic[3] - m * cm[0] * cm[1]);
+    c.IO[4] = T(ic[4] - m * cm[0] * cm[2]);
+    c.IO[5] = T(ic[5] - m * cm[1] * cm[2]);
+    for (int a = 0; a < 3; ++a) {
+        c.mc[a] = T(m * cm[a]);
+        c.g[a] = T(d->gravity[a]);
+        c.arm[a] = T(d->armature[a]); c.damp[a] = T(d->damping[a]);
+        c.qlo[a] = T(d->q_lo[a]); c.qhi[a] = T(d->q_hi[a]); c.qdmax[a] = T(d->qd_max[a]);
+    }
+    c.kp = T(d->kp); c.sigma = T(d->setpoint_scale);
+    c.inv_w2 = T(1.0 / (d->fl_width * d->fl_width));
+    c.kpe_e0 = T(d->kpe / d->e0);
+    c.inv_pe_den = T(1.0 / (std::exp(d->kpe) - 1.0));
+    const double slope0 = 1.0 + 1.0 / d->fv_a;
+    const double c2l = slope0 / (d->fv_n - 1.0);
+    c.fv_c1s = T(1.0); c.fv_c2s = T(-1.0 / d->fv_a);
+    c.fv_c1l = T(d->fv_n * c2l); c.fv_c2l = T(c2l);
+    c.h = T(step_size / nsub); c.nsub = nsub;
+    return RB_OK;
+}
+
+}  // namespace rb

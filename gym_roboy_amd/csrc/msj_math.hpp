@@ -1,0 +1,275 @@
+// msj_math.hpp - per-env arithmetic of the ball-joint ("MSJ class") tendon robot.
+//
+// Model: DESIGN.md §2 (spec) and §4 (this closed form).  A robot of this class
+// is one rigid body on a ball joint written as three chained revolutes x-y-z
+// through the base origin, pulled by NT tendons that each have exactly one
+// moving segment (last base via-point A_k -> first body via-point B_k); every
+// other segment has constant length and is folded into `lc`.  Everything is
+// evaluated in the BODY frame, where the inertia about the joint centre and
+// the body-side via-points are constants:
+//
+//   R    = Rx(q0) Ry(q1) Rz(q2)                    body -> world
+//   zeta = R^T [z0 z1 z2] = [(c1c2,-c1s2,s1), (s2,c2,0), (0,0,1)]
+//   w_b  = zeta qd                                  angular velocity
+//   a_k  = R^T A_k,  d = B_k - a_k,  u = d/|d|,  l_k = |d| + lc_k
+//   w_k  = B_k x u;  dl_k/dt = w_b . w_k;  row k of the cable-length Jacobian
+//          is L_kj = zeta_j . w_k (never formed: -L^T F = zeta^T (-sum F_k w_k))
+//   M    = zeta^T I_O zeta + diag(armature)
+//   bias = zeta^T ( I_O (zeta_dot qd) + w_b x I_O w_b - (m c) x R^T g )
+//   qdd  = M^-1 ( zeta^T(-sum F_k w_k) - D qd - bias )
+//
+// The reference has no counterpart (its physics is the external CARDSflow
+// step behind ros_simulation_client.py:48-60); the CPU oracle
+// (oracle/physics_np.py, oracle/roboy_oracle.c) evaluates the same model with
+// the generic tree algorithms and is what this file is checked against.
+//
+// The header is plain C++ templated on the scalar type so the same source is
+// compiled by hipcc for the kernels and by g++ in tests/ (host double/float)
+// to check the derivation without a GPU.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RB_HD __host__ __device__ __forceinline__
+#else
+#define RB_HD inline
+#endif
+
+namespace rb {
+
+// ---- scalar helpers: fast hardware forms on the device, libm on the host ----
+template <typename T> struct Fast;
+template <> struct Fast<double> {
+    static RB_HD void sincos(double x, double &s, double &c) { s = ::sin(x); c = ::cos(x); }
+    static RB_HD double exp(double x) { return ::exp(x); }
+    static RB_HD double rsqrt(double x) { return 1.0 / ::sqrt(x); }
+    static RB_HD double rcp(double x) { return 1.0 / x; }
+};
+template <> struct Fast<float> {
+    static RB_HD void sincos(float x, float &s, float &c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        s = __sinf(x); c = __cosf(x);          // v_sin_f32 / v_cos_f32
+#else
+        s = ::sinf(x); c = ::cosf(x);
+#endif
+    }
+    static RB_HD float exp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __expf(x);                       // v_exp_f32
+#else
+        return ::expf(x);
+#endif
+    }
+    static RB_HD float rsqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __frsqrt_rn(x);                  // v_rsq_f32
+#else
+        return 1.0f / ::sqrtf(x);
+#endif
+    }
+    static RB_HD float rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __frcp_rn(x);                    // v_rcp_f32
+#else
+        return 1.0f / x;
+#endif
+    }
+};
+
+template <typename T> RB_HD T tmin(T a, T b) { return a < b ? a : b; }
+template <typename T> RB_HD T tmax(T a, T b) { return a > b ? a : b; }
+template <typename T> RB_HD T tclamp(T x, T lo, T hi) { return tmin(tmax(x, lo), hi); }
+
+// ---- per-robot constants (wave-uniform: live in SGPRs via the kernarg) ----
+template <typename T, int NT>
+struct MsjConst {
+    T A[NT][3];       // last base via-point, world = base frame
+    T B[NT][3];       // first body via-point, body frame
+    T lc[NT];         // summed length of the segments that do not move
+    T l0[NT];         // rest length (zero pose)
+    T inv_l0[NT];
+    T fmax[NT];
+    T inv_vl0[NT];    // 1 / (v_max * l0)
+    T IO[6];          // inertia about the joint centre, body frame: xx,yy,zz,xy,xz,yz
+    T mc[3];          // mass * centre of mass (body frame)
+    T g[3];           // gravity, world
+    T arm[3], damp[3], qlo[3], qhi[3], qdmax[3];
+    T kp, sigma, inv_w2, kpe_e0, inv_pe_den;
+    T fv_c1s, fv_c2s, fv_c1l, fv_c2l;
+    T h;              // integrator substep
+    int32_t nsub;
+};
+
+template <typename T, int NT>
+struct MsjModel {
+    using C = MsjConst<T, NT>;
+
+    // qdd = f(q, qd, set-points)
+    static RB_HD void accel(const C &c, const T q[3], const T qd[3], const T sp[NT], T qdd[3]) {
+        T s0, c0, s1, c1, s2, c2;
+        Fast<T>::sincos(q[0], s0, c0);
+        Fast<T>::sincos(q[1], s1, c1);
+        Fast<T>::sincos(q[2], s2, c2);
+        // R = Rx Ry Rz, rows
+        const T r00 = c1 * c2, r01 = -c1 * s2, r02 = s1;
+        const T r10 = c0 * s2 + s0 * s1 * c2, r11 = c0 * c2 - s0 * s1 * s2, r12 = -s0 * c1;
+        const T r20 = s0 * s2 - c0 * s1 * c2, r21 = s0 * c2 + c0 * s1 * s2, r22 = c0 * c1;
+        // joint axes in the body frame: zeta0 = row 0 of R, zeta1 = (s2,c2,0), zeta2 = e_z
+        const T wx = r00 * qd[0] + s2 * qd[1];
+        const T wy = r01 * qd[0] + c2 * qd[1];
+        const T wz = r02 * qd[0] + qd[2];
+
+        // ---- tendons: torque about the joint centre, body frame ----
+        T tx = T(0), ty = T(0), tz = T(0);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const T ax = r00 * c.A[k][0] + r10 * c.A[k][1] + r20 * c.A[k][2];
+            const T ay = r01 * c.A[k][0] + r11 * c.A[k][1] + r21 * c.A[k][2];
+            const T az = r02 * c.A[k][0] + r12 * c.A[k][1] + r22 * c.A[k][2];
+            const T dx = c.B[k][0] - ax, dy = c.B[k][1] - ay, dz = c.B[k][2] - az;
+            const T d2 = dx * dx + dy * dy + dz * dz;
+            const T inv = Fast<T>::rsqrt(d2);
+            const T len = d2 * inv + c.lc[k];
+            const T ux = dx * inv, uy = dy * inv, uz = dz * inv;
+            // w = B x u
+            const T mx = c.B[k][1] * uz - c.B[k][2] * uy;
+            const T my = c.B[k][2] * ux - c.B[k][0] * uz;
+            const T mz = c.B[k][0] * uy - c.B[k][1] * ux;
+            const T ldot = wx * mx + wy * my + wz * mz;
+            // Hill-type muscle
+            const T ln = len * c.inv_l0[k];
+            const T err = (len - c.l0[k] - c.sigma * sp[k]) * c.inv_l0[k];
+            const T act = tclamp(c.kp * err, T(0), T(1));
+            const T e = ln - T(1);
+            const T fl = Fast<T>::exp(-(e * e) * c.inv_w2);
+            T v = ldot * c.inv_vl0[k];
+            const bool lengthening = v > T(0);
+            const T c1v = lengthening ? c.fv_c1l : c.fv_c1s;
+            const T c2v = lengthening ? c.fv_c2l : c.fv_c2s;
+            v = tmax(v, T(-1));
+            const T fv = tmax((T(1) + c1v * v) * Fast<T>::rcp(T(1) + c2v * v), T(0));
+            const T fpe = tmax((Fast<T>::exp(c.kpe_e0 * e) - T(1)) * c.inv_pe_den, T(0));
+            const T F = c.fmax[k] * (act * fl * fv + fpe);
+            tx -= F * mx; ty -= F * my; tz -= F * mz;
+        }
+
+        // ---- rigid body about the joint centre ----
+        const T Ixx = c.IO[0], Iyy = c.IO[1], Izz = c.IO[2], Ixy = c.IO[3], Ixz = c.IO[4], Iyz = c.IO[5];
+        // columns I_O zeta_j
+        const T a0x = Ixx * r00 + Ixy * r01 + Ixz * r02;
+        const T a0y = Ixy * r00 + Iyy * r01 + Iyz * r02;
+        const T a0z = Ixz * r00 + Iyz * r01 + Izz * r02;
+        const T a1x = Ixx * s2 + Ixy * c2;
+        const T a1y = Ixy * s2 + Iyy * c2;
+        const T a1z = Ixz * s2 + Iyz * c2;
+        // M = zeta^T I_O zeta + armature
+        const T m00 = r00 * a0x + r01 * a0y + r02 * a0z + c.arm[0];
+        const T m01 = s2 * a0x + c2 * a0y;
+        const T m02 = a0z;
+        const T m11 = s2 * a1x + c2 * a1y + c.arm[1];
+        const T m12 = a1z;
+        const T m22 = Izz + c.arm[2];
+        // angular momentum and gyroscopic term
+        const T hx = a0x * qd[0] + a1x * qd[1] + Ixz * qd[2];
+        const T hy = a0y * qd[0] + a1y * qd[1] + Iyz * qd[2];
+        const T hz = a0z * qd[0] + a1z * qd[1] + Izz * qd[2];
+        // zeta_dot qd
+        const T z0x = -s1 * c2 * qd[1] - c1 * s2 * qd[2];
+        const T z0y = s1 * s2 * qd[1] - c1 * c2 * qd[2];
+        const T z0z = c1 * qd[1];
+        const T bx = z0x * qd[0] + c2 * qd[2] * qd[1];
+        const T by = z0y * qd[0] - s2 * qd[2] * qd[1];
+        const T bz = z0z * qd[0];
+        const T nx = Ixx * bx + Ixy * by + Ixz * bz + (wy * hz - wz * hy);
+        const T ny = Ixy * bx + Iyy * by + Iyz * bz + (wz * hx - wx * hz);
+        const T nz = Ixz * bx + Iyz * by + Izz * bz + (wx * hy - wy * hx);
+        // gravity torque (m c) x R^T g
+        const T gx = r00 * c.g[0] + r10 * c.g[1] + r20 * c.g[2];
+        const T gy = r01 * c.g[0] + r11 * c.g[1] + r21 * c.g[2];
+        const T gz = r02 * c.g[0] + r12 * c.g[1] + r22 * c.g[2];
+        const T vx = tx + (c.mc[1] * gz - c.mc[2] * gy) - nx;
+        const T vy = ty + (c.mc[2] * gx - c.mc[0] * gz) - ny;
+        const T vz = tz + (c.mc[0] * gy - c.mc[1] * gx) - nz;
+        const T t0 = r00 * vx + r01 * vy + r02 * vz - c.damp[0] * qd[0];
+        const T t1 = s2 * vx + c2 * vy - c.damp[1] * qd[1];
+        const T t2 = vz - c.damp[2] * qd[2];
+        // 3x3 SPD solve by the adjugate (one reciprocal)
+        const T k00 = m11 * m22 - m12 * m12;
+        const T k01 = m02 * m12 - m01 * m22;
+        const T k02 = m01 * m12 - m02 * m11;
+        const T k11 = m00 * m22 - m02 * m02;
+        const T k12 = m01 * m02 - m00 * m12;
+        const T k22 = m00 * m11 - m01 * m01;
+        const T idet = Fast<T>::rcp(m00 * k00 + m01 * k01 + m02 * k02);
+        qdd[0] = (k00 * t0 + k01 * t1 + k02 * t2) * idet;
+        qdd[1] = (k01 * t0 + k11 * t1 + k12 * t2) * idet;
+        qdd[2] = (k02 * t0 + k12 * t1 + k22 * t2) * idet;
+    }
+
+    static RB_HD void sat(const C &c, const T v[3], T out[3]) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) out[j] = tclamp(v[j], -c.qdmax[j], c.qdmax[j]);
+    }
+
+    // velocity saturation + joint limits; returns false when a limit was hit
+    static RB_HD bool limit(const C &c, T q[3], T qd[3]) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            T v = tclamp(qd[j], -c.qdmax[j], c.qdmax[j]);
+            const bool over = q[j] > c.qhi[j], under = q[j] < c.qlo[j];
+            if (over) { q[j] = c.qhi[j]; v = tmin(v, T(0)); }
+            if (under) { q[j] = c.qlo[j]; v = tmax(v, T(0)); }
+            qd[j] = v;
+            ok = ok && !(over || under);
+        }
+        return ok;
+    }
+
+    // one env step = nsub integrator substeps with the set-points held
+    template <int INTEG>
+    static RB_HD bool step(const C &c, T q[3], T qd[3], const T sp[NT]) {
+        bool feasible = true;
+        const T h = c.h;
+        for (int sub = 0; sub < c.nsub; ++sub) {
+            if (INTEG == 0) {          // semi-implicit Euler
+                T a[3];
+                accel(c, q, qd, sp, a);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    qd[j] = tclamp(qd[j] + h * a[j], -c.qdmax[j], c.qdmax[j]);
+                    q[j] = q[j] + h * qd[j];
+                }
+            } else {                   // RK4, stage velocities saturated
+                T k1q[3], k1v[3], k2q[3], k2v[3], k3q[3], k3v[3], k4q[3], k4v[3], qs[3], vs[3];
+                const T hh = T(0.5) * h;
+                sat(c, qd, k1q);
+                accel(c, q, k1q, sp, k1v);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { qs[j] = q[j] + hh * k1q[j]; vs[j] = qd[j] + hh * k1v[j]; }
+                sat(c, vs, k2q);
+                accel(c, qs, k2q, sp, k2v);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { qs[j] = q[j] + hh * k2q[j]; vs[j] = qd[j] + hh * k2v[j]; }
+                sat(c, vs, k3q);
+                accel(c, qs, k3q, sp, k3v);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { qs[j] = q[j] + h * k3q[j]; vs[j] = qd[j] + h * k3v[j]; }
+                sat(c, vs, k4q);
+                accel(c, qs, k4q, sp, k4v);
+                const T h6 = h * T(1.0 / 6.0);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    q[j] = q[j] + h6 * (k1q[j] + T(2) * k2q[j] + T(2) * k3q[j] + k4q[j]);
+                    qd[j] = qd[j] + h6 * (k1v[j] + T(2) * k2v[j] + T(2) * k3v[j] + k4v[j]);
+                }
+            }
+            feasible = limit(c, q, qd) && feasible;
+        }
+        return feasible;
+    }
+};
+
+}  // namespace rb

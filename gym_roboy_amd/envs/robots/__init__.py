@@ -1,0 +1,3 @@
+from .roboy_robot import RobotState, RoboyRobot
+from .description import RobotDescription
+from .msj_robot import MsjRobot, msj_platform_spec

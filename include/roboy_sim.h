@@ -1,0 +1,173 @@
+/* roboy_sim.h - C ABI of the MI355X batched tendon-robot physics step.
+ *
+ * Drop-in boundary for gym-roboy's SimulationClient plugin interface
+ * (reference: gym_roboy/envs/simulations/simulation_client.py:6-23).  In the
+ * reference every method of that interface is one ROS service round-trip into
+ * the external CARDSflow simulator (ros_simulation_client.py:32-81); here each
+ * is one in-process call that advances / reads N independent environments
+ * whose state lives in HBM.  Plain pointers and sizes only; no torch types.
+ *
+ *   reference method (file:line)                         entry point here
+ *   ---------------------------------------------------  ----------------------
+ *   RosSimulationClient.__init__        (ros_..py:16-30)  rb_create
+ *   forward_step_command(action)        (ros_..py:48-60)  rb_step / rb_step_dev
+ *   forward_reset_command()             (ros_..py:32-38)  rb_reset
+ *   read_state()                        (ros_..py:66-71)  rb_read_state
+ *   get_new_goal_joint_angles()         (ros_..py:73-81)  rb_sample_goals
+ *   _check_service_available_or_timeout (ros_..py:62-64)  return codes + rb_last_error
+ *   RoboyEnv.step env layer             (roboy_env.py:51-70,92-134)  rb_env_step_dev
+ *
+ * Layouts.  Host-facing arrays are row-major [n_envs][n] float32 (what numpy
+ * and a policy network produce).  Device state is struct-of-arrays: joint
+ * angle plane j is q[j*n_envs .. (j+1)*n_envs), same for velocities, plus one
+ * uint32 feasibility word per env.  Device action slabs are row-major
+ * [n_envs][n_t] float32 (one 32-byte record per MsjRobot env: two 16-byte
+ * loads per lane, contiguous across the wave).
+ *
+ * Threading: a handle owns one device and one stream; calls on one handle
+ * must be serialised by the caller; handles are independent (one process per
+ * GPU for the multi-GPU configuration).  All functions return RB_OK (0) or an
+ * error code, never abort; rb_last_error() gives the message (thread-local).
+ */
+#ifndef ROBOY_SIM_H
+#define ROBOY_SIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RB_ABI_VERSION 1
+
+enum rb_status {
+    RB_OK = 0,
+    RB_EINVAL = 1,       /* bad argument / malformed robot description      */
+    RB_EUNSUPPORTED = 2, /* robot structure has no HIP kernel (yet)         */
+    RB_EHIP = 3,         /* HIP runtime error (no device, launch failure)   */
+    RB_ENOMEM = 4
+};
+
+enum rb_integrator { RB_EULER = 0, RB_RK4 = 1 };
+
+/* kernel variants (rb_select_kernel): */
+enum rb_kernel {
+    RB_KERNEL_AUTO = 0,
+    RB_KERNEL_ENV_PER_LANE = 1,    /* one env per lane: throughput form        */
+    RB_KERNEL_TENDON_PER_LANE = 2  /* 8 lanes per env + DPP reductions: latency form */
+};
+
+/* Robot description, format "roboy-tendon-robot/1" (Python
+ * mirror: gym_roboy_amd/envs/robots/description.py).  All arrays are owned by
+ * the caller and only read during rb_create. */
+typedef struct rb_robot_desc {
+    int32_t n_q;             /* joints = moving links                         */
+    int32_t n_t;             /* tendons                                       */
+    int32_t n_vp;            /* total via-points                              */
+    int32_t _pad;
+    const int32_t *parent;   /* [n_q] parent link, -1 = base                  */
+    const double *axis;      /* [n_q][3] unit joint axis, parent frame        */
+    const double *origin;    /* [n_q][3] joint origin, parent frame           */
+    const double *mass;      /* [n_q]                                         */
+    const double *com;       /* [n_q][3] centre of mass, link frame           */
+    const double *inertia;   /* [n_q][6] xx,yy,zz,xy,xz,yz about COM          */
+    const double *armature;  /* [n_q] reflected actuator inertia              */
+    const double *damping;   /* [n_q] viscous joint damping                   */
+    const double *q_lo;      /* [n_q] feasible region, lower                  */
+    const double *q_hi;      /* [n_q] feasible region, upper                  */
+    const double *qd_max;    /* [n_q] joint speed limit                       */
+    double gravity[3];
+    const int32_t *vp_offset;/* [n_t+1] CSR offsets into the via-point arrays */
+    const int32_t *vp_link;  /* [n_vp] link of each via-point, -1 = base      */
+    const double *vp_pos;    /* [n_vp][3] position in that link's frame       */
+    const double *f_max;     /* [n_t] maximum isometric muscle force          */
+    double kp, setpoint_scale, v_max, fl_width, kpe, e0, fv_a, fv_n;
+} rb_robot_desc;
+
+typedef struct rb_sim rb_sim;
+
+typedef struct rb_sim_info {
+    int64_t n_envs;
+    int32_t n_q, n_t;
+    int32_t integrator, n_substeps;
+    int32_t kernel;             /* rb_kernel actually in use                  */
+    int32_t device;
+    double step_size;
+    int64_t bytes_per_env_step; /* algorithmic HBM bytes: 4*(4 n_q + n_t + 1) */
+    int64_t env_id_offset;
+} rb_sim_info;
+
+/* env-layer configuration for rb_env_* (reference RoboyEnv.__init__ kwargs and
+ * constants, roboy_env.py:12-28) */
+typedef struct rb_env_config {
+    int32_t joint_vel_penalty;      /* roboy_env.py:13                        */
+    int32_t goal_bonus;             /* is_agent_getting_bonus_for_reaching_goal */
+    int32_t max_episode_length;     /* 400, roboy_env.py:28                   */
+    int32_t _pad;
+    float penalty_boundary;         /* 1,    roboy_env.py:26                  */
+    float bonus_goal;               /* 1000, roboy_env.py:27                  */
+    float angle_lo, angle_hi;       /* joint-angle box (msj_robot.py:9)       */
+    float vel_lo, vel_hi;           /* joint-velocity box (msj_robot.py:10)   */
+    float action_lo, action_hi;     /* tendon set-point box (msj_robot.py:16) */
+} rb_env_config;
+
+const char *rb_last_error(void);
+int rb_abi_version(void);
+int rb_device_count(int *count);
+
+/* rb_create: build a batch of n_envs environments on `device`.
+ * env_id_offset shards one logical batch over several handles/GPUs: all
+ * counter-based random streams are keyed by (seed, env_id_offset + i), so
+ * results do not depend on how the batch is split. */
+int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator,
+              double step_size, int n_substeps, int device, uint64_t seed,
+              int64_t env_id_offset, rb_sim **out);
+void rb_destroy(rb_sim *sim);
+int rb_info(const rb_sim *sim, rb_sim_info *info);
+int rb_select_kernel(rb_sim *sim, int kernel);
+int rb_set_stream(rb_sim *sim, void *hip_stream); /* NULL = the handle's own */
+int rb_synchronize(rb_sim *sim);
+
+/* ---- host-buffer entry points (synchronous; plumbing, not the hot loop) ---- */
+int rb_reset(rb_sim *sim, const uint8_t *mask /* [n_envs] or NULL = all */);
+int rb_set_state(rb_sim *sim, const float *q, const float *qd,
+                 const uint8_t *feasible /* NULL = all feasible */);
+int rb_read_state(rb_sim *sim, float *q, float *qd, uint8_t *feasible);
+/* set-point = act_scale * act; act_scale = 1 when the caller has already
+ * rescaled to the robot's set-point box (roboy_env.py:54-57) */
+int rb_step(rb_sim *sim, const float *act, float act_scale,
+            float *q, float *qd, uint8_t *feasible);
+int rb_sample_goals(rb_sim *sim, const uint8_t *mask, float *goal_q);
+
+/* ---- device-pointer entry points (asynchronous on the handle's stream) ---- */
+int rb_state_ptrs(rb_sim *sim, float **d_q, float **d_qd, uint32_t **d_feasible);
+int rb_step_dev(rb_sim *sim, const float *d_act, float act_scale);
+/* n_steps per-step launches; step t reads slab (t % ring) of d_act_ring
+ * ([ring][n_envs][n_t]).  use_graph != 0 replays them from a captured hipGraph.
+ * One kernel per env step either way (a policy sits between steps in real use). */
+int rb_rollout_dev(rb_sim *sim, const float *d_act_ring, int ring, int n_steps,
+                   float act_scale, int use_graph);
+/* synthetic i.i.d. U[-1,1) actions: Philox4x32-10, key = seed,
+ * counter = (env id, step, stream 0) */
+int rb_fill_actions_dev(rb_sim *sim, float *d_act, uint32_t step);
+int rb_sample_goals_dev(rb_sim *sim, const uint8_t *d_mask, float *d_goal_q /* [n_q][n_envs] */);
+
+/* ---- fused env layer (next row of the scope table) ---- */
+int rb_env_configure(rb_sim *sim, const rb_env_config *cfg);
+int rb_env_reset_dev(rb_sim *sim, float *d_obs /* [n_envs][3 n_q] */);
+int rb_env_step_dev(rb_sim *sim, const float *d_act /* [n_envs][n_t] in [-1,1] */,
+                    float *d_obs, float *d_reward, uint32_t *d_done);
+/* sums over envs since the last call: [sum r, sum r^2, n_steps, n_episodes,
+ * sum episode length, n_goal_reached, n_infeasible_steps, 0] (fp64, host) */
+int rb_env_stats(rb_sim *sim, double *stats8, int reset);
+
+/* device memory helpers so a ctypes caller needs no HIP binding of its own */
+int rb_malloc(rb_sim *sim, int64_t bytes, void **d_ptr);
+int rb_free(rb_sim *sim, void *d_ptr);
+int rb_memcpy_h2d(rb_sim *sim, void *d_dst, const void *h_src, int64_t bytes);
+int rb_memcpy_d2h(rb_sim *sim, void *h_dst, const void *d_src, int64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROBOY_SIM_H */
