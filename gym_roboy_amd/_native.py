@@ -1,0 +1,132 @@
+"""ctypes binding of ``include/roboy_sim.h`` (``csrc/libroboy_sim.so``).
+
+There is no CPU fallback: if the shared library is missing, or a call fails,
+this raises.  The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C gym_roboy_amd/csrc``.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .envs.robots.description import RobotDescriptionC
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libroboy_sim.so")
+
+RB_OK, RB_EINVAL, RB_EUNSUPPORTED, RB_EHIP, RB_ENOMEM = range(5)
+RB_EULER, RB_RK4 = 0, 1
+RB_KERNEL_AUTO, RB_KERNEL_ENV_PER_LANE, RB_KERNEL_TENDON_PER_LANE = 0, 1, 2
+
+INTEGRATORS = {"euler": RB_EULER, "semi-implicit-euler": RB_EULER, "rk4": RB_RK4,
+               RB_EULER: RB_EULER, RB_RK4: RB_RK4}
+
+
+class SimInfo(ctypes.Structure):
+    _fields_ = [("n_envs", ctypes.c_int64), ("n_q", ctypes.c_int32), ("n_t", ctypes.c_int32),
+                ("integrator", ctypes.c_int32), ("n_substeps", ctypes.c_int32),
+                ("kernel", ctypes.c_int32), ("device", ctypes.c_int32),
+                ("step_size", ctypes.c_double), ("bytes_per_env_step", ctypes.c_int64),
+                ("env_id_offset", ctypes.c_int64)]
+
+
+class EnvConfig(ctypes.Structure):
+    _fields_ = [("joint_vel_penalty", ctypes.c_int32), ("goal_bonus", ctypes.c_int32),
+                ("max_episode_length", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("penalty_boundary", ctypes.c_float), ("bonus_goal", ctypes.c_float),
+                ("angle_lo", ctypes.c_float), ("angle_hi", ctypes.c_float),
+                ("vel_lo", ctypes.c_float), ("vel_hi", ctypes.c_float),
+                ("action_lo", ctypes.c_float), ("action_hi", ctypes.c_float)]
+
+
+_vp = ctypes.c_void_p
+_fp = ctypes.POINTER(ctypes.c_float)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_sim = ctypes.c_void_p
+
+# every symbol include/roboy_sim.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "rb_last_error": (ctypes.c_char_p, []),
+    "rb_abi_version": (ctypes.c_int, []),
+    "rb_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "rb_create": (ctypes.c_int, [ctypes.POINTER(RobotDescriptionC), ctypes.c_int64, ctypes.c_int,
+                                 ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
+                                 ctypes.c_int64, ctypes.POINTER(_sim)]),
+    "rb_destroy": (None, [_sim]),
+    "rb_info": (ctypes.c_int, [_sim, ctypes.POINTER(SimInfo)]),
+    "rb_select_kernel": (ctypes.c_int, [_sim, ctypes.c_int]),
+    "rb_set_stream": (ctypes.c_int, [_sim, _vp]),
+    "rb_synchronize": (ctypes.c_int, [_sim]),
+    "rb_reset": (ctypes.c_int, [_sim, _u8p]),
+    "rb_set_state": (ctypes.c_int, [_sim, _fp, _fp, _u8p]),
+    "rb_read_state": (ctypes.c_int, [_sim, _fp, _fp, _u8p]),
+    "rb_step": (ctypes.c_int, [_sim, _fp, ctypes.c_float, _fp, _fp, _u8p]),
+    "rb_sample_goals": (ctypes.c_int, [_sim, _u8p, _fp]),
+    "rb_state_ptrs": (ctypes.c_int, [_sim, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    "rb_step_dev": (ctypes.c_int, [_sim, _vp, ctypes.c_float]),
+    "rb_rollout_dev": (ctypes.c_int, [_sim, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]),
+    "rb_fill_actions_dev": (ctypes.c_int, [_sim, _vp, ctypes.c_uint32]),
+    "rb_sample_goals_dev": (ctypes.c_int, [_sim, _vp, _vp]),
+    "rb_env_configure": (ctypes.c_int, [_sim, ctypes.POINTER(EnvConfig)]),
+    "rb_env_reset_dev": (ctypes.c_int, [_sim, _vp]),
+    "rb_env_step_dev": (ctypes.c_int, [_sim, _vp, _vp, _vp, _vp]),
+    "rb_env_stats": (ctypes.c_int, [_sim, ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
+    "rb_malloc": (ctypes.c_int, [_sim, ctypes.c_int64, ctypes.POINTER(_vp)]),
+    "rb_free": (ctypes.c_int, [_sim, _vp]),
+    "rb_memcpy_h2d": (ctypes.c_int, [_sim, _vp, _vp, ctypes.c_int64]),
+    "rb_memcpy_d2h": (ctypes.c_int, [_sim, _vp, _vp, ctypes.c_int64]),
+}
+
+_LIB = None
+
+
+class NativeError(RuntimeError):
+    """A call into libroboy_sim.so failed (message from ``rb_last_error``)."""
+
+
+def load():
+    """Load the HIP library once; raise if it is not built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                "HIP extension not built: %s is missing (run `python -c 'import "
+                "__graft_entry__ as g; g.build()'` or `make -C gym_roboy_amd/csrc`). "
+                "There is no CPU fallback for the physics step." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError if the symbol is missing
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _LIB = lib
+    return _LIB
+
+
+def check(rc):
+    if rc != RB_OK:
+        msg = load().rb_last_error().decode("utf-8", "replace")
+        if rc == RB_EINVAL:
+            raise ValueError(msg)
+        raise NativeError("libroboy_sim error %d: %s" % (rc, msg))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    rc = load().rb_device_count(ctypes.byref(n))
+    return n.value if rc == RB_OK else 0
+
+
+def fptr(a):
+    return a.ctypes.data_as(_fp)
+
+
+def u8ptr(a):
+    return None if a is None else a.ctypes.data_as(_u8p)
+
+
+def as_f32(a, shape, name):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.shape != tuple(shape):
+        raise ValueError("%s must have shape %s, got %s" % (name, tuple(shape), a.shape))
+    return a

@@ -64,14 +64,14 @@ template <> struct Fast<float> {
     }
     static RB_HD float rsqrt(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        return __frsqrt_rn(x);                  // v_rsq_f32
+        return __builtin_amdgcn_rsqf(x);        // v_rsq_f32 (1 ulp)
 #else
         return 1.0f / ::sqrtf(x);
 #endif
     }
     static RB_HD float rcp(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        return __frcp_rn(x);                    // v_rcp_f32
+        return __builtin_amdgcn_rcpf(x);        // v_rcp_f32 (1 ulp)
 #else
         return 1.0f / x;
 #endif

@@ -1,0 +1,1 @@
+from .roboy_env import RoboyEnv
