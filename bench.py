@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py - env-steps/s of the batched MsjRobot physics step on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+One "step" = one lock-step call of the batched ``forward_step_command`` = one
+kernel launch that advances every env of the rank's shard by one integrator
+step of dt = 0.1.  Actions are i.i.d. U[-1,1) from the Philox
+streams, pre-generated as a ring of 4 slabs resident in HBM and rescaled by
+0.3 in the kernel.  The default workload is BASELINE.json configs[1]
+("MsjRobot 4 096 envs, semi-implicit Euler fp32, 1 MI355X"); the other
+single-GPU configs are available through --workload and are also measured
+briefly and reported under "also" (they are not the headline).
+
+N > 1: launched by torch.distributed.run, one rank per GPU; envs shard
+contiguously (weak scaling: the per-GPU batch is fixed), no data-path
+collective; every 100 steps the rank's episode statistics (8 doubles) are
+all-reduced over RCCL.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (envs per GPU, integrator, substeps, default steps, default warmup, BASELINE.json config)
+    "msj-4096-euler": (4096, "euler", 1, 4000, 200, "configs[1]: MsjRobot 4 096 envs, semi-implicit Euler fp32"),
+    "msj-262144-rk4": (262144, "rk4", 1, 400, 40, "configs[2]: MsjRobot 262 144 envs, RK4 fp32"),
+    "msj-262144-euler": (262144, "euler", 1, 1000, 100, "configs[4] shard: 262 144 envs per GPU, Euler fp32"),
+    "msj-2097152-euler": (2097152, "euler", 1, 300, 30, "large batch: 2 097 152 envs on one GPU, Euler fp32"),
+}
+RING = 4
+STATS_EVERY = 100
+HBM_PEAK = 8.0e12          # B/s, spec (MI355X_MICROARCH.md "HBM3E peak BW")
+HBM_COPY = 6.29e12         # B/s, measured float4 copy (same table)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="msj-4096-euler", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs", type=int, default=None, help="override envs per GPU")
+    ap.add_argument("--no-graph", action="store_true", help="eager per-step launches instead of hipGraph replay")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world, dist):
+    """Returns dict(ms_per_step, value, kernel_us, ...) for this workload."""
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    n_envs, integrator, nsub, d_steps, d_warm, label = WORKLOADS[name]
+    n_envs = envs or n_envs
+    steps = steps or d_steps
+    warmup = d_warm if warmup is None else warmup
+    dev = torch.cuda.current_device()
+    sim = HipBatchSimulation(robot, n_envs, integrator=integrator, n_substeps=nsub, device=dev,
+                             seed=0, env_id_offset=rank * n_envs)
+    stream = torch.cuda.current_stream()        # main() made a non-default stream current
+    sim.set_stream(stream.cuda_stream)          # launches and torch events share one stream
+    slab = n_envs * sim.n_t
+    ring = torch.empty(RING * slab, dtype=torch.float32, device="cuda")
+    for r in range(RING):
+        sim.fill_actions_dev(ring.data_ptr() + 4 * r * slab, r)
+    stats = torch.zeros(8, dtype=torch.float64, device="cuda")
+    act_scale = float(robot.get_action_space().high[0])
+
+    def rollout(k):
+        done = 0
+        while done < k:
+            chunk = min(STATS_EVERY, k - done)
+            sim.rollout_dev(ring.data_ptr(), RING, chunk, act_scale, use_graph=use_graph)
+            done += chunk
+            if world > 1 and chunk == STATS_EVERY:
+                # episode statistics of the shard -> sum over ranks (RCCL over xGMI)
+                from gym_roboy_amd import _native as nat
+                import ctypes
+                nat.check(sim._lib.rb_env_stats_dev(sim.handle, ctypes.c_void_p(stats.data_ptr()), 0))
+                dist.all_reduce(stats)
+
+    # 16 untimed steps from the reset state decorrelate the envs, then warm-up
+    rollout(16)
+    rollout(warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    rollout(steps)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    q, qd, feas = sim.read_state()
+    info = sim.info()
+    sim.close()
+    bytes_per_launch = info["bytes_per_env_step"] * n_envs
+    launch_s = dev_ms * 1e-3 / steps            # HIP events on the launch stream, per launch
+    return {
+        "workload": name, "label": label, "envs_per_gpu": n_envs, "integrator": integrator,
+        "substeps": nsub, "steps": steps, "warmup": warmup,
+        "value": world * n_envs * steps / wall, "ms_per_step": wall * 1e3 / steps,
+        "launch_us_events": launch_s * 1e6, "bytes_per_launch": bytes_per_launch,
+        "achieved_GBps": bytes_per_launch / launch_s / 1e9,
+        "finite": bool(np.isfinite(q).all() and np.isfinite(qd).all()),
+        "feasible_frac": float(feas.mean()),
+    }
+
+
+def cpu_baseline(robot, seconds, name):
+    """The C restatement of the same step (oracle/roboy_oracle.c, fp32 build)
+    timed on this box's host cores on a bounded sample of the workload."""
+    from oracle.c_oracle import COracle
+    from oracle import philox_np as ph
+    n_envs, integrator, nsub, *_ = WORKLOADS[name]
+    n = min(n_envs, 4096)
+    desc = robot.get_description()
+    orc = COracle(desc, "f32")
+    integ = 0 if integrator == "euler" else 1
+    ids = np.arange(n, dtype=np.uint64)
+    slabs = [np.ascontiguousarray(ph.actions(0, ids, r, desc.n_t) * np.float32(0.3)) for r in range(RING)]
+    q = np.zeros((n, desc.n_q), np.float32)
+    qd = np.zeros((n, desc.n_q), np.float32)
+    feas = np.zeros(n, np.uint8)
+    out = {}
+    cores_avail = len(os.sched_getaffinity(0))
+    for threads in sorted({1, cores_avail}):
+        for t in range(16):
+            orc.step_inplace(q, qd, slabs[t % RING], feas, integrator=integ, n_substeps=nsub, threads=threads)
+        budget = seconds / 2
+        t0 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t0 < budget:
+            orc.step_inplace(q, qd, slabs[k % RING], feas, integrator=integ, n_substeps=nsub, threads=threads)
+            k += 1
+        out[threads] = (n * k / (time.perf_counter() - t0), k)
+    best = max(out, key=lambda th: out[th][0])
+    return {
+        "value": out[best][0], "unit": "env-steps/s", "cores": best, "kind": "port",
+        "sample": "%d envs x %d steps of %s, C fp32 restatement (oracle/roboy_oracle.c), OpenMP over envs"
+                  % (n, out[best][1], name),
+        "value_1_core": out[1][0], "host_cores_available": cores_avail,
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the physics step)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from gym_roboy_amd.envs.robots import MsjRobot
+    robot = MsjRobot()
+    use_graph = not args.no_graph
+    also = []
+    # stream capture is not allowed on the legacy default stream: run on a side stream
+    with torch.cuda.stream(torch.cuda.Stream()):
+        head = run_workload(torch, robot, args.workload, args.steps, args.warmup, args.envs, use_graph,
+                            rank, world, dist)
+        if world == 1 and not args.no_also:
+            for name in ("msj-262144-rk4", "msj-2097152-euler"):
+                if name != args.workload:
+                    r = run_workload(torch, robot, name, None, None, None, use_graph, rank, world, dist)
+                    also.append({k: r[k] for k in ("workload", "label", "value", "ms_per_step", "launch_us_events",
+                                                   "achieved_GBps", "steps")} |
+                                {"frac_of_hbm_peak": r["achieved_GBps"] * 1e9 / HBM_PEAK})
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(robot, args.cpu_seconds, args.workload)
+
+    if rank == 0:
+        line = {
+            "metric": "env-steps/sec, MsjRobot (3-DOF/8-tendon) batched rollout",
+            "value": head["value"], "unit": "env-steps/s",
+            "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"],
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": head["label"], "robot": "MsjRobot", "envs_per_gpu": head["envs_per_gpu"],
+                       "total_envs": head["envs_per_gpu"] * world, "integrator": head["integrator"],
+                       "substeps": head["substeps"], "step_size": 0.1,
+                       "launch": "hipGraph replay of per-step kernels" if use_graph else "eager per-step launches",
+                       "parallelism": "env shards x%d, RCCL all-reduce of episode statistics every %d steps"
+                                      % (world, STATS_EVERY) if world > 1 else "single GPU"},
+            "roofline": {
+                "bound": "hbm", "achieved": head["achieved_GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": head["achieved_GBps"] * 1e9 / HBM_PEAK, "traffic": None,
+                "kernel": "msj_step_env_per_lane", "bytes_per_env_step": 84,
+                "bytes_per_launch": head["bytes_per_launch"], "launch_us_events": head["launch_us_events"],
+                "note": "events bracket the whole timed region on the launch stream, so the per-launch "
+                        "time includes the kernel boundary; rocprofv3 kernel-only time is in profiles/",
+            },
+            "cpu_baseline": cpu,
+            "also": also,
+            "sanity": {"finite": head["finite"], "feasible_frac": head["feasible_frac"]},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

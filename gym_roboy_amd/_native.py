@@ -32,11 +32,12 @@ class SimInfo(ctypes.Structure):
 
 class EnvConfig(ctypes.Structure):
     _fields_ = [("joint_vel_penalty", ctypes.c_int32), ("goal_bonus", ctypes.c_int32),
-                ("max_episode_length", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("max_episode_length", ctypes.c_int32), ("auto_reset", ctypes.c_int32),
                 ("penalty_boundary", ctypes.c_float), ("bonus_goal", ctypes.c_float),
                 ("angle_lo", ctypes.c_float), ("angle_hi", ctypes.c_float),
                 ("vel_lo", ctypes.c_float), ("vel_hi", ctypes.c_float),
-                ("action_lo", ctypes.c_float), ("action_hi", ctypes.c_float)]
+                ("action_lo", ctypes.c_float), ("action_hi", ctypes.c_float),
+                ("goal_angle_tol", ctypes.c_float), ("goal_vel_tol", ctypes.c_float)]
 
 
 _vp = ctypes.c_void_p
@@ -72,6 +73,7 @@ SIGNATURES = {
     "rb_env_reset_dev": (ctypes.c_int, [_sim, _vp]),
     "rb_env_step_dev": (ctypes.c_int, [_sim, _vp, _vp, _vp, _vp]),
     "rb_env_stats": (ctypes.c_int, [_sim, ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
+    "rb_env_stats_dev": (ctypes.c_int, [_sim, _vp, ctypes.c_int]),
     "rb_malloc": (ctypes.c_int, [_sim, ctypes.c_int64, ctypes.POINTER(_vp)]),
     "rb_free": (ctypes.c_int, [_sim, _vp]),
     "rb_memcpy_h2d": (ctypes.c_int, [_sim, _vp, _vp, ctypes.c_int64]),
@@ -85,10 +87,33 @@ class NativeError(RuntimeError):
     """A call into libroboy_sim.so failed (message from ``rb_last_error``)."""
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own
+    ``libamdhip64.so`` and asks for it by the unversioned name, so if this
+    library pulls in ``/opt/rocm/lib/libamdhip64.so.7`` first, a later
+    ``import torch`` loads a second runtime that then sees no GPU.  Loading
+    torch's copy first (by path, without importing torch) makes both bind to
+    the same one whatever the import order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
 def load():
     """Load the HIP library once; raise if it is not built."""
     global _LIB
     if _LIB is None:
+        _share_hip_runtime_with_torch()
         if not os.path.exists(LIB_PATH):
             raise NativeError(
                 "HIP extension not built: %s is missing (run `python -c 'import "

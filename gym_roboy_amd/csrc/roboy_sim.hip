@@ -43,8 +43,8 @@ using Const8 = rb::MsjConst<float, NT8>;
 template <int INTEG, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 msj_step_env_per_lane(const Const8 c, float *__restrict__ q, float *__restrict__ qd,
-                      uint32_t *__restrict__ feas, const float *__restrict__ act,
-                      float act_scale, long n) {
+                      uint32_t *__restrict__ feas, uint32_t *__restrict__ infeas_n,
+                      const float *__restrict__ act, float act_scale, long n) {
     const long i = long(blockIdx.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     float qq[3], vv[3], sp[NT8];
@@ -58,6 +58,7 @@ msj_step_env_per_lane(const Const8 c, float *__restrict__ q, float *__restrict__
 #pragma unroll
     for (int j = 0; j < 3; ++j) { q[j * n + i] = qq[j]; qd[j * n + i] = vv[j]; }
     feas[i] = ok ? 1u : 0u;
+    if (!ok) infeas_n[i] += 1u;   // rare: feeds rb_env_stats, no traffic otherwise
 }
 
 __global__ void reset_kernel(float *q, float *qd, uint32_t *feas, const uint8_t *mask, int n_q, long n) {
@@ -100,8 +101,16 @@ __global__ void fill_actions_kernel(float *act, int n_t, long n, uint64_t seed, 
 
 // goal = lo + (hi - lo) * u, both operations rounded separately in fp32 so the
 // numpy restatement reproduces it bit for bit
+// a * b + c with two roundings.  hipcc contracts a*b+c into one fma by default
+// (-ffp-contract=fast) and HIP's __fmul_rn/__fadd_rn are plain operators, so
+// the contraction has to be switched off for this statement.
+__device__ __forceinline__ float mul_then_add(float a, float b, float c) {
+#pragma clang fp contract(off)
+    const float p = a * b;
+    return p + c;
+}
 __device__ __forceinline__ float goal_value(float lo, float hi, uint32_t u) {
-    return __fadd_rn(lo, __fmul_rn(__fsub_rn(hi, lo), rb::u01(u)));
+    return mul_then_add(hi - lo, rb::u01(u), lo);
 }
 struct GoalBox { float lo[32]; float hi[32]; };
 __global__ void sample_goals_kernel(float *goal, uint32_t *count, const uint8_t *mask, GoalBox box,
@@ -119,6 +128,166 @@ __global__ void sample_goals_kernel(float *goal, uint32_t *count, const uint8_t 
             if (rows) goal[i * n_q + j] = g; else goal[j * n + i] = g;
         }
     }
+}
+
+
+// ------------------------------------------------------------ fused env layer
+// RoboyEnv.step for a batch (reference gym_roboy/envs/roboy_env.py:51-70):
+// rescale action -> physics step -> obs / reward / done -> goal resampling,
+// plus the reset the reference's SubprocVecEnv workers apply on done
+// (train_parallel.py:29) when auto_reset is set.  DESIGN.md §6.
+struct EnvParams {
+    int vel_penalty, bonus, max_len, auto_reset;
+    float penalty, bonus_val;
+    float a_lo, a_hi, v_lo, v_hi;    // joint angle / velocity boxes
+    float act_hi, slope;             // set-point box upper bound, (hi-lo)/(1-(-1)) in fp32
+    float tol_a, tol_v;
+};
+
+__device__ __forceinline__ float norm_pm1(float v, float hi, float lo) {
+    // (2 v - max - min) / (max - min), roboy_robot.py:93-95
+    return (2.0f * v - hi - lo) / (hi - lo);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// obs/goal helper: draw goal number `draw` of env `gid`
+__device__ __forceinline__ void draw_goal3(const GoalBox &box, uint64_t seed, uint64_t gid, uint32_t draw, float g[3]) {
+    const rb::Philox4 r = rb::philox_draw(seed, gid, draw, rb::STREAM_GOALS, 0u);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g[j] = goal_value(box.lo[j], box.hi[j], r.v[j]);
+}
+
+template <int INTEG, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+msj_env_step_kernel(const Const8 c, const EnvParams e, const GoalBox box,
+                    float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
+                    float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
+                    uint32_t *__restrict__ goal_count, const float *__restrict__ act,
+                    float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
+                    float *__restrict__ ep_acc, uint32_t *__restrict__ infeas_n,
+                    long n, uint64_t seed, uint64_t env0) {
+    const long i = long(blockIdx.x) * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float qq[3], vv[3], gg[3], sp[NT8];
+    const float4 a0 = reinterpret_cast<const float4 *>(act)[2 * i];
+    const float4 a1 = reinterpret_cast<const float4 *>(act)[2 * i + 1];
+    const float a[NT8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { qq[j] = q[j * n + i]; vv[j] = qd[j * n + i]; gg[j] = goal[j * n + i]; }
+#pragma unroll
+    for (int k = 0; k < NT8; ++k) {
+        // the reference asserts the action lies in [-1,1] (roboy_env.py:52); a
+        // batched kernel cannot raise, so it clamps.  Then
+        // slope * (x - in_high) + out_high, each op rounded (roboy_env.py:157-158)
+        const float x = fminf(fmaxf(a[k], -1.0f), 1.0f);
+        sp[k] = mul_then_add(e.slope, x - 1.0f, e.act_hi);
+    }
+    const bool ok = rb::MsjModel<float, NT8>::template step<INTEG>(c, qq, vv, sp);
+    uint32_t sn = step_num[i] + 1u;
+
+    // reward (roboy_env.py:92-112), fp32
+    float d2 = 0.0f, dq2 = 0.0f, dv2 = 0.0f, vn2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float dn = norm_pm1(qq[j], e.a_hi, e.a_lo) - norm_pm1(gg[j], e.a_hi, e.a_lo);
+        d2 += dn * dn;
+        const float dq = qq[j] - gg[j];
+        dq2 += dq * dq;
+        dv2 += vv[j] * vv[j];
+        const float vn = norm_pm1(vv[j], e.v_hi, e.v_lo) - norm_pm1(0.0f, e.v_hi, e.v_lo);
+        vn2 += vn * vn;
+    }
+    float r = -expf(sqrtf(d2));
+    if (e.vel_penalty) r = (sqrtf(vn2) + 1.0f) * (r - expf(r));
+    if (!ok) r -= fabsf(e.penalty);
+    const bool reached = (sqrtf(dq2) < e.tol_a) && (sqrtf(dv2) < e.tol_v);
+    if (reached && e.bonus) r += e.bonus_val;
+    const bool dn = reached || (sn > uint32_t(e.max_len));
+
+    float o[9] = {qq[0], qq[1], qq[2], vv[0], vv[1], vv[2], gg[0], gg[1], gg[2]};
+    float ret = ep_ret[i] + r;
+    uint32_t fz = ok ? 1u : 0u;
+    if (!ok) infeas_n[i] += 1u;
+    if (dn) {
+        // per-env episode accumulators, touched only when an episode ends;
+        // rb_env_stats reduces them (no atomics in the step kernel)
+        float *acc = ep_acc + i;
+        acc[0 * n] += ret; acc[1 * n] += ret * ret; acc[2 * n] += 1.0f;
+        acc[3 * n] += float(sn - 1u); acc[4 * n] += reached ? 1.0f : 0.0f;
+        const uint64_t gid = env0 + uint64_t(i);
+        uint32_t draw = goal_count[i];
+        draw_goal3(box, seed, gid, draw++, gg);          // RoboyEnv.step: _set_new_goal (:67-68)
+        if (e.auto_reset) {                              // VecEnv worker: env.reset() (:82-87)
+            draw_goal3(box, seed, gid, draw++, gg);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { qq[j] = 0.0f; vv[j] = 0.0f; o[j] = 0.0f; o[3 + j] = 0.0f; o[6 + j] = gg[j]; }
+            sn = 1u; fz = 1u;
+        }
+        ret = 0.0f;
+        goal_count[i] = draw;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) goal[j * n + i] = gg[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { q[j * n + i] = qq[j]; qd[j * n + i] = vv[j]; }
+    feas[i] = fz; step_num[i] = sn; ep_ret[i] = ret;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) obs[i * 9 + j] = o[j];
+    reward[i] = r; done[i] = dn ? 1u : 0u;
+}
+
+// rb_env_stats: block-reduce the per-env accumulators in fp64, one atomic per
+// block and statistic (runs once per reporting interval, not per step)
+__global__ void __launch_bounds__(256)
+stats_reduce_kernel(const float *ep_acc, const float *ep_ret, const uint32_t *infeas_n, double *out,
+                    double env_steps, long n) {
+    __shared__ double sh[4][7];
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n; i += long(gridDim.x) * 256) {
+        if (ep_acc) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k] += double(ep_acc[k * n + i]);
+            v[6] += double(ep_ret[i]);
+        }
+        v[5] += double(infeas_n[i]);
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 7; ++k) sh[w][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const double t = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        // out: [sum return, sum return^2, n_episodes, sum length, n_goal, n_infeasible, (n_env_steps), sum reward]
+        const int slot = threadIdx.x < 6 ? threadIdx.x : 7;
+        // sum reward = finished returns + running returns
+        if (threadIdx.x == 6) unsafeAtomicAdd(out + 7, t + sh[0][0] + sh[1][0] + sh[2][0] + sh[3][0]);
+        else unsafeAtomicAdd(out + slot, t);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 7) out[6] = env_steps;
+}
+
+__global__ void env_reset_kernel(const GoalBox box, float *q, float *qd, uint32_t *feas, float *goal,
+                                 uint32_t *step_num, float *ep_ret, uint32_t *goal_count, float *obs,
+                                 long n, uint64_t seed, uint64_t env0) {
+    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float g[3];
+    const uint32_t draw = goal_count[i];
+    draw_goal3(box, seed, env0 + uint64_t(i), draw, g);
+    goal_count[i] = draw + 1u;
+    for (int j = 0; j < 3; ++j) {
+        q[j * n + i] = 0.0f; qd[j * n + i] = 0.0f; goal[j * n + i] = g[j];
+        if (obs) { obs[i * 9 + j] = 0.0f; obs[i * 9 + 3 + j] = 0.0f; obs[i * 9 + 6 + j] = g[j]; }
+    }
+    feas[i] = 1u; step_num[i] = 1u; ep_ret[i] = 0.0f;
 }
 
 inline unsigned blocks_for(long n, int block) { return unsigned((n + block - 1) / block); }
@@ -139,6 +308,13 @@ struct rb_sim {
     hipStream_t own_stream = nullptr, stream = nullptr;
     float *d_q = nullptr, *d_qd = nullptr;
     uint32_t *d_feas = nullptr, *d_goal_count = nullptr;
+    // fused env layer (rb_env_*)
+    bool env_ready = false;
+    EnvParams env;
+    float *d_goal = nullptr, *d_ep_ret = nullptr, *d_ep_acc = nullptr;   // ep_acc: [5][n]
+    uint32_t *d_step_num = nullptr, *d_infeas_n = nullptr;
+    double *d_stats = nullptr;   // [8] scratch of the reduction
+    double env_steps = 0.0;      // env steps issued since the statistics were reset
     // host I/O staging
     float *d_rows = nullptr;   // [n][max(n_q, n_t)]
     uint8_t *d_u8 = nullptr;   // [n]
@@ -160,18 +336,18 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale) {
         constexpr int B = 64;
         if (s->integrator == RB_EULER)
             hipLaunchKernelGGL((msj_step_env_per_lane<0, B>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream,
-                               s->c8, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
+                               s->c8, s->d_q, s->d_qd, s->d_feas, s->d_infeas_n, d_act, act_scale, n);
         else
             hipLaunchKernelGGL((msj_step_env_per_lane<1, B>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream,
-                               s->c8, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
+                               s->c8, s->d_q, s->d_qd, s->d_feas, s->d_infeas_n, d_act, act_scale, n);
     } else {
         constexpr int B = 256;
         if (s->integrator == RB_EULER)
             hipLaunchKernelGGL((msj_step_env_per_lane<0, B>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream,
-                               s->c8, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
+                               s->c8, s->d_q, s->d_qd, s->d_feas, s->d_infeas_n, d_act, act_scale, n);
         else
             hipLaunchKernelGGL((msj_step_env_per_lane<1, B>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream,
-                               s->c8, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
+                               s->c8, s->d_q, s->d_qd, s->d_feas, s->d_infeas_n, d_act, act_scale, n);
     }
     RB_HIP(hipGetLastError());
     return RB_OK;
@@ -271,6 +447,9 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
     RB_TRY(hipMalloc(&s->d_rows, plane * width));
     RB_TRY(hipMalloc(&s->d_u8, size_t(n_envs)));
     RB_TRY(hipMemsetAsync(s->d_goal_count, 0, sizeof(uint32_t) * size_t(n_envs), s->stream));
+    RB_TRY(hipMalloc(&s->d_infeas_n, sizeof(uint32_t) * size_t(n_envs)));
+    RB_TRY(hipMemsetAsync(s->d_infeas_n, 0, sizeof(uint32_t) * size_t(n_envs), s->stream));
+    RB_TRY(hipMalloc(&s->d_stats, sizeof(double) * 8));
 #undef RB_TRY
     *out = s;
     rc = rb_reset(s, nullptr);
@@ -285,6 +464,8 @@ void rb_destroy(rb_sim *s) {
     for (auto &kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     (void)hipFree(s->d_q); (void)hipFree(s->d_qd); (void)hipFree(s->d_feas);
     (void)hipFree(s->d_goal_count); (void)hipFree(s->d_rows); (void)hipFree(s->d_u8);
+    (void)hipFree(s->d_goal); (void)hipFree(s->d_ep_ret); (void)hipFree(s->d_ep_acc);
+    (void)hipFree(s->d_step_num); (void)hipFree(s->d_infeas_n); (void)hipFree(s->d_stats);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     delete s;
 }
@@ -367,6 +548,7 @@ int rb_step(rb_sim *s, const float *act, float act_scale, float *q, float *qd, u
     RB_HIP(hipMemcpyAsync(s->d_rows, act, sizeof(float) * s->n * s->n_t, hipMemcpyHostToDevice, s->stream));
     int rc = launch_step(s, s->d_rows, act_scale);
     if (rc) return rc;
+    s->env_steps += double(s->n);
     RB_HIP(hipStreamSynchronize(s->stream));   // d_rows is reused by the read-back
     return read_state_host(s, q, qd, feasible);
 }
@@ -399,6 +581,7 @@ int rb_state_ptrs(rb_sim *s, float **d_q, float **d_qd, uint32_t **d_feasible) {
 int rb_step_dev(rb_sim *s, const float *d_act, float act_scale) {
     if (check(s) || !d_act) return fail(RB_EINVAL, "null argument");
     if (reinterpret_cast<uintptr_t>(d_act) % 16) return fail(RB_EINVAL, "action slab must be 16-byte aligned");
+    s->env_steps += double(s->n);
     return launch_step(s, d_act, act_scale);
 }
 
@@ -409,9 +592,9 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
     const size_t slab = size_t(s->n) * s->n_t;
     int t = 0;
     if (use_graph) {
-        int chunk = ring;
-        while (chunk < 32) chunk += ring;
-        if (n_steps >= chunk) {
+        // one graph of up to 128 per-step kernel nodes (a whole number of ring turns)
+        const int chunk = ((n_steps < 128 ? n_steps : 128) / ring) * ring;
+        if (chunk >= 8) {
             rb_sim::GraphKey key;
             std::memset(&key, 0, sizeof(key));
             key.ring_ptr = d_ring; key.ring = ring; key.chunk = chunk; key.scale = act_scale; key.kernel = s->kernel;
@@ -437,6 +620,7 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
         int rc = launch_step(s, d_ring + size_t(t % ring) * slab, act_scale);
         if (rc) return rc;
     }
+    s->env_steps += double(s->n) * n_steps;
     return RB_OK;
 }
 
@@ -456,10 +640,99 @@ int rb_sample_goals_dev(rb_sim *s, const uint8_t *d_mask, float *d_goal_q) {
     return RB_OK;
 }
 
-int rb_env_configure(rb_sim *, const rb_env_config *) { return fail(RB_EUNSUPPORTED, "fused env layer not built yet"); }
-int rb_env_reset_dev(rb_sim *, float *) { return fail(RB_EUNSUPPORTED, "fused env layer not built yet"); }
-int rb_env_step_dev(rb_sim *, const float *, float *, float *, uint32_t *) { return fail(RB_EUNSUPPORTED, "fused env layer not built yet"); }
-int rb_env_stats(rb_sim *, double *, int) { return fail(RB_EUNSUPPORTED, "fused env layer not built yet"); }
+int rb_env_configure(rb_sim *s, const rb_env_config *cfg) {
+    if (check(s) || !cfg) return fail(RB_EINVAL, "null argument");
+    if (s->n_q != 3 || s->n_t != NT8) return fail(RB_EUNSUPPORTED, "fused env layer is built for 3-DOF / 8-tendon robots");
+    if (cfg->max_episode_length < 1) return fail(RB_EINVAL, "max_episode_length must be >= 1");
+    if (!(cfg->angle_hi > cfg->angle_lo) || !(cfg->vel_hi > cfg->vel_lo) || !(cfg->action_hi > cfg->action_lo))
+        return fail(RB_EINVAL, "empty box in env config");
+    RB_HIP(hipSetDevice(s->device));
+    EnvParams &e = s->env;
+    e.vel_penalty = cfg->joint_vel_penalty != 0; e.bonus = cfg->goal_bonus != 0;
+    e.max_len = cfg->max_episode_length; e.auto_reset = cfg->auto_reset != 0;
+    e.penalty = cfg->penalty_boundary; e.bonus_val = cfg->bonus_goal;
+    e.a_lo = cfg->angle_lo; e.a_hi = cfg->angle_hi; e.v_lo = cfg->vel_lo; e.v_hi = cfg->vel_hi;
+    e.act_hi = cfg->action_hi;
+    // (out.high - out.low) / (in.high - in.low) evaluated in fp32 like the reference's float32 Boxes
+    e.slope = (cfg->action_hi - cfg->action_lo) / (1.0f - (-1.0f));
+    e.tol_a = cfg->goal_angle_tol; e.tol_v = cfg->goal_vel_tol;
+    if (!s->d_goal) {
+        const size_t plane = sizeof(float) * size_t(s->n);
+        RB_HIP(hipMalloc(&s->d_goal, plane * s->n_q));
+        RB_HIP(hipMalloc(&s->d_ep_ret, plane));
+        RB_HIP(hipMalloc(&s->d_step_num, sizeof(uint32_t) * size_t(s->n)));
+        RB_HIP(hipMalloc(&s->d_ep_acc, plane * 5));
+    }
+    RB_HIP(hipMemsetAsync(s->d_ep_acc, 0, sizeof(float) * size_t(s->n) * 5, s->stream));
+    RB_HIP(hipMemsetAsync(s->d_infeas_n, 0, sizeof(uint32_t) * size_t(s->n), s->stream));
+    s->env_steps = 0.0;
+    s->env_ready = true;
+    return rb_env_reset_dev(s, nullptr);
+}
+
+int rb_env_reset_dev(rb_sim *s, float *d_obs) {
+    if (check(s)) return RB_EINVAL;
+    if (!s->env_ready) return fail(RB_EINVAL, "rb_env_configure has not been called");
+    hipLaunchKernelGGL(env_reset_kernel, dim3(blocks_for(s->n, 256)), dim3(256), 0, s->stream,
+                       s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, s->d_ep_ret,
+                       s->d_goal_count, d_obs, s->n, s->seed, uint64_t(s->env0));
+    RB_HIP(hipGetLastError());
+    return RB_OK;
+}
+
+int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward, uint32_t *d_done) {
+    if (check(s) || !d_act || !d_obs || !d_reward || !d_done) return fail(RB_EINVAL, "null argument");
+    if (!s->env_ready) return fail(RB_EINVAL, "rb_env_configure has not been called");
+    if (reinterpret_cast<uintptr_t>(d_act) % 16) return fail(RB_EINVAL, "action slab must be 16-byte aligned");
+    const long n = s->n;
+#define RB_ENV_LAUNCH(INTEG, B)                                                                          \
+    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream,  \
+                       s->c8, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num,      \
+                       s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done, s->d_ep_acc,       \
+                       s->d_infeas_n, n,                                                                \
+                       s->seed, uint64_t(s->env0))
+    if (n <= 65536) { if (s->integrator == RB_EULER) RB_ENV_LAUNCH(0, 64); else RB_ENV_LAUNCH(1, 64); }
+    else            { if (s->integrator == RB_EULER) RB_ENV_LAUNCH(0, 256); else RB_ENV_LAUNCH(1, 256); }
+#undef RB_ENV_LAUNCH
+    RB_HIP(hipGetLastError());
+    s->env_steps += double(n);
+    return RB_OK;
+}
+
+static int stats_launch(rb_sim *s, int reset) {
+    RB_HIP(hipMemsetAsync(s->d_stats, 0, sizeof(double) * 8, s->stream));
+    unsigned g = blocks_for(s->n, 256);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(stats_reduce_kernel, dim3(g), dim3(256), 0, s->stream,
+                       s->env_ready ? s->d_ep_acc : nullptr, s->d_ep_ret, s->d_infeas_n, s->d_stats,
+                       s->env_steps, s->n);
+    RB_HIP(hipGetLastError());
+    (void)reset;
+    return RB_OK;
+}
+static int stats_reset(rb_sim *s) {
+    if (s->env_ready) RB_HIP(hipMemsetAsync(s->d_ep_acc, 0, sizeof(float) * size_t(s->n) * 5, s->stream));
+    RB_HIP(hipMemsetAsync(s->d_infeas_n, 0, sizeof(uint32_t) * size_t(s->n), s->stream));
+    s->env_steps = 0.0;
+    return RB_OK;
+}
+
+int rb_env_stats_dev(rb_sim *s, double *d_stats8, int reset) {
+    if (check(s) || !d_stats8) return fail(RB_EINVAL, "null argument");
+    int rc = stats_launch(s, reset);
+    if (rc) return rc;
+    RB_HIP(hipMemcpyAsync(d_stats8, s->d_stats, sizeof(double) * 8, hipMemcpyDeviceToDevice, s->stream));
+    return reset ? stats_reset(s) : RB_OK;
+}
+
+int rb_env_stats(rb_sim *s, double *stats8, int reset) {
+    if (check(s) || !stats8) return fail(RB_EINVAL, "null argument");
+    int rc = stats_launch(s, reset);
+    if (rc) return rc;
+    RB_HIP(hipMemcpyAsync(stats8, s->d_stats, sizeof(double) * 8, hipMemcpyDeviceToHost, s->stream));
+    RB_HIP(hipStreamSynchronize(s->stream));
+    return reset ? stats_reset(s) : RB_OK;
+}
 
 int rb_malloc(rb_sim *s, int64_t bytes, void **d_ptr) {
     if (check(s) || !d_ptr || bytes < 0) return fail(RB_EINVAL, "bad argument");

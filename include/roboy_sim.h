@@ -103,12 +103,17 @@ typedef struct rb_env_config {
     int32_t joint_vel_penalty;      /* roboy_env.py:13                        */
     int32_t goal_bonus;             /* is_agent_getting_bonus_for_reaching_goal */
     int32_t max_episode_length;     /* 400, roboy_env.py:28                   */
-    int32_t _pad;
+    int32_t auto_reset;             /* 1: on done also reset the env, as the
+                                       reference's SubprocVecEnv workers do
+                                       (train_parallel.py:29); 0: RoboyEnv.step
+                                       alone (goal resampled only, :67-68)    */
     float penalty_boundary;         /* 1,    roboy_env.py:26                  */
     float bonus_goal;               /* 1000, roboy_env.py:27                  */
     float angle_lo, angle_hi;       /* joint-angle box (msj_robot.py:9)       */
     float vel_lo, vel_hi;           /* joint-velocity box (msj_robot.py:10)   */
     float action_lo, action_hi;     /* tendon set-point box (msj_robot.py:16) */
+    float goal_angle_tol;           /* _MAX_DISTANCE_JOINT_ANGLE / 200 (:127) */
+    float goal_vel_tol;             /* _MAX_DISTANCE_JOINT_VELS / 5    (:130) */
 } rb_env_config;
 
 const char *rb_last_error(void);
@@ -157,9 +162,13 @@ int rb_env_configure(rb_sim *sim, const rb_env_config *cfg);
 int rb_env_reset_dev(rb_sim *sim, float *d_obs /* [n_envs][3 n_q] */);
 int rb_env_step_dev(rb_sim *sim, const float *d_act /* [n_envs][n_t] in [-1,1] */,
                     float *d_obs, float *d_reward, uint32_t *d_done);
-/* sums over envs since the last call: [sum r, sum r^2, n_steps, n_episodes,
- * sum episode length, n_goal_reached, n_infeasible_steps, 0] (fp64, host) */
+/* episode statistics summed over this handle's envs since the last reset of
+ * the accumulators: [sum episode return, sum return^2, n_episodes, sum episode
+ * length, n_goal_reached, n_infeasible_env_steps, n_env_steps, sum reward]
+ * (fp64).  The _dev form copies them into caller-owned device memory (e.g. a
+ * torch tensor that is then all-reduced over RCCL); the host form synchronises. */
 int rb_env_stats(rb_sim *sim, double *stats8, int reset);
+int rb_env_stats_dev(rb_sim *sim, double *d_stats8, int reset);
 
 /* device memory helpers so a ctypes caller needs no HIP binding of its own */
 int rb_malloc(rb_sim *sim, int64_t bytes, void **d_ptr);

@@ -1,0 +1,169 @@
+"""GPU parity of the fused env layer (rb_env_step_dev) against the reference's
+formulas.
+
+The host model below replays, for every env, exactly what the reference does
+around a simulator (``RoboyEnv.step`` roboy_env.py:51-70 inside a
+``SubprocVecEnv`` worker that calls ``env.reset()`` on done): it uses the
+plain physics kernel for the state (same kernels, so q/qd/goal must match the
+fused kernel BIT FOR BIT), ``oracle/philox_np.py`` for the goal stream and
+``gym_roboy_amd/envs/reward.py`` (pinned to the reference by tests/golden) in
+float64 for reward/done.  Reward is float arithmetic: rtol 2e-5 / atol 2e-4 on
+values up to |r| ~ 33 (fp32 exp of a fp32 norm).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class HostEnvModel:
+    def __init__(self, robot, n, seed, max_len, vel_penalty, bonus, auto_reset):
+        from gym_roboy_amd.envs.simulations import HipBatchSimulation
+        from gym_roboy_amd.envs import reward as rw
+        self.rw = rw
+        self.robot, self.n, self.seed = robot, n, seed
+        self.sim = HipBatchSimulation(robot, n, seed=seed)
+        self.desc = robot.get_description()
+        self.max_len, self.vel_penalty, self.bonus, self.auto_reset = max_len, vel_penalty, bonus, auto_reset
+        self.angles, self.vels, self.acts = (robot.get_joint_angles_space(), robot.get_joint_vels_space(),
+                                             robot.get_action_space())
+        self.max_da = rw.l2_distance(self.angles.low, self.angles.high)
+        self.max_dv = rw.l2_distance(self.vels.low, self.vels.high)
+        self.draws = np.zeros(n, np.uint32)
+        self.ids = np.arange(n, dtype=np.uint64)
+        self.step_num = np.ones(n, np.int64)
+        self.goal = self._draw(np.ones(n, bool))
+
+    def _draw(self, mask):
+        from oracle import philox_np as ph
+        g = np.zeros((self.n, 3), np.float32)
+        idx = np.nonzero(mask)[0]
+        for d in np.unique(self.draws[idx]):
+            sel = idx[self.draws[idx] == d]
+            g[sel] = ph.goals(self.seed, self.ids[sel], int(d), self.desc.q_lo.astype(np.float32),
+                              self.desc.q_hi.astype(np.float32))
+        self.draws[idx] += 1
+        return g
+
+    def step(self, action):
+        rw = self.rw
+        one = np.ones(8, np.float32)
+        sp = rw.rescale_between_boxes(action.astype(np.float32), -one, one, self.acts.low, self.acts.high)
+        q, qd, feas = self.sim.forward_step_command(sp.astype(np.float32))
+        self.step_num += 1
+        obs = np.concatenate([q, qd, self.goal], axis=1)
+        q64, qd64, g64 = q.astype(np.float64), qd.astype(np.float64), self.goal.astype(np.float64)
+        zero = np.zeros_like(qd64)
+        reward = rw.compute_reward(q64, qd64, feas, g64, zero, (self.angles.low, self.angles.high),
+                                   (self.vels.low, self.vels.high), self.max_da, self.max_dv,
+                                   self.vel_penalty, self.bonus)
+        dist_a = rw.l2_distance(q64, g64)
+        dist_v = rw.l2_distance(qd64, zero)
+        reached = (dist_a < self.max_da / 200) & (dist_v < self.max_dv / 5)
+        done = reached | (self.step_num > self.max_len)
+        margin = np.minimum(np.abs(dist_a - self.max_da / 200), np.abs(dist_v - self.max_dv / 5))
+        if done.any():
+            new_goal = self._draw(done)
+            self.goal = np.where(done[:, None], new_goal, self.goal)
+            if self.auto_reset:
+                self.sim.forward_reset_command(done)
+                self.step_num[done] = 1
+                new_goal = self._draw(done)
+                self.goal = np.where(done[:, None], new_goal, self.goal)
+                obs[done, :6] = 0.0
+                obs[done, 6:] = self.goal[done]
+        return obs, reward, done, margin
+
+
+@pytest.mark.parametrize("auto_reset", [True, False])
+@pytest.mark.parametrize("vel_penalty", [False, True])
+def test_fused_env_step_matches_host_replay(msj_robot, auto_reset, vel_penalty):
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    n, seed, max_len = 777, 5, 12
+    vec = RoboyVecEnv(msj_robot, n, seed=seed, joint_vel_penalty=vel_penalty, auto_reset=auto_reset,
+                      max_episode_length=max_len)
+    host = HostEnvModel(msj_robot, n, seed, max_len, vel_penalty, True, auto_reset)
+    obs0 = vec.reset()
+    # vec.__init__ drew goal 0 (configure), reset() drew goal 1: mirror RoboyEnv(...) then reset()
+    host.goal = host._draw(np.ones(n, bool))
+    assert np.array_equal(obs0[:, :6], np.zeros((n, 6), np.float32))
+    assert np.array_equal(obs0[:, 6:], host.goal)
+    rng = np.random.default_rng(0)
+    n_done = 0
+    for t in range(40):
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        if t % 7 == 3:
+            a[: n // 2] = 0.0
+        obs, rew, done, _ = vec.step(a)
+        h_obs, h_rew, h_done, margin = host.step(a)
+        clear = margin > 1e-5
+        assert np.array_equal(done[clear], h_done[clear])
+        same = done == h_done
+        assert np.array_equal(obs[same], h_obs[same].astype(np.float32))
+        np.testing.assert_allclose(rew[same], h_rew[same], rtol=2e-5, atol=2e-4)
+        assert same.all(), "done flags diverged on a borderline env; host replay is no longer in step"
+        n_done += int(done.sum())
+    assert n_done >= n   # every env hit the 12-step episode limit at least once
+    st = vec.stats()
+    assert st["n_env_steps"] == 40 * n
+    assert st["n_episodes"] == n_done
+    vec.close(); host.sim.close()
+
+
+def _heavy_robot():
+    """MsjRobot whose actuators are so heavy that one step does not move it:
+    lets a test park the state exactly on the goal."""
+    from gym_roboy_amd.envs.robots import MsjRobot, RobotDescription, msj_platform_spec
+    spec = msj_platform_spec()
+    for j in spec["joints"]:
+        j["armature"] = 1.0e6
+    desc = RobotDescription(spec)
+
+    class HeavyMsjRobot(MsjRobot):
+        @classmethod
+        def get_description(cls):
+            return desc
+    return HeavyMsjRobot()
+
+
+def test_reaching_the_goal_gives_bonus_and_done():
+    """roboy_env.py:104-107 / test_roboy_env.py:60-68: at the goal with zero
+    action the reward is the maximum, -exp(0) + 1000 = 999."""
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    n = 64
+    vec = RoboyVecEnv(_heavy_robot(), n, seed=1, auto_reset=False)
+    obs = vec.reset()
+    goal = obs[:, 6:9].copy()
+    vec.sim.set_state(goal, np.zeros((n, 3), np.float32))
+    obs, rew, done, _ = vec.step(np.zeros((n, 8), np.float32))
+    assert np.abs(obs[:, :3] - goal).max() < 1e-4
+    assert done.all()
+    np.testing.assert_allclose(rew, 999.0, atol=1e-2)
+    assert not np.array_equal(obs[:, 6:9], vec.step(np.zeros((n, 8), np.float32))[0][:, 6:9])  # goal was resampled
+    st = vec.stats()
+    assert st["n_goal_reached"] >= n
+    # moving at the goal is not "reached" (test_roboy_env.py:71-79)
+    obs = vec.reset()
+    goal = obs[:, 6:9].copy()
+    fast = np.tile(vec.robot.get_joint_vels_space().high, (n, 1)).astype(np.float32)
+    vec.sim.set_state(goal, fast)
+    _, rew, done, _ = vec.step(np.zeros((n, 8), np.float32))
+    assert not done.any() and np.all(rew < 0)
+    vec.close()
+
+
+def test_torch_tensor_path_is_zero_copy_and_equal(msj_robot):
+    import torch
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    n = 2048
+    a = np.random.default_rng(3).uniform(-1, 1, (n, 8)).astype(np.float32)
+    v1 = RoboyVecEnv(msj_robot, n, seed=9)
+    v2 = RoboyVecEnv(msj_robot, n, seed=9)
+    v1.reset(); v2.reset()
+    o1, r1, d1, _ = v1.step(a)
+    o2, r2, d2, _ = v2.step(torch.from_numpy(a).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(o1, o2.cpu().numpy())
+    assert np.array_equal(r1, r2.cpu().numpy())
+    assert np.array_equal(d1, d2.cpu().numpy())
+    v1.close(); v2.close()

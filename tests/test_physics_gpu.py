@@ -179,3 +179,31 @@ def test_unsupported_robot_is_refused_loudly(msj_robot):
             return RobotDescription(spec)
     with pytest.raises(NativeError, match="no HIP kernel"):
         HipBatchSimulation(Odd(), 4)
+
+
+def test_random_streams_match_the_numpy_restatement_bit_for_bit(msj_robot):
+    """Device Philox streams (synthetic actions, goals) vs oracle/philox_np.py,
+    which is itself pinned to the Random123 known-answer vectors."""
+    from oracle import philox_np as ph
+    n, seed, off = 1000, 0x1234567890ABCDEF, (1 << 33) + 17
+    sim = _sim(msj_robot, n, seed=seed, env_id_offset=off)
+    ids = np.arange(off, off + n, dtype=np.uint64)
+    d_act = sim.malloc(4 * n * 8)
+    for step in (0, 1, 4000000000):
+        sim.fill_actions_dev(d_act, step)
+        sim.synchronize()
+        got = sim.download(d_act, (n, 8))
+        want = ph.actions(seed, ids, step, 8)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert got.min() >= -1.0 and got.max() < 1.0
+    desc = msj_robot.get_description()
+    lo, hi = desc.q_lo.astype(np.float32), desc.q_hi.astype(np.float32)
+    seen = []
+    for draw in range(3):
+        got = sim.get_new_goal_joint_angles()
+        want = ph.goals(seed, ids, draw, lo, hi)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert np.all(got >= lo) and np.all(got <= hi)
+        seen.append(got)
+    assert not np.allclose(seen[0], seen[1]) and not np.allclose(seen[1], seen[2])
+    sim.close()
