@@ -150,7 +150,9 @@ class RoboyEnv(BaseGoalEnv):
 
 
 def _l2_distance(joint_angle1, joint_angle2):
-    return float(rw.l2_distance(joint_angle1, joint_angle2))
+    # numpy scalar of the inputs' dtype, as in the reference: the goal
+    # thresholds derived from it (:127,:130) are therefore float32 values
+    return rw.l2_distance(joint_angle1, joint_angle2)
 
 
 def _rescale_from_one_space_to_other(input_val: np.ndarray, input_space, output_space) -> np.ndarray:

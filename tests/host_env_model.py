@@ -1,0 +1,105 @@
+"""TEST HELPER: host replay of what the reference does around a simulator for a
+batch of envs - ``RoboyEnv.step`` (roboy_env.py:51-70) inside a SubprocVecEnv
+worker that calls ``env.reset()`` on done (train_parallel.py:29) - with the
+physics delegated to a `stepper` (the plain HIP kernel on the GPU box, the C
+oracle on CPU), goals from oracle/philox_np.py and reward/done from
+gym_roboy_amd/envs/reward.py in float64."""
+import numpy as np
+
+from gym_roboy_amd.envs import reward as rw
+from oracle import philox_np as ph
+
+
+class HipStepper:
+    def __init__(self, robot, n, seed, env_id_offset=0):
+        from gym_roboy_amd.envs.simulations import HipBatchSimulation
+        self.sim = HipBatchSimulation(robot, n, seed=seed, env_id_offset=env_id_offset)
+
+    def step(self, sp):
+        return self.sim.forward_step_command(sp)
+
+    def reset(self, mask):
+        self.sim.forward_reset_command(mask)
+
+    def close(self):
+        self.sim.close()
+
+
+class COracleStepper:
+    def __init__(self, robot, n):
+        from oracle.c_oracle import COracle
+        self.orc = COracle(robot.get_description(), "f32")
+        self.q = np.zeros((n, 3), np.float32)
+        self.qd = np.zeros((n, 3), np.float32)
+        self.f = np.ones(n, np.uint8)
+
+    def step(self, sp):
+        self.orc.step_inplace(self.q, self.qd, np.ascontiguousarray(sp, dtype=np.float32), self.f)
+        return self.q.copy(), self.qd.copy(), self.f.astype(bool)
+
+    def reset(self, mask):
+        self.q[mask] = 0; self.qd[mask] = 0; self.f[mask] = 1
+
+    def close(self):
+        pass
+
+
+class HostEnvModel:
+    def __init__(self, robot, stepper, n, seed, max_len, vel_penalty, bonus, auto_reset, env_id_offset=0):
+        self.robot, self.n, self.seed, self.stepper = robot, n, seed, stepper
+        self.desc = robot.get_description()
+        self.max_len, self.vel_penalty, self.bonus, self.auto_reset = max_len, vel_penalty, bonus, auto_reset
+        self.angles, self.vels, self.acts = (robot.get_joint_angles_space(), robot.get_joint_vels_space(),
+                                             robot.get_action_space())
+        self.max_da = rw.l2_distance(self.angles.low, self.angles.high)
+        self.max_dv = rw.l2_distance(self.vels.low, self.vels.high)
+        self.draws = np.zeros(n, np.uint32)
+        self.ids = np.arange(env_id_offset, env_id_offset + n, dtype=np.uint64)
+        self.step_num = np.ones(n, np.int64)
+        self.ep_ret = np.zeros(n)
+        self.stats = np.zeros(8)
+        self.goal = self.draw(np.ones(n, bool))
+
+    def draw(self, mask):
+        g = np.zeros((self.n, 3), np.float32)
+        idx = np.nonzero(mask)[0]
+        for d in np.unique(self.draws[idx]):
+            sel = idx[self.draws[idx] == d]
+            g[sel] = ph.goals(self.seed, self.ids[sel], int(d), self.desc.q_lo.astype(np.float32),
+                              self.desc.q_hi.astype(np.float32))
+        self.draws[idx] += 1
+        return g
+
+    def step(self, action):
+        one = np.ones(8, np.float32)
+        sp = rw.rescale_between_boxes(action.astype(np.float32), -one, one, self.acts.low, self.acts.high)
+        q, qd, feas = self.stepper.step(sp.astype(np.float32))
+        self.step_num += 1
+        obs = np.concatenate([q, qd, self.goal], axis=1)
+        q64, qd64, g64 = q.astype(np.float64), qd.astype(np.float64), self.goal.astype(np.float64)
+        zero = np.zeros_like(qd64)
+        reward = rw.compute_reward(q64, qd64, feas, g64, zero, (self.angles.low, self.angles.high),
+                                   (self.vels.low, self.vels.high), self.max_da, self.max_dv,
+                                   self.vel_penalty, self.bonus)
+        dist_a = rw.l2_distance(q64, g64)
+        dist_v = rw.l2_distance(qd64, zero)
+        reached = (dist_a < self.max_da / 200) & (dist_v < self.max_dv / 5)
+        done = reached | (self.step_num > self.max_len)
+        margin = np.minimum(np.abs(dist_a - self.max_da / 200), np.abs(dist_v - self.max_dv / 5))
+        self.ep_ret += reward
+        s = self.stats
+        s[5] += np.sum(~feas); s[6] += self.n; s[7] += reward.sum()
+        if done.any():
+            s[0] += self.ep_ret[done].sum(); s[1] += (self.ep_ret[done] ** 2).sum(); s[2] += done.sum()
+            s[3] += (self.step_num[done] - 1).sum(); s[4] += reached.sum()
+            self.ep_ret[done] = 0.0
+            new_goal = self.draw(done)
+            self.goal = np.where(done[:, None], new_goal, self.goal)
+            if self.auto_reset:
+                self.stepper.reset(done)
+                self.step_num[done] = 1
+                new_goal = self.draw(done)
+                self.goal = np.where(done[:, None], new_goal, self.goal)
+                obs[done, :6] = 0.0
+                obs[done, 6:] = self.goal[done]
+        return obs, reward, done, margin

@@ -16,63 +16,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-class HostEnvModel:
-    def __init__(self, robot, n, seed, max_len, vel_penalty, bonus, auto_reset):
-        from gym_roboy_amd.envs.simulations import HipBatchSimulation
-        from gym_roboy_amd.envs import reward as rw
-        self.rw = rw
-        self.robot, self.n, self.seed = robot, n, seed
-        self.sim = HipBatchSimulation(robot, n, seed=seed)
-        self.desc = robot.get_description()
-        self.max_len, self.vel_penalty, self.bonus, self.auto_reset = max_len, vel_penalty, bonus, auto_reset
-        self.angles, self.vels, self.acts = (robot.get_joint_angles_space(), robot.get_joint_vels_space(),
-                                             robot.get_action_space())
-        self.max_da = rw.l2_distance(self.angles.low, self.angles.high)
-        self.max_dv = rw.l2_distance(self.vels.low, self.vels.high)
-        self.draws = np.zeros(n, np.uint32)
-        self.ids = np.arange(n, dtype=np.uint64)
-        self.step_num = np.ones(n, np.int64)
-        self.goal = self._draw(np.ones(n, bool))
-
-    def _draw(self, mask):
-        from oracle import philox_np as ph
-        g = np.zeros((self.n, 3), np.float32)
-        idx = np.nonzero(mask)[0]
-        for d in np.unique(self.draws[idx]):
-            sel = idx[self.draws[idx] == d]
-            g[sel] = ph.goals(self.seed, self.ids[sel], int(d), self.desc.q_lo.astype(np.float32),
-                              self.desc.q_hi.astype(np.float32))
-        self.draws[idx] += 1
-        return g
-
-    def step(self, action):
-        rw = self.rw
-        one = np.ones(8, np.float32)
-        sp = rw.rescale_between_boxes(action.astype(np.float32), -one, one, self.acts.low, self.acts.high)
-        q, qd, feas = self.sim.forward_step_command(sp.astype(np.float32))
-        self.step_num += 1
-        obs = np.concatenate([q, qd, self.goal], axis=1)
-        q64, qd64, g64 = q.astype(np.float64), qd.astype(np.float64), self.goal.astype(np.float64)
-        zero = np.zeros_like(qd64)
-        reward = rw.compute_reward(q64, qd64, feas, g64, zero, (self.angles.low, self.angles.high),
-                                   (self.vels.low, self.vels.high), self.max_da, self.max_dv,
-                                   self.vel_penalty, self.bonus)
-        dist_a = rw.l2_distance(q64, g64)
-        dist_v = rw.l2_distance(qd64, zero)
-        reached = (dist_a < self.max_da / 200) & (dist_v < self.max_dv / 5)
-        done = reached | (self.step_num > self.max_len)
-        margin = np.minimum(np.abs(dist_a - self.max_da / 200), np.abs(dist_v - self.max_dv / 5))
-        if done.any():
-            new_goal = self._draw(done)
-            self.goal = np.where(done[:, None], new_goal, self.goal)
-            if self.auto_reset:
-                self.sim.forward_reset_command(done)
-                self.step_num[done] = 1
-                new_goal = self._draw(done)
-                self.goal = np.where(done[:, None], new_goal, self.goal)
-                obs[done, :6] = 0.0
-                obs[done, 6:] = self.goal[done]
-        return obs, reward, done, margin
+from host_env_model import HipStepper, HostEnvModel
 
 
 @pytest.mark.parametrize("auto_reset", [True, False])
@@ -82,10 +26,10 @@ def test_fused_env_step_matches_host_replay(msj_robot, auto_reset, vel_penalty):
     n, seed, max_len = 777, 5, 12
     vec = RoboyVecEnv(msj_robot, n, seed=seed, joint_vel_penalty=vel_penalty, auto_reset=auto_reset,
                       max_episode_length=max_len)
-    host = HostEnvModel(msj_robot, n, seed, max_len, vel_penalty, True, auto_reset)
+    host = HostEnvModel(msj_robot, HipStepper(msj_robot, n, seed), n, seed, max_len, vel_penalty, True, auto_reset)
     obs0 = vec.reset()
     # vec.__init__ drew goal 0 (configure), reset() drew goal 1: mirror RoboyEnv(...) then reset()
-    host.goal = host._draw(np.ones(n, bool))
+    host.goal = host.draw(np.ones(n, bool))
     assert np.array_equal(obs0[:, :6], np.zeros((n, 6), np.float32))
     assert np.array_equal(obs0[:, 6:], host.goal)
     rng = np.random.default_rng(0)
@@ -107,7 +51,10 @@ def test_fused_env_step_matches_host_replay(msj_robot, auto_reset, vel_penalty):
     st = vec.stats()
     assert st["n_env_steps"] == 40 * n
     assert st["n_episodes"] == n_done
-    vec.close(); host.sim.close()
+    got = np.array([st[k] for k in ("sum_return", "sum_return_sq", "n_episodes", "sum_length", "n_goal_reached",
+                                    "n_infeasible_steps", "n_env_steps", "sum_reward")])
+    np.testing.assert_allclose(got, host.stats, rtol=1e-4, atol=1e-2)
+    vec.close(); host.stepper.close()
 
 
 def _heavy_robot():
