@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="msj-4096-euler", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=None, help="override envs per GPU")
+    ap.add_argument("--substeps", type=int, default=None, help="override integrator substeps per env step")
     ap.add_argument("--no-graph", action="store_true", help="eager per-step launches instead of hipGraph replay")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -56,11 +57,12 @@ def parse():
     return ap.parse_args()
 
 
-def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world, dist):
+def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world, dist, substeps=None):
     """Returns dict(ms_per_step, value, kernel_us, ...) for this workload."""
     from gym_roboy_amd.envs.simulations import HipBatchSimulation
     n_envs, integrator, nsub, d_steps, d_warm, label = WORKLOADS[name]
     n_envs = envs or n_envs
+    nsub = substeps or nsub
     steps = steps or d_steps
     warmup = d_warm if warmup is None else warmup
     dev = torch.cuda.current_device()
@@ -188,7 +190,7 @@ def main():
     # stream capture is not allowed on the legacy default stream: run on a side stream
     with torch.cuda.stream(torch.cuda.Stream()):
         head = run_workload(torch, robot, args.workload, args.steps, args.warmup, args.envs, use_graph,
-                            rank, world, dist)
+                            rank, world, dist, args.substeps)
         if world == 1 and not args.no_also:
             for name in ("msj-262144-rk4", "msj-2097152-euler"):
                 if name != args.workload:

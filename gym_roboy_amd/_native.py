@@ -12,7 +12,8 @@ import numpy as np
 from .envs.robots.description import RobotDescriptionC
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libroboy_sim.so")
+# ROBOY_SIM_LIB lets kernel A/B experiments point at another build of the same ABI
+LIB_PATH = os.environ.get("ROBOY_SIM_LIB") or os.path.join(_HERE, "csrc", "libroboy_sim.so")
 
 RB_OK, RB_EINVAL, RB_EUNSUPPORTED, RB_EHIP, RB_ENOMEM = range(5)
 RB_EULER, RB_RK4 = 0, 1

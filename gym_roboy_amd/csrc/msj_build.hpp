@@ -62,10 +62,12 @@ int msj_build(const rb_robot_desc *d, double step_size, int nsub, MsjConst<T, NT
         const double moving0 = seglen(va, vb);   // R = I in the zero pose
         if (moving0 < 1e-6) { err = "degenerate tendon segment"; return RB_EINVAL; }
         const double l0 = lc + moving0;
-        for (int a = 0; a < 3; ++a) { c.A[k][a] = T(d->vp_pos[3 * va + a]); c.B[k][a] = T(d->vp_pos[3 * vb + a]); }
-        c.lc[k] = T(lc); c.l0[k] = T(l0); c.inv_l0[k] = T(1.0 / l0);
-        c.fmax[k] = T(d->f_max[k]);
-        c.inv_vl0[k] = T(1.0 / (d->v_max * l0));
+        MsjTendon<T> &t = c.ten[k];
+        for (int a = 0; a < 3; ++a) { t.A[a] = T(d->vp_pos[3 * va + a]); t.B[a] = T(d->vp_pos[3 * vb + a]); }
+        t.lc = T(lc); t.inv_l0 = T(1.0 / l0); t.sg_l0 = T(d->setpoint_scale / l0);
+        t.fmax = T(d->f_max[k]);
+        t.inv_vl0 = T(1.0 / (d->v_max * l0));
+        for (int a = 0; a < 5; ++a) t.pad[a] = T(0);
     }
     const double m = d->mass[2];
     const double *cm = d->com + 6, *ic = d->inertia + 12;
@@ -82,13 +84,14 @@ int msj_build(const rb_robot_desc *d, double step_size, int nsub, MsjConst<T, NT
         c.arm[a] = T(d->armature[a]); c.damp[a] = T(d->damping[a]);
         c.qlo[a] = T(d->q_lo[a]); c.qhi[a] = T(d->q_hi[a]); c.qdmax[a] = T(d->qd_max[a]);
     }
-    c.kp = T(d->kp); c.sigma = T(d->setpoint_scale);
-    c.inv_w2 = T(1.0 / (d->fl_width * d->fl_width));
-    c.kpe_e0 = T(d->kpe / d->e0);
+    const double log2e = 1.4426950408889634;
+    c.kp = T(d->kp);
+    c.fl_k2 = T(-log2e / (d->fl_width * d->fl_width));
+    c.pe_k2 = T(log2e * d->kpe / d->e0);
     c.inv_pe_den = T(1.0 / (std::exp(d->kpe) - 1.0));
     const double slope0 = 1.0 + 1.0 / d->fv_a;
     const double c2l = slope0 / (d->fv_n - 1.0);
-    c.fv_c1s = T(1.0); c.fv_c2s = T(-1.0 / d->fv_a);
+    c.fv_c2s = T(-1.0 / d->fv_a);
     c.fv_c1l = T(d->fv_n * c2l); c.fv_c2l = T(c2l);
     c.h = T(step_size / nsub); c.nsub = nsub;
     return RB_OK;

@@ -37,6 +37,7 @@
 #define RB_HD inline
 #endif
 
+
 namespace rb {
 
 // ---- scalar helpers: fast hardware forms on the device, libm on the host ----
@@ -44,6 +45,7 @@ template <typename T> struct Fast;
 template <> struct Fast<double> {
     static RB_HD void sincos(double x, double &s, double &c) { s = ::sin(x); c = ::cos(x); }
     static RB_HD double exp(double x) { return ::exp(x); }
+    static RB_HD double exp2(double x) { return ::exp2(x); }
     static RB_HD double rsqrt(double x) { return 1.0 / ::sqrt(x); }
     static RB_HD double rcp(double x) { return 1.0 / x; }
 };
@@ -60,6 +62,13 @@ template <> struct Fast<float> {
         return __expf(x);                       // v_exp_f32
 #else
         return ::expf(x);
+#endif
+    }
+    static RB_HD float exp2(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_exp2f(x);       // bare v_exp_f32
+#else
+        return ::exp2f(x);
 #endif
     }
     static RB_HD float rsqrt(float x) {
@@ -82,32 +91,55 @@ template <typename T> RB_HD T tmin(T a, T b) { return a < b ? a : b; }
 template <typename T> RB_HD T tmax(T a, T b) { return a > b ? a : b; }
 template <typename T> RB_HD T tclamp(T x, T lo, T hi) { return tmin(tmax(x, lo), hi); }
 
-// ---- per-robot constants (wave-uniform: live in SGPRs via the kernarg) ----
+// ---- per-robot constants (wave-uniform: fetched by scalar loads into SGPRs) ----
+// One 16-scalar record per tendon, so a rolled tendon loop needs a single
+// s_load_dwordx16 per trip and only ~16 SGPRs of tendon constants are live.
+template <typename T>
+struct alignas(64) MsjTendon {
+    T A[3];        // last base via-point, world = base frame
+    T B[3];        // first body via-point, body frame
+    T lc;          // summed length of the segments that do not move
+    T inv_l0;      // 1 / rest length
+    T sg_l0;       // setpoint_scale / rest length
+    T fmax;        // maximum isometric force
+    T inv_vl0;     // 1 / (v_max * rest length)
+    T pad[5];
+};
+
 template <typename T, int NT>
 struct MsjConst {
-    T A[NT][3];       // last base via-point, world = base frame
-    T B[NT][3];       // first body via-point, body frame
-    T lc[NT];         // summed length of the segments that do not move
-    T l0[NT];         // rest length (zero pose)
-    T inv_l0[NT];
-    T fmax[NT];
-    T inv_vl0[NT];    // 1 / (v_max * l0)
+    MsjTendon<T> ten[NT];
     T IO[6];          // inertia about the joint centre, body frame: xx,yy,zz,xy,xz,yz
     T mc[3];          // mass * centre of mass (body frame)
     T g[3];           // gravity, world
     T arm[3], damp[3], qlo[3], qhi[3], qdmax[3];
-    T kp, sigma, inv_w2, kpe_e0, inv_pe_den;
-    T fv_c1s, fv_c2s, fv_c1l, fv_c2l;
+    T kp;             // activation per unit of normalised length error
+    T fl_k2;          // -log2(e) / fl_width^2           (f_L  = exp2(fl_k2 * e^2))
+    T pe_k2;          // log2(e) * kpe / e0              (f_PE = (exp2(pe_k2 * e) - 1) * inv_pe_den)
+    T inv_pe_den;     // 1 / (exp(kpe) - 1)
+    T fv_c1l, fv_c2l; // lengthening branch of f_V; the shortening branch is (1 + v)/(1 + fv_c2s v)
+    T fv_c2s;
     T h;              // integrator substep
     int32_t nsub;
+};
+
+// set-points held in a per-lane register array (compile-time indices only)
+template <typename T, int NT>
+struct SpArray {
+    const T *v;
+    RB_HD T operator()(int k) const { return v[k]; }
 };
 
 template <typename T, int NT>
 struct MsjModel {
     using C = MsjConst<T, NT>;
 
-    // qdd = f(q, qd, set-points)
-    static RB_HD void accel(const C &c, const T q[3], const T qd[3], const T sp[NT], T qdd[3]) {
+    // qdd = f(q, qd, set-points).  UNROLL = unroll factor of the tendon loop
+    // (NT: straight-line code, most ILP; 1: rolled, fewest registers).
+    // SP: set-point source, sp(k) = set-point of tendon k (a register array for
+    // straight-line code, an LDS column for the rolled loop: see SpArray/SpLds)
+    template <int UNROLL, typename SP>
+    static RB_HD void accel(const C &c, const T q[3], const T qd[3], const SP &sp, T qdd[3]) {
         T s0, c0, s1, c1, s2, c2;
         Fast<T>::sincos(q[0], s0, c0);
         Fast<T>::sincos(q[1], s1, c1);
@@ -123,35 +155,39 @@ struct MsjModel {
 
         // ---- tendons: torque about the joint centre, body frame ----
         T tx = T(0), ty = T(0), tz = T(0);
-#pragma unroll
+        // software prefetch: the record of tendon k+1 is requested (scalar load)
+        // before the arithmetic of tendon k, so its latency is covered
+        MsjTendon<T> nxt = c.ten[0];
+#pragma unroll UNROLL
         for (int k = 0; k < NT; ++k) {
-            const T ax = r00 * c.A[k][0] + r10 * c.A[k][1] + r20 * c.A[k][2];
-            const T ay = r01 * c.A[k][0] + r11 * c.A[k][1] + r21 * c.A[k][2];
-            const T az = r02 * c.A[k][0] + r12 * c.A[k][1] + r22 * c.A[k][2];
-            const T dx = c.B[k][0] - ax, dy = c.B[k][1] - ay, dz = c.B[k][2] - az;
+            const MsjTendon<T> t = nxt;
+            nxt = c.ten[(k + 1) & (NT - 1)];
+            const T ax = r00 * t.A[0] + r10 * t.A[1] + r20 * t.A[2];
+            const T ay = r01 * t.A[0] + r11 * t.A[1] + r21 * t.A[2];
+            const T az = r02 * t.A[0] + r12 * t.A[1] + r22 * t.A[2];
+            const T dx = t.B[0] - ax, dy = t.B[1] - ay, dz = t.B[2] - az;
             const T d2 = dx * dx + dy * dy + dz * dz;
             const T inv = Fast<T>::rsqrt(d2);
-            const T len = d2 * inv + c.lc[k];
+            const T len = d2 * inv + t.lc;
             const T ux = dx * inv, uy = dy * inv, uz = dz * inv;
             // w = B x u
-            const T mx = c.B[k][1] * uz - c.B[k][2] * uy;
-            const T my = c.B[k][2] * ux - c.B[k][0] * uz;
-            const T mz = c.B[k][0] * uy - c.B[k][1] * ux;
+            const T mx = t.B[1] * uz - t.B[2] * uy;
+            const T my = t.B[2] * ux - t.B[0] * uz;
+            const T mz = t.B[0] * uy - t.B[1] * ux;
             const T ldot = wx * mx + wy * my + wz * mz;
-            // Hill-type muscle
-            const T ln = len * c.inv_l0[k];
-            const T err = (len - c.l0[k] - c.sigma * sp[k]) * c.inv_l0[k];
-            const T act = tclamp(c.kp * err, T(0), T(1));
-            const T e = ln - T(1);
-            const T fl = Fast<T>::exp(-(e * e) * c.inv_w2);
-            T v = ldot * c.inv_vl0[k];
-            const bool lengthening = v > T(0);
-            const T c1v = lengthening ? c.fv_c1l : c.fv_c1s;
-            const T c2v = lengthening ? c.fv_c2l : c.fv_c2s;
-            v = tmax(v, T(-1));
-            const T fv = tmax((T(1) + c1v * v) * Fast<T>::rcp(T(1) + c2v * v), T(0));
-            const T fpe = tmax((Fast<T>::exp(c.kpe_e0 * e) - T(1)) * c.inv_pe_den, T(0));
-            const T F = c.fmax[k] * (act * fl * fv + fpe);
+            // Hill-type muscle: e = l/l0 - 1, err = e - (sigma/l0) s
+            const T e = len * t.inv_l0 - T(1);
+            const T act = tclamp(c.kp * (e - t.sg_l0 * sp(k)), T(0), T(1));
+            const T fl = Fast<T>::exp2(c.fl_k2 * (e * e));
+            // f_V = (1 + c1 v)/(1 + c2 v) per branch, written branch-free with
+            // v+ = max(v,0) and v- = clamp(v,-1,0) (one of them is zero)
+            const T v = ldot * t.inv_vl0;
+            const T vp = tmax(v, T(0)), vm = tclamp(v, T(-1), T(0));
+            const T num = c.fv_c1l * vp + (T(1) + vm);
+            const T den = c.fv_c2l * vp + (c.fv_c2s * vm + T(1));
+            const T fv = num * Fast<T>::rcp(den);          // >= 0: num >= 0, den >= 1
+            const T fpe = tmax((Fast<T>::exp2(c.pe_k2 * e) - T(1)) * c.inv_pe_den, T(0));
+            const T F = t.fmax * (act * fl * fv + fpe);
             tx -= F * mx; ty -= F * my; tz -= F * mz;
         }
 
@@ -229,14 +265,14 @@ struct MsjModel {
     }
 
     // one env step = nsub integrator substeps with the set-points held
-    template <int INTEG>
-    static RB_HD bool step(const C &c, T q[3], T qd[3], const T sp[NT]) {
+    template <int INTEG, int UNROLL, typename SP>
+    static RB_HD bool step_sp(const C &c, T q[3], T qd[3], const SP &sp) {
         bool feasible = true;
         const T h = c.h;
         for (int sub = 0; sub < c.nsub; ++sub) {
             if (INTEG == 0) {          // semi-implicit Euler
                 T a[3];
-                accel(c, q, qd, sp, a);
+                accel<UNROLL>(c, q, qd, sp, a);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     qd[j] = tclamp(qd[j] + h * a[j], -c.qdmax[j], c.qdmax[j]);
@@ -246,19 +282,19 @@ struct MsjModel {
                 T k1q[3], k1v[3], k2q[3], k2v[3], k3q[3], k3v[3], k4q[3], k4v[3], qs[3], vs[3];
                 const T hh = T(0.5) * h;
                 sat(c, qd, k1q);
-                accel(c, q, k1q, sp, k1v);
+                accel<UNROLL>(c, q, k1q, sp, k1v);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) { qs[j] = q[j] + hh * k1q[j]; vs[j] = qd[j] + hh * k1v[j]; }
                 sat(c, vs, k2q);
-                accel(c, qs, k2q, sp, k2v);
+                accel<UNROLL>(c, qs, k2q, sp, k2v);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) { qs[j] = q[j] + hh * k2q[j]; vs[j] = qd[j] + hh * k2v[j]; }
                 sat(c, vs, k3q);
-                accel(c, qs, k3q, sp, k3v);
+                accel<UNROLL>(c, qs, k3q, sp, k3v);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) { qs[j] = q[j] + h * k3q[j]; vs[j] = qd[j] + h * k3v[j]; }
                 sat(c, vs, k4q);
-                accel(c, qs, k4q, sp, k4v);
+                accel<UNROLL>(c, qs, k4q, sp, k4v);
                 const T h6 = h * T(1.0 / 6.0);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
@@ -269,6 +305,11 @@ struct MsjModel {
             feasible = limit(c, q, qd) && feasible;
         }
         return feasible;
+    }
+
+    template <int INTEG, int UNROLL = NT>
+    static RB_HD bool step(const C &c, T q[3], T qd[3], const T sp[NT]) {
+        return step_sp<INTEG, UNROLL>(c, q, qd, SpArray<T, NT>{sp});
     }
 };
 

@@ -32,6 +32,9 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
             return fail(RB_EHIP, std::string(#call) + ": " + hipGetErrorString(e_));      \
     } while (0)
 
+#ifndef RB_SMALL_BATCH
+#define RB_SMALL_BATCH 65536   // <= this many envs: latency-oriented launch configuration
+#endif
 constexpr int NT8 = 8;
 using Const8 = rb::MsjConst<float, NT8>;
 
@@ -40,11 +43,20 @@ using Const8 = rb::MsjConst<float, NT8>;
 // One env per lane.  Loads: q, qd planes (dword per lane, 256 B contiguous per
 // wave and plane) and the env's 32-byte action record (two dwordx4).  Stores:
 // q', qd' planes and the feasibility word.  84 algorithmic bytes per env step.
-template <int INTEG, int BLOCK>
+// Set-points of one env staged as an LDS column: the rolled tendon loop reads
+// sp(k) with one ds_read_b32 instead of selecting among 8 registers with a
+// runtime index (7 v_cndmask + 14 SALU per trip before).  [NT8][BLOCK] floats,
+// lane-contiguous rows: conflict-free.
+struct SpLds {
+    const float *col;   // &lds[0][threadIdx.x]
+    int stride;         // BLOCK
+    __device__ __forceinline__ float operator()(int k) const { return col[k * stride]; }
+};
+
+template <int INTEG, int BLOCK, int UNROLL>
 __global__ void __launch_bounds__(BLOCK)
 msj_step_env_per_lane(const Const8 c, float *__restrict__ q, float *__restrict__ qd,
-                      uint32_t *__restrict__ feas, uint32_t *__restrict__ infeas_n,
-                      const float *__restrict__ act, float act_scale, long n) {
+                      uint32_t *__restrict__ feas, const float *__restrict__ act, float act_scale, long n) {
     const long i = long(blockIdx.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     float qq[3], vv[3], sp[NT8];
@@ -54,12 +66,21 @@ msj_step_env_per_lane(const Const8 c, float *__restrict__ q, float *__restrict__
     for (int j = 0; j < 3; ++j) { qq[j] = q[j * n + i]; vv[j] = qd[j * n + i]; }
     sp[0] = a0.x * act_scale; sp[1] = a0.y * act_scale; sp[2] = a0.z * act_scale; sp[3] = a0.w * act_scale;
     sp[4] = a1.x * act_scale; sp[5] = a1.y * act_scale; sp[6] = a1.z * act_scale; sp[7] = a1.w * act_scale;
-    const bool ok = rb::MsjModel<float, NT8>::template step<INTEG>(c, qq, vv, sp);
+    bool ok;
+    if (UNROLL >= NT8) {
+        ok = rb::MsjModel<float, NT8>::template step<INTEG, UNROLL>(c, qq, vv, sp);
+    } else {
+        __shared__ float lds_sp[NT8][BLOCK];
+#pragma unroll
+        for (int k = 0; k < NT8; ++k) lds_sp[k][threadIdx.x] = sp[k];
+        // each lane reads back only what it wrote: no barrier needed
+        ok = rb::MsjModel<float, NT8>::template step_sp<INTEG, UNROLL>(c, qq, vv, SpLds{&lds_sp[0][threadIdx.x], BLOCK});
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) { q[j * n + i] = qq[j]; qd[j * n + i] = vv[j]; }
     feas[i] = ok ? 1u : 0u;
-    if (!ok) infeas_n[i] += 1u;   // rare: feeds rb_env_stats, no traffic otherwise
 }
+
 
 __global__ void reset_kernel(float *q, float *qd, uint32_t *feas, const uint8_t *mask, int n_q, long n) {
     const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -162,7 +183,7 @@ __device__ __forceinline__ void draw_goal3(const GoalBox &box, uint64_t seed, ui
     for (int j = 0; j < 3; ++j) g[j] = goal_value(box.lo[j], box.hi[j], r.v[j]);
 }
 
-template <int INTEG, int BLOCK>
+template <int INTEG, int BLOCK, int UNROLL>
 __global__ void __launch_bounds__(BLOCK)
 msj_env_step_kernel(const Const8 c, const EnvParams e, const GoalBox box,
                     float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
@@ -187,7 +208,7 @@ msj_env_step_kernel(const Const8 c, const EnvParams e, const GoalBox box,
         const float x = fminf(fmaxf(a[k], -1.0f), 1.0f);
         sp[k] = mul_then_add(e.slope, x - 1.0f, e.act_hi);
     }
-    const bool ok = rb::MsjModel<float, NT8>::template step<INTEG>(c, qq, vv, sp);
+    const bool ok = rb::MsjModel<float, NT8>::template step<INTEG, UNROLL>(c, qq, vv, sp);
     uint32_t sn = step_num[i] + 1u;
 
     // reward (roboy_env.py:92-112), fp32
@@ -244,8 +265,8 @@ msj_env_step_kernel(const Const8 c, const EnvParams e, const GoalBox box,
 // rb_env_stats: block-reduce the per-env accumulators in fp64, one atomic per
 // block and statistic (runs once per reporting interval, not per step)
 __global__ void __launch_bounds__(256)
-stats_reduce_kernel(const float *ep_acc, const float *ep_ret, const uint32_t *infeas_n, double *out,
-                    double env_steps, long n) {
+stats_reduce_kernel(const float *ep_acc, const float *ep_ret, const uint32_t *infeas_n,
+                    const uint32_t *feas, double *out, double env_steps, long n) {
     __shared__ double sh[4][7];
     double v[7] = {0, 0, 0, 0, 0, 0, 0};
     for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n; i += long(gridDim.x) * 256) {
@@ -253,8 +274,10 @@ stats_reduce_kernel(const float *ep_acc, const float *ep_ret, const uint32_t *in
 #pragma unroll
             for (int k = 0; k < 5; ++k) v[k] += double(ep_acc[k * n + i]);
             v[6] += double(ep_ret[i]);
+            v[5] += double(infeas_n[i]);     // env layer: infeasible env-steps since the reset
+        } else {
+            v[5] += feas[i] ? 0.0 : 1.0;     // plain rollouts: envs flagged infeasible right now
         }
-        v[5] += double(infeas_n[i]);
     }
 #pragma unroll
     for (int k = 0; k < 7; ++k)
@@ -296,7 +319,7 @@ inline unsigned blocks_for(long n, int block) { return unsigned((n + block - 1) 
 
 // --------------------------------------------------------------------- handle
 struct rb_sim {
-    int device = 0;
+    int device = 0, n_cu = 256;
     long n = 0;
     int n_q = 0, n_t = 0;
     int integrator = 0, nsub = 1, kernel = RB_KERNEL_ENV_PER_LANE;
@@ -332,23 +355,19 @@ namespace {
 
 int launch_step(rb_sim *s, const float *d_act, float act_scale) {
     const long n = s->n;
-    if (n <= 65536) {   // few waves: spread one wave per workgroup over the CUs
-        constexpr int B = 64;
-        if (s->integrator == RB_EULER)
-            hipLaunchKernelGGL((msj_step_env_per_lane<0, B>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream,
-                               s->c8, s->d_q, s->d_qd, s->d_feas, s->d_infeas_n, d_act, act_scale, n);
-        else
-            hipLaunchKernelGGL((msj_step_env_per_lane<1, B>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream,
-                               s->c8, s->d_q, s->d_qd, s->d_feas, s->d_infeas_n, d_act, act_scale, n);
+    // Small batches are latency-bound (a few waves per CU): one wave per
+    // workgroup spread over the CUs, tendon loop fully unrolled for ILP.
+    // Large batches are VALU-issue-bound: rolled tendon loop (one 16-dword
+    // scalar load per trip, ~70 VGPRs, 7 waves/SIMD).  Measured: DESIGN.md §7.
+#define RB_STEP_LAUNCH(INTEG, B, U)                                                                   \
+    hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U>), dim3(blocks_for(n, B)), dim3(B), 0,      \
+                       s->stream, s->c8, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n)
+    if (n <= RB_SMALL_BATCH) {
+        if (s->integrator == RB_EULER) RB_STEP_LAUNCH(0, 64, 8); else RB_STEP_LAUNCH(1, 64, 8);
     } else {
-        constexpr int B = 256;
-        if (s->integrator == RB_EULER)
-            hipLaunchKernelGGL((msj_step_env_per_lane<0, B>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream,
-                               s->c8, s->d_q, s->d_qd, s->d_feas, s->d_infeas_n, d_act, act_scale, n);
-        else
-            hipLaunchKernelGGL((msj_step_env_per_lane<1, B>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream,
-                               s->c8, s->d_q, s->d_qd, s->d_feas, s->d_infeas_n, d_act, act_scale, n);
+        if (s->integrator == RB_EULER) RB_STEP_LAUNCH(0, 256, 1); else RB_STEP_LAUNCH(1, 256, 1);
     }
+#undef RB_STEP_LAUNCH
     RB_HIP(hipGetLastError());
     return RB_OK;
 }
@@ -436,6 +455,11 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
         }                                                                                 \
     } while (0)
     RB_TRY(hipSetDevice(device));
+    {
+        hipDeviceProp_t prop;
+        RB_TRY(hipGetDeviceProperties(&prop, device));
+        s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     RB_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
     s->stream = s->own_stream;
     const size_t plane = sizeof(float) * size_t(n_envs);
@@ -685,14 +709,14 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
     if (!s->env_ready) return fail(RB_EINVAL, "rb_env_configure has not been called");
     if (reinterpret_cast<uintptr_t>(d_act) % 16) return fail(RB_EINVAL, "action slab must be 16-byte aligned");
     const long n = s->n;
-#define RB_ENV_LAUNCH(INTEG, B)                                                                          \
-    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream,  \
+#define RB_ENV_LAUNCH(INTEG, B, U)                                                                       \
+    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, U>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream, \
                        s->c8, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num,      \
                        s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done, s->d_ep_acc,       \
                        s->d_infeas_n, n,                                                                \
                        s->seed, uint64_t(s->env0))
-    if (n <= 65536) { if (s->integrator == RB_EULER) RB_ENV_LAUNCH(0, 64); else RB_ENV_LAUNCH(1, 64); }
-    else            { if (s->integrator == RB_EULER) RB_ENV_LAUNCH(0, 256); else RB_ENV_LAUNCH(1, 256); }
+    if (n <= RB_SMALL_BATCH) { if (s->integrator == RB_EULER) RB_ENV_LAUNCH(0, 64, 8); else RB_ENV_LAUNCH(1, 64, 8); }
+    else                     { if (s->integrator == RB_EULER) RB_ENV_LAUNCH(0, 256, 1); else RB_ENV_LAUNCH(1, 256, 1); }
 #undef RB_ENV_LAUNCH
     RB_HIP(hipGetLastError());
     s->env_steps += double(n);
@@ -704,7 +728,7 @@ static int stats_launch(rb_sim *s, int reset) {
     unsigned g = blocks_for(s->n, 256);
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL(stats_reduce_kernel, dim3(g), dim3(256), 0, s->stream,
-                       s->env_ready ? s->d_ep_acc : nullptr, s->d_ep_ret, s->d_infeas_n, s->d_stats,
+                       s->env_ready ? s->d_ep_acc : nullptr, s->d_ep_ret, s->d_infeas_n, s->d_feas, s->d_stats,
                        s->env_steps, s->n);
     RB_HIP(hipGetLastError());
     (void)reset;

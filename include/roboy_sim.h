@@ -165,7 +165,8 @@ int rb_env_step_dev(rb_sim *sim, const float *d_act /* [n_envs][n_t] in [-1,1] *
 /* episode statistics summed over this handle's envs since the last reset of
  * the accumulators: [sum episode return, sum return^2, n_episodes, sum episode
  * length, n_goal_reached, n_infeasible_env_steps, n_env_steps, sum reward]
- * (fp64).  The _dev form copies them into caller-owned device memory (e.g. a
+ * (fp64).  Without rb_env_configure only [5] (envs flagged infeasible at the
+ * time of the call) and [6] are non-zero.  The _dev form copies them into caller-owned device memory (e.g. a
  * torch tensor that is then all-reduced over RCCL); the host form synchronises. */
 int rb_env_stats(rb_sim *sim, double *stats8, int reset);
 int rb_env_stats_dev(rb_sim *sim, double *d_stats8, int reset);
