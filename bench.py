@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--workload", default="msj-4096-euler", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=None, help="override envs per GPU")
     ap.add_argument("--substeps", type=int, default=None, help="override integrator substeps per env step")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 env-per-lane, 2 tendon-per-lane")
     ap.add_argument("--no-graph", action="store_true", help="eager per-step launches instead of hipGraph replay")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -57,7 +58,7 @@ def parse():
     return ap.parse_args()
 
 
-def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world, dist, substeps=None):
+def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world, dist, substeps=None, kernel=0):
     """Returns dict(ms_per_step, value, kernel_us, ...) for this workload."""
     from gym_roboy_amd.envs.simulations import HipBatchSimulation
     n_envs, integrator, nsub, d_steps, d_warm, label = WORKLOADS[name]
@@ -68,6 +69,7 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
     dev = torch.cuda.current_device()
     sim = HipBatchSimulation(robot, n_envs, integrator=integrator, n_substeps=nsub, device=dev,
                              seed=0, env_id_offset=rank * n_envs)
+    sim.select_kernel(kernel)
     stream = torch.cuda.current_stream()        # main() made a non-default stream current
     sim.set_stream(stream.cuda_stream)          # launches and torch events share one stream
     slab = n_envs * sim.n_t
@@ -123,6 +125,7 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
         "value": world * n_envs * steps / wall, "ms_per_step": wall * 1e3 / steps,
         "launch_us_events": launch_s * 1e6, "bytes_per_launch": bytes_per_launch,
         "achieved_GBps": bytes_per_launch / launch_s / 1e9,
+        "kernel": {1: "msj_step_env_per_lane", 2: "msj_step_tendon_per_lane"}[info["kernel"]],
         "finite": bool(np.isfinite(q).all() and np.isfinite(qd).all()),
         "feasible_frac": float(feas.mean()),
     }
@@ -190,7 +193,7 @@ def main():
     # stream capture is not allowed on the legacy default stream: run on a side stream
     with torch.cuda.stream(torch.cuda.Stream()):
         head = run_workload(torch, robot, args.workload, args.steps, args.warmup, args.envs, use_graph,
-                            rank, world, dist, args.substeps)
+                            rank, world, dist, args.substeps, args.kernel)
         if world == 1 and not args.no_also:
             for name in ("msj-262144-rk4", "msj-2097152-euler"):
                 if name != args.workload:
@@ -218,7 +221,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": head["achieved_GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": head["achieved_GBps"] * 1e9 / HBM_PEAK, "traffic": None,
-                "kernel": "msj_step_env_per_lane", "bytes_per_env_step": 84,
+                "kernel": head["kernel"], "bytes_per_env_step": 84,
                 "bytes_per_launch": head["bytes_per_launch"], "launch_us_events": head["launch_us_events"],
                 "note": "events bracket the whole timed region on the launch stream, so the per-launch "
                         "time includes the kernel boundary; rocprofv3 kernel-only time is in profiles/",

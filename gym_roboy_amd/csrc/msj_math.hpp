@@ -134,64 +134,64 @@ template <typename T, int NT>
 struct MsjModel {
     using C = MsjConst<T, NT>;
 
-    // qdd = f(q, qd, set-points).  UNROLL = unroll factor of the tendon loop
-    // (NT: straight-line code, most ILP; 1: rolled, fewest registers).
-    // SP: set-point source, sp(k) = set-point of tendon k (a register array for
-    // straight-line code, an LDS column for the rolled loop: see SpArray/SpLds)
-    template <int UNROLL, typename SP>
-    static RB_HD void accel(const C &c, const T q[3], const T qd[3], const SP &sp, T qdd[3]) {
+    // body frame of one env: rotation rows, joint-axis sines/cosines, angular velocity
+    struct Frame {
         T s0, c0, s1, c1, s2, c2;
-        Fast<T>::sincos(q[0], s0, c0);
-        Fast<T>::sincos(q[1], s1, c1);
-        Fast<T>::sincos(q[2], s2, c2);
+        T r00, r01, r02, r10, r11, r12, r20, r21, r22;
+        T wx, wy, wz;
+    };
+
+    static RB_HD Frame frame(const T q[3], const T qd[3]) {
+        Frame f;
+        Fast<T>::sincos(q[0], f.s0, f.c0);
+        Fast<T>::sincos(q[1], f.s1, f.c1);
+        Fast<T>::sincos(q[2], f.s2, f.c2);
         // R = Rx Ry Rz, rows
-        const T r00 = c1 * c2, r01 = -c1 * s2, r02 = s1;
-        const T r10 = c0 * s2 + s0 * s1 * c2, r11 = c0 * c2 - s0 * s1 * s2, r12 = -s0 * c1;
-        const T r20 = s0 * s2 - c0 * s1 * c2, r21 = s0 * c2 + c0 * s1 * s2, r22 = c0 * c1;
+        f.r00 = f.c1 * f.c2; f.r01 = -f.c1 * f.s2; f.r02 = f.s1;
+        f.r10 = f.c0 * f.s2 + f.s0 * f.s1 * f.c2; f.r11 = f.c0 * f.c2 - f.s0 * f.s1 * f.s2; f.r12 = -f.s0 * f.c1;
+        f.r20 = f.s0 * f.s2 - f.c0 * f.s1 * f.c2; f.r21 = f.s0 * f.c2 + f.c0 * f.s1 * f.s2; f.r22 = f.c0 * f.c1;
         // joint axes in the body frame: zeta0 = row 0 of R, zeta1 = (s2,c2,0), zeta2 = e_z
-        const T wx = r00 * qd[0] + s2 * qd[1];
-        const T wy = r01 * qd[0] + c2 * qd[1];
-        const T wz = r02 * qd[0] + qd[2];
+        f.wx = f.r00 * qd[0] + f.s2 * qd[1];
+        f.wy = f.r01 * qd[0] + f.c2 * qd[1];
+        f.wz = f.r02 * qd[0] + qd[2];
+        return f;
+    }
 
-        // ---- tendons: torque about the joint centre, body frame ----
-        T tx = T(0), ty = T(0), tz = T(0);
-        // software prefetch: the record of tendon k+1 is requested (scalar load)
-        // before the arithmetic of tendon k, so its latency is covered
-        MsjTendon<T> nxt = c.ten[0];
-#pragma unroll UNROLL
-        for (int k = 0; k < NT; ++k) {
-            const MsjTendon<T> t = nxt;
-            nxt = c.ten[(k + 1) & (NT - 1)];
-            const T ax = r00 * t.A[0] + r10 * t.A[1] + r20 * t.A[2];
-            const T ay = r01 * t.A[0] + r11 * t.A[1] + r21 * t.A[2];
-            const T az = r02 * t.A[0] + r12 * t.A[1] + r22 * t.A[2];
-            const T dx = t.B[0] - ax, dy = t.B[1] - ay, dz = t.B[2] - az;
-            const T d2 = dx * dx + dy * dy + dz * dz;
-            const T inv = Fast<T>::rsqrt(d2);
-            const T len = d2 * inv + t.lc;
-            const T ux = dx * inv, uy = dy * inv, uz = dz * inv;
-            // w = B x u
-            const T mx = t.B[1] * uz - t.B[2] * uy;
-            const T my = t.B[2] * ux - t.B[0] * uz;
-            const T mz = t.B[0] * uy - t.B[1] * ux;
-            const T ldot = wx * mx + wy * my + wz * mz;
-            // Hill-type muscle: e = l/l0 - 1, err = e - (sigma/l0) s
-            const T e = len * t.inv_l0 - T(1);
-            const T act = tclamp(c.kp * (e - t.sg_l0 * sp(k)), T(0), T(1));
-            const T fl = Fast<T>::exp2(c.fl_k2 * (e * e));
-            // f_V = (1 + c1 v)/(1 + c2 v) per branch, written branch-free with
-            // v+ = max(v,0) and v- = clamp(v,-1,0) (one of them is zero)
-            const T v = ldot * t.inv_vl0;
-            const T vp = tmax(v, T(0)), vm = tclamp(v, T(-1), T(0));
-            const T num = c.fv_c1l * vp + (T(1) + vm);
-            const T den = c.fv_c2l * vp + (c.fv_c2s * vm + T(1));
-            const T fv = num * Fast<T>::rcp(den);          // >= 0: num >= 0, den >= 1
-            const T fpe = tmax((Fast<T>::exp2(c.pe_k2 * e) - T(1)) * c.inv_pe_den, T(0));
-            const T F = t.fmax * (act * fl * fv + fpe);
-            tx -= F * mx; ty -= F * my; tz -= F * mz;
-        }
+    // one tendon: routing, Hill-type force, torque about the joint centre (body
+    // frame) subtracted from (tx,ty,tz)
+    static RB_HD void tendon(const C &c, const Frame &f, const MsjTendon<T> &t, T spk, T &tx, T &ty, T &tz) {
+        const T ax = f.r00 * t.A[0] + f.r10 * t.A[1] + f.r20 * t.A[2];
+        const T ay = f.r01 * t.A[0] + f.r11 * t.A[1] + f.r21 * t.A[2];
+        const T az = f.r02 * t.A[0] + f.r12 * t.A[1] + f.r22 * t.A[2];
+        const T dx = t.B[0] - ax, dy = t.B[1] - ay, dz = t.B[2] - az;
+        const T d2 = dx * dx + dy * dy + dz * dz;
+        const T inv = Fast<T>::rsqrt(d2);
+        const T len = d2 * inv + t.lc;
+        const T ux = dx * inv, uy = dy * inv, uz = dz * inv;
+        // w = B x u
+        const T mx = t.B[1] * uz - t.B[2] * uy;
+        const T my = t.B[2] * ux - t.B[0] * uz;
+        const T mz = t.B[0] * uy - t.B[1] * ux;
+        const T ldot = f.wx * mx + f.wy * my + f.wz * mz;
+        // Hill-type muscle: e = l/l0 - 1, err = e - (sigma/l0) s
+        const T e = len * t.inv_l0 - T(1);
+        const T act = tclamp(c.kp * (e - t.sg_l0 * spk), T(0), T(1));
+        const T fl = Fast<T>::exp2(c.fl_k2 * (e * e));
+        // f_V = (1 + c1 v)/(1 + c2 v) per branch, written branch-free with
+        // v+ = max(v,0) and v- = clamp(v,-1,0) (one of them is zero)
+        const T v = ldot * t.inv_vl0;
+        const T vp = tmax(v, T(0)), vm = tclamp(v, T(-1), T(0));
+        const T num = c.fv_c1l * vp + (T(1) + vm);
+        const T den = c.fv_c2l * vp + (c.fv_c2s * vm + T(1));
+        const T fv = num * Fast<T>::rcp(den);          // >= 0: num >= 0, den >= 1
+        const T fpe = tmax((Fast<T>::exp2(c.pe_k2 * e) - T(1)) * c.inv_pe_den, T(0));
+        const T F = t.fmax * (act * fl * fv + fpe);
+        tx -= F * mx; ty -= F * my; tz -= F * mz;
+    }
 
-        // ---- rigid body about the joint centre ----
+    // rigid body about the joint centre: qdd from the summed tendon torque
+    static RB_HD void rigid_body(const C &c, const Frame &f, const T qd[3], T tx, T ty, T tz, T qdd[3]) {
+        const T r00 = f.r00, r01 = f.r01, r02 = f.r02, s2 = f.s2, c2 = f.c2;
         const T Ixx = c.IO[0], Iyy = c.IO[1], Izz = c.IO[2], Ixy = c.IO[3], Ixz = c.IO[4], Iyz = c.IO[5];
         // columns I_O zeta_j
         const T a0x = Ixx * r00 + Ixy * r01 + Ixz * r02;
@@ -212,19 +212,19 @@ struct MsjModel {
         const T hy = a0y * qd[0] + a1y * qd[1] + Iyz * qd[2];
         const T hz = a0z * qd[0] + a1z * qd[1] + Izz * qd[2];
         // zeta_dot qd
-        const T z0x = -s1 * c2 * qd[1] - c1 * s2 * qd[2];
-        const T z0y = s1 * s2 * qd[1] - c1 * c2 * qd[2];
-        const T z0z = c1 * qd[1];
+        const T z0x = -f.s1 * c2 * qd[1] - f.c1 * s2 * qd[2];
+        const T z0y = f.s1 * s2 * qd[1] - f.c1 * c2 * qd[2];
+        const T z0z = f.c1 * qd[1];
         const T bx = z0x * qd[0] + c2 * qd[2] * qd[1];
         const T by = z0y * qd[0] - s2 * qd[2] * qd[1];
         const T bz = z0z * qd[0];
-        const T nx = Ixx * bx + Ixy * by + Ixz * bz + (wy * hz - wz * hy);
-        const T ny = Ixy * bx + Iyy * by + Iyz * bz + (wz * hx - wx * hz);
-        const T nz = Ixz * bx + Iyz * by + Izz * bz + (wx * hy - wy * hx);
+        const T nx = Ixx * bx + Ixy * by + Ixz * bz + (f.wy * hz - f.wz * hy);
+        const T ny = Ixy * bx + Iyy * by + Iyz * bz + (f.wz * hx - f.wx * hz);
+        const T nz = Ixz * bx + Iyz * by + Izz * bz + (f.wx * hy - f.wy * hx);
         // gravity torque (m c) x R^T g
-        const T gx = r00 * c.g[0] + r10 * c.g[1] + r20 * c.g[2];
-        const T gy = r01 * c.g[0] + r11 * c.g[1] + r21 * c.g[2];
-        const T gz = r02 * c.g[0] + r12 * c.g[1] + r22 * c.g[2];
+        const T gx = r00 * c.g[0] + f.r10 * c.g[1] + f.r20 * c.g[2];
+        const T gy = r01 * c.g[0] + f.r11 * c.g[1] + f.r21 * c.g[2];
+        const T gz = r02 * c.g[0] + f.r12 * c.g[1] + f.r22 * c.g[2];
         const T vx = tx + (c.mc[1] * gz - c.mc[2] * gy) - nx;
         const T vy = ty + (c.mc[2] * gx - c.mc[0] * gz) - ny;
         const T vz = tz + (c.mc[0] * gy - c.mc[1] * gx) - nz;
@@ -243,6 +243,23 @@ struct MsjModel {
         qdd[1] = (k01 * t0 + k11 * t1 + k12 * t2) * idet;
         qdd[2] = (k02 * t0 + k12 * t1 + k22 * t2) * idet;
     }
+
+    // Acceleration with all NT tendons evaluated by this lane.  UNROLL = unroll
+    // factor of the tendon loop (NT: straight-line code, most ILP; 1: rolled,
+    // one scalar load of the tendon record per trip, fewest registers).
+    // SP: set-point source, sp(k) (register array or LDS column).
+    template <int UNROLL, typename SP>
+    struct AccelAllTendons {
+        const C &c;
+        const SP &sp;
+        RB_HD void operator()(const T q[3], const T qd[3], T qdd[3]) const {
+            const Frame f = frame(q, qd);
+            T tx = T(0), ty = T(0), tz = T(0);
+#pragma unroll UNROLL
+            for (int k = 0; k < NT; ++k) tendon(c, f, c.ten[k], sp(k), tx, ty, tz);
+            rigid_body(c, f, qd, tx, ty, tz, qdd);
+        }
+    };
 
     static RB_HD void sat(const C &c, const T v[3], T out[3]) {
 #pragma unroll
@@ -264,15 +281,16 @@ struct MsjModel {
         return ok;
     }
 
-    // one env step = nsub integrator substeps with the set-points held
-    template <int INTEG, int UNROLL, typename SP>
-    static RB_HD bool step_sp(const C &c, T q[3], T qd[3], const SP &sp) {
+    // one env step = nsub integrator substeps with the set-points held;
+    // `accel(q, qd, qdd)` is one of the acceleration functors
+    template <int INTEG, typename ACCEL>
+    static RB_HD bool integrate(const C &c, T q[3], T qd[3], const ACCEL &accel) {
         bool feasible = true;
         const T h = c.h;
         for (int sub = 0; sub < c.nsub; ++sub) {
             if (INTEG == 0) {          // semi-implicit Euler
                 T a[3];
-                accel<UNROLL>(c, q, qd, sp, a);
+                accel(q, qd, a);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     qd[j] = tclamp(qd[j] + h * a[j], -c.qdmax[j], c.qdmax[j]);
@@ -282,19 +300,19 @@ struct MsjModel {
                 T k1q[3], k1v[3], k2q[3], k2v[3], k3q[3], k3v[3], k4q[3], k4v[3], qs[3], vs[3];
                 const T hh = T(0.5) * h;
                 sat(c, qd, k1q);
-                accel<UNROLL>(c, q, k1q, sp, k1v);
+                accel(q, k1q, k1v);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) { qs[j] = q[j] + hh * k1q[j]; vs[j] = qd[j] + hh * k1v[j]; }
                 sat(c, vs, k2q);
-                accel<UNROLL>(c, qs, k2q, sp, k2v);
+                accel(qs, k2q, k2v);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) { qs[j] = q[j] + hh * k2q[j]; vs[j] = qd[j] + hh * k2v[j]; }
                 sat(c, vs, k3q);
-                accel<UNROLL>(c, qs, k3q, sp, k3v);
+                accel(qs, k3q, k3v);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) { qs[j] = q[j] + h * k3q[j]; vs[j] = qd[j] + h * k3v[j]; }
                 sat(c, vs, k4q);
-                accel<UNROLL>(c, qs, k4q, sp, k4v);
+                accel(qs, k4q, k4v);
                 const T h6 = h * T(1.0 / 6.0);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
@@ -307,9 +325,15 @@ struct MsjModel {
         return feasible;
     }
 
+    template <int INTEG, int UNROLL, typename SP>
+    static RB_HD bool step_sp(const C &c, T q[3], T qd[3], const SP &sp) {
+        return integrate<INTEG>(c, q, qd, AccelAllTendons<UNROLL, SP>{c, sp});
+    }
+
     template <int INTEG, int UNROLL = NT>
     static RB_HD bool step(const C &c, T q[3], T qd[3], const T sp[NT]) {
-        return step_sp<INTEG, UNROLL>(c, q, qd, SpArray<T, NT>{sp});
+        const SpArray<T, NT> src{sp};
+        return step_sp<INTEG, UNROLL>(c, q, qd, src);
     }
 };
 

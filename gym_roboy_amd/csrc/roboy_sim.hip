@@ -35,6 +35,15 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #ifndef RB_SMALL_BATCH
 #define RB_SMALL_BATCH 65536   // <= this many envs: latency-oriented launch configuration
 #endif
+// AUTO picks the tendon-per-lane form up to this many envs (measured crossover,
+// profiles/r1_b/sweep.log: Euler 2.9 vs 3.5 us at 8 192 and a tie at 16 384; RK4
+// 6.2 vs 7.0 us at 16 384 and 10.2 vs 7.1 us at 32 768)
+#ifndef RB_TENDON_LANE_BATCH_EULER
+#define RB_TENDON_LANE_BATCH_EULER 8192
+#endif
+#ifndef RB_TENDON_LANE_BATCH_RK4
+#define RB_TENDON_LANE_BATCH_RK4 16384
+#endif
 constexpr int NT8 = 8;
 using Const8 = rb::MsjConst<float, NT8>;
 
@@ -81,6 +90,69 @@ msj_step_env_per_lane(const Const8 c, float *__restrict__ q, float *__restrict__
     feas[i] = ok ? 1u : 0u;
 }
 
+
+
+// ---------------------------------------------------------------------------
+// Tendon-per-lane form for small batches.  8 consecutive lanes share one env:
+// lane k evaluates tendon k (routing, Hill force, torque contribution), the 3
+// torque components are summed over the 8 lanes with DPP adds (no LDS), and
+// every lane then carries the (cheap, redundant) rigid-body solve.  A wave
+// advances 8 envs with ~1/3 of the per-wave instruction chain of the
+// env-per-lane form, and a 4 096-env batch becomes 512 waves instead of 64:
+// what a latency-bound launch needs.  The per-tendon record is lane-dependent
+// here, so it is read from a small device table (one 64-byte record per lane,
+// L1/L2-resident) instead of SGPRs.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 8 lanes of an env group, result in every lane:
+// quad_perm(1,0,3,2), quad_perm(2,3,0,1), then row_half_mirror (lane i <-> 7-i)
+__device__ __forceinline__ float sum8(float v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    return v;
+}
+
+struct AccelOneTendon {
+    const Const8 &c;
+    const rb::MsjTendon<float> &t;
+    float spk;
+    __device__ __forceinline__ void operator()(const float q[3], const float qd[3], float qdd[3]) const {
+        using M = rb::MsjModel<float, NT8>;
+        const M::Frame f = M::frame(q, qd);
+        float tx = 0.0f, ty = 0.0f, tz = 0.0f;
+        M::tendon(c, f, t, spk, tx, ty, tz);
+        tx = sum8(tx); ty = sum8(ty); tz = sum8(tz);
+        M::rigid_body(c, f, qd, tx, ty, tz, qdd);
+    }
+};
+
+template <int INTEG>
+__global__ void __launch_bounds__(64)
+msj_step_tendon_per_lane(const Const8 c, const rb::MsjTendon<float> *__restrict__ ten,
+                         float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
+                         const float *__restrict__ act, float act_scale, long n) {
+    const long t = long(blockIdx.x) * 64 + threadIdx.x;
+    const int k = threadIdx.x & 7;
+    long e = t >> 3;
+    const bool live = e < n;          // whole 8-lane groups are live or not; dead groups
+    if (!live) e = n - 1;             // shadow the last env so every DPP partner is active
+    const rb::MsjTendon<float> rec = ten[k];
+    const float spk = act[e * NT8 + k] * act_scale;
+    float qq[3], vv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { qq[j] = q[j * n + e]; vv[j] = qd[j * n + e]; }
+    const bool ok = rb::MsjModel<float, NT8>::template integrate<INTEG>(c, qq, vv, AccelOneTendon{c, rec, spk});
+    // lanes 0-2 store q, 3-5 store qd, 6 stores the feasibility word: one store each
+    if (live && k < 6) {
+        const float val = k == 0 ? qq[0] : k == 1 ? qq[1] : k == 2 ? qq[2] : k == 3 ? vv[0] : k == 4 ? vv[1] : vv[2];
+        float *plane = (k < 3 ? q : qd) + long(k < 3 ? k : k - 3) * n;
+        plane[e] = val;
+    }
+    if (live && k == 6) feas[e] = ok ? 1u : 0u;
+}
 
 __global__ void reset_kernel(float *q, float *qd, uint32_t *feas, const uint8_t *mask, int n_q, long n) {
     const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -327,6 +399,8 @@ struct rb_sim {
     uint64_t seed = 0;
     int64_t env0 = 0;
     Const8 c8;
+    rb::MsjTendon<float> *d_ten = nullptr;   // device copy of c8.ten for the tendon-per-lane form
+    int kernel_choice = RB_KERNEL_AUTO;
     GoalBox box;
     hipStream_t own_stream = nullptr, stream = nullptr;
     float *d_q = nullptr, *d_qd = nullptr;
@@ -362,7 +436,15 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale) {
 #define RB_STEP_LAUNCH(INTEG, B, U)                                                                   \
     hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U>), dim3(blocks_for(n, B)), dim3(B), 0,      \
                        s->stream, s->c8, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n)
-    if (n <= RB_SMALL_BATCH) {
+    if (s->kernel == RB_KERNEL_TENDON_PER_LANE) {
+        const unsigned g = blocks_for(n * NT8, 64);
+        if (s->integrator == RB_EULER)
+            hipLaunchKernelGGL((msj_step_tendon_per_lane<0>), dim3(g), dim3(64), 0, s->stream,
+                               s->c8, s->d_ten, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
+        else
+            hipLaunchKernelGGL((msj_step_tendon_per_lane<1>), dim3(g), dim3(64), 0, s->stream,
+                               s->c8, s->d_ten, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
+    } else if (n <= RB_SMALL_BATCH) {
         if (s->integrator == RB_EULER) RB_STEP_LAUNCH(0, 64, 8); else RB_STEP_LAUNCH(1, 64, 8);
     } else {
         if (s->integrator == RB_EULER) RB_STEP_LAUNCH(0, 256, 1); else RB_STEP_LAUNCH(1, 256, 1);
@@ -470,12 +552,15 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
     const int width = s->n_q > s->n_t ? s->n_q : s->n_t;
     RB_TRY(hipMalloc(&s->d_rows, plane * width));
     RB_TRY(hipMalloc(&s->d_u8, size_t(n_envs)));
+    RB_TRY(hipMalloc(&s->d_ten, sizeof(s->c8.ten)));
+    RB_TRY(hipMemcpyAsync(s->d_ten, s->c8.ten, sizeof(s->c8.ten), hipMemcpyHostToDevice, s->stream));
     RB_TRY(hipMemsetAsync(s->d_goal_count, 0, sizeof(uint32_t) * size_t(n_envs), s->stream));
     RB_TRY(hipMalloc(&s->d_infeas_n, sizeof(uint32_t) * size_t(n_envs)));
     RB_TRY(hipMemsetAsync(s->d_infeas_n, 0, sizeof(uint32_t) * size_t(n_envs), s->stream));
     RB_TRY(hipMalloc(&s->d_stats, sizeof(double) * 8));
 #undef RB_TRY
     *out = s;
+    (void)rb_select_kernel(s, RB_KERNEL_AUTO);
     rc = rb_reset(s, nullptr);
     if (rc != RB_OK) { std::string m = g_err; rb_destroy(s); *out = nullptr; return fail(rc, m); }
     return RB_OK;
@@ -487,7 +572,7 @@ void rb_destroy(rb_sim *s) {
     if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
     for (auto &kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     (void)hipFree(s->d_q); (void)hipFree(s->d_qd); (void)hipFree(s->d_feas);
-    (void)hipFree(s->d_goal_count); (void)hipFree(s->d_rows); (void)hipFree(s->d_u8);
+    (void)hipFree(s->d_goal_count); (void)hipFree(s->d_rows); (void)hipFree(s->d_u8); (void)hipFree(s->d_ten);
     (void)hipFree(s->d_goal); (void)hipFree(s->d_ep_ret); (void)hipFree(s->d_ep_acc);
     (void)hipFree(s->d_step_num); (void)hipFree(s->d_infeas_n); (void)hipFree(s->d_stats);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
@@ -506,8 +591,16 @@ int rb_info(const rb_sim *s, rb_sim_info *info) {
 
 int rb_select_kernel(rb_sim *s, int kernel) {
     if (check(s)) return RB_EINVAL;
-    if (kernel == RB_KERNEL_AUTO || kernel == RB_KERNEL_ENV_PER_LANE) { s->kernel = RB_KERNEL_ENV_PER_LANE; return RB_OK; }
-    return fail(RB_EUNSUPPORTED, "kernel variant not built");
+    if (kernel != RB_KERNEL_AUTO && kernel != RB_KERNEL_ENV_PER_LANE && kernel != RB_KERNEL_TENDON_PER_LANE)
+        return fail(RB_EINVAL, "unknown kernel variant");
+    s->kernel_choice = kernel;
+    s->kernel = kernel != RB_KERNEL_AUTO ? kernel
+                : (s->n <= (s->integrator == RB_EULER ? RB_TENDON_LANE_BATCH_EULER : RB_TENDON_LANE_BATCH_RK4)
+                       ? RB_KERNEL_TENDON_PER_LANE : RB_KERNEL_ENV_PER_LANE);
+    // graphs captured with the other variant must not be replayed
+    for (auto &kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
+    s->graphs.clear();
+    return RB_OK;
 }
 
 int rb_set_stream(rb_sim *s, void *hip_stream) {

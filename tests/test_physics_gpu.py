@@ -20,11 +20,17 @@ def _sim(robot, n, **kw):
     return HipBatchSimulation(robot, n, **kw)
 
 
-def _check_step(robot, oracle, n, integrator, nsub, seed):
+KERNELS = {"env_per_lane": 1, "tendon_per_lane": 2}
+
+
+def _check_step(robot, oracle, n, integrator, nsub, seed, kernel=0):
     from oracle.physics_np import EULER, RK4
     desc = robot.get_description()
     q, qd, sp = random_states(desc, n, seed)
     sim = _sim(robot, n, integrator=integrator, n_substeps=nsub)
+    sim.select_kernel(kernel)
+    auto_limit = 8192 if integrator == "euler" else 16384
+    assert sim.info()["kernel"] == (kernel or (2 if n <= auto_limit else 1))
     sim.set_state(q, qd)
     q1, qd1, f1 = sim.forward_step_command(sp)
     qo, qdo, fo = oracle.step(q.astype(np.float64), qd.astype(np.float64), sp.astype(np.float64),
@@ -38,16 +44,36 @@ def _check_step(robot, oracle, n, integrator, nsub, seed):
     return np.abs(q1 - qo).max(), np.abs(qd1 - qdo).max()
 
 
+@pytest.mark.parametrize("kernel", sorted(KERNELS))
 @pytest.mark.parametrize("integrator", ["euler", "rk4"])
 @pytest.mark.parametrize("nsub", [1, 4])
-@pytest.mark.parametrize("n", [1, 63, 4096])
-def test_step_matches_oracle(msj_robot, msj_oracle, integrator, nsub, n):
-    _check_step(msj_robot, msj_oracle, n, integrator, nsub, seed=n + nsub)
+@pytest.mark.parametrize("n", [1, 63, 4097])
+def test_step_matches_oracle(msj_robot, msj_oracle, kernel, integrator, nsub, n):
+    """Both kernel forms, ragged sizes (1 env; 63 = not a whole wave; 4097 = one
+    env into the next wave / the next 8-lane group)."""
+    _check_step(msj_robot, msj_oracle, n, integrator, nsub, seed=n + nsub, kernel=KERNELS[kernel])
 
 
-def test_step_large_batch_matches_oracle(msj_robot, msj_oracle):
-    # > 65536 envs takes the 256-thread launch configuration
-    _check_step(msj_robot, msj_oracle, 70001, "euler", 1, seed=5)
+@pytest.mark.parametrize("integrator", ["euler", "rk4"])
+def test_step_large_batch_matches_oracle(msj_robot, msj_oracle, integrator):
+    # > 65536 envs takes the rolled-loop, 256-thread launch configuration (AUTO)
+    _check_step(msj_robot, msj_oracle, 70001, integrator, 1, seed=5)
+
+
+def test_kernel_forms_agree_with_each_other(msj_robot):
+    """Same inputs through both forms: they differ only in the order the 8
+    tendon torques are summed (sequential vs DPP butterfly)."""
+    n = 3000
+    q, qd, sp = random_states(msj_robot.get_description(), n, 21)
+    out = []
+    for kernel in (1, 2):
+        sim = _sim(msj_robot, n, integrator="rk4")
+        sim.select_kernel(kernel)
+        sim.set_state(q, qd)
+        out.append(sim.forward_step_command(sp))
+        sim.close()
+    assert np.abs(out[0][0] - out[1][0]).max() < 5e-6 and np.abs(out[0][1] - out[1][1]).max() < 5e-6
+    assert np.mean(out[0][2] == out[1][2]) > 0.999
 
 
 def test_reset_gives_zero_state(msj_robot):
