@@ -35,6 +35,8 @@ WORKLOADS = {
     "msj-262144-rk4": (262144, "rk4", 1, 400, 40, "configs[2]: MsjRobot 262 144 envs, RK4 fp32"),
     "msj-262144-euler": (262144, "euler", 1, 1000, 100, "configs[4] shard: 262 144 envs per GPU, Euler fp32"),
     "msj-2097152-euler": (2097152, "euler", 1, 300, 30, "large batch: 2 097 152 envs on one GPU, Euler fp32"),
+    "upper-body-8192-euler": (8192, "euler", 1, 300, 30, "configs[3]: upper body (20 DOF / 38 tendons) 8 192 envs, Euler fp32"),
+    "upper-body-8192-rk4": (8192, "rk4", 1, 100, 10, "configs[3]: upper body (20 DOF / 38 tendons) 8 192 envs, RK4 fp32"),
 }
 RING = 4
 STATS_EVERY = 100
@@ -125,7 +127,7 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
         "value": world * n_envs * steps / wall, "ms_per_step": wall * 1e3 / steps,
         "launch_us_events": launch_s * 1e6, "bytes_per_launch": bytes_per_launch,
         "achieved_GBps": bytes_per_launch / launch_s / 1e9,
-        "kernel": {1: "msj_step_env_per_lane", 2: "msj_step_tendon_per_lane"}[info["kernel"]],
+        "kernel": {1: "msj_step_env_per_lane", 2: "msj_step_tendon_per_lane", 3: "tree_step_wave_per_env"}[info["kernel"]],
         "finite": bool(np.isfinite(q).all() and np.isfinite(qd).all()),
         "feasible_frac": float(feas.mean()),
     }
@@ -137,7 +139,7 @@ def cpu_baseline(robot, seconds, name):
     from oracle.c_oracle import COracle
     from oracle import philox_np as ph
     n_envs, integrator, nsub, *_ = WORKLOADS[name]
-    n = min(n_envs, 4096)
+    n = min(n_envs, 4096 if robot.get_description().n_q <= 3 else 512)
     desc = robot.get_description()
     orc = COracle(desc, "f32")
     integ = 0 if integrator == "euler" else 1
@@ -186,8 +188,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from gym_roboy_amd.envs.robots import MsjRobot
-    robot = MsjRobot()
+    from gym_roboy_amd.envs.robots import MsjRobot, UpperBodyRobot
+    robot = UpperBodyRobot() if args.workload.startswith("upper-body") else MsjRobot()
     use_graph = not args.no_graph
     also = []
     # stream capture is not allowed on the legacy default stream: run on a side stream
@@ -195,9 +197,10 @@ def main():
         head = run_workload(torch, robot, args.workload, args.steps, args.warmup, args.envs, use_graph,
                             rank, world, dist, args.substeps, args.kernel)
         if world == 1 and not args.no_also:
-            for name in ("msj-262144-rk4", "msj-2097152-euler"):
+            for name in ("msj-262144-rk4", "msj-2097152-euler", "upper-body-8192-euler"):
                 if name != args.workload:
-                    r = run_workload(torch, robot, name, None, None, None, use_graph, rank, world, dist)
+                    rob = UpperBodyRobot() if name.startswith("upper-body") else MsjRobot()
+                    r = run_workload(torch, rob, name, None, None, None, use_graph, rank, world, dist)
                     also.append({k: r[k] for k in ("workload", "label", "value", "ms_per_step", "launch_us_events",
                                                    "achieved_GBps", "steps")} |
                                 {"frac_of_hbm_peak": r["achieved_GBps"] * 1e9 / HBM_PEAK})
@@ -207,12 +210,13 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "env-steps/sec, MsjRobot (3-DOF/8-tendon) batched rollout",
+            "metric": "env-steps/sec, MsjRobot (3-DOF/8-tendon) batched rollout" if type(robot).__name__ == "MsjRobot"
+                      else "env-steps/sec, %s batched rollout" % type(robot).__name__,
             "value": head["value"], "unit": "env-steps/s",
             "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"],
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": head["label"], "robot": "MsjRobot", "envs_per_gpu": head["envs_per_gpu"],
+            "config": {"workload": head["label"], "robot": type(robot).__name__, "envs_per_gpu": head["envs_per_gpu"],
                        "total_envs": head["envs_per_gpu"] * world, "integrator": head["integrator"],
                        "substeps": head["substeps"], "step_size": 0.1,
                        "launch": "hipGraph replay of per-step kernels" if use_graph else "eager per-step launches",
@@ -221,7 +225,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": head["achieved_GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": head["achieved_GBps"] * 1e9 / HBM_PEAK, "traffic": None,
-                "kernel": head["kernel"], "bytes_per_env_step": 84,
+                "kernel": head["kernel"], "bytes_per_env_step": head["bytes_per_launch"] // head["envs_per_gpu"],
                 "bytes_per_launch": head["bytes_per_launch"], "launch_us_events": head["launch_us_events"],
                 "note": "events bracket the whole timed region on the launch stream, so the per-launch "
                         "time includes the kernel boundary; rocprofv3 kernel-only time is in profiles/",

@@ -18,6 +18,7 @@
 #include "msj_build.hpp"
 #include "msj_math.hpp"
 #include "philox.hpp"
+#include "tree_kernels.hpp"
 
 namespace {
 
@@ -401,6 +402,11 @@ struct rb_sim {
     Const8 c8;
     rb::MsjTendon<float> *d_ten = nullptr;   // device copy of c8.ten for the tendon-per-lane form
     int kernel_choice = RB_KERNEL_AUTO;
+    // generic joint-tree robots (tree_kernels.hpp): wave-per-env kernel
+    bool tree = false;
+    rbt::TreeHost tree_host;
+    int *d_tree_ints = nullptr;
+    float *d_tree_floats = nullptr;
     GoalBox box;
     hipStream_t own_stream = nullptr, stream = nullptr;
     float *d_q = nullptr, *d_qd = nullptr;
@@ -436,7 +442,15 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale) {
 #define RB_STEP_LAUNCH(INTEG, B, U)                                                                   \
     hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U>), dim3(blocks_for(n, B)), dim3(B), 0,      \
                        s->stream, s->c8, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n)
-    if (s->kernel == RB_KERNEL_TENDON_PER_LANE) {
+    if (s->tree) {
+        const size_t lds = s->tree_host.lds_floats * sizeof(float);
+        if (s->integrator == RB_EULER)
+            hipLaunchKernelGGL((rbt::tree_step_wave_per_env<0>), dim3(unsigned(n)), dim3(64), lds, s->stream,
+                               s->tree_host.dev, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
+        else
+            hipLaunchKernelGGL((rbt::tree_step_wave_per_env<1>), dim3(unsigned(n)), dim3(64), lds, s->stream,
+                               s->tree_host.dev, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
+    } else if (s->kernel == RB_KERNEL_TENDON_PER_LANE) {
         const unsigned g = blocks_for(n * NT8, 64);
         if (s->integrator == RB_EULER)
             hipLaunchKernelGGL((msj_step_tendon_per_lane<0>), dim3(g), dim3(64), 0, s->stream,
@@ -504,16 +518,23 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
     if (integrator != RB_EULER && integrator != RB_RK4) return fail(RB_EINVAL, "unknown integrator");
     if (!(step_size > 0.0) || n_substeps < 1) return fail(RB_EINVAL, "step_size must be > 0 and n_substeps >= 1");
     if (robot->n_q < 1 || robot->n_q > 32 || robot->n_t < 1) return fail(RB_EINVAL, "n_q must be in [1, 32], n_t >= 1");
+    if (n_envs > (int64_t(1) << 30)) return fail(RB_EINVAL, "n_envs too large");
     if (env_id_offset < 0) return fail(RB_EINVAL, "env_id_offset must be >= 0");
 
     rb_sim *s = new (std::nothrow) rb_sim();
     if (!s) return fail(RB_ENOMEM, "out of host memory");
     std::string why;
     int rc = rb::msj_build<float, NT8>(robot, step_size, n_substeps, &s->c8, why);
+    if (rc == RB_EUNSUPPORTED) {
+        // not a ball-joint robot: the generic joint-tree kernel (one env per wave)
+        std::string why_tree;
+        rc = rbt::tree_build(robot, step_size, n_substeps, s->tree_host, why_tree);
+        if (rc == RB_OK) s->tree = true;
+        else why = "not a ball-joint robot (" + why + ") and not a supported joint tree (" + why_tree + ")";
+    }
     if (rc != RB_OK) {
         delete s;
-        return fail(rc, "no HIP kernel for this robot structure: " + why +
-                            " (built so far: 3-DOF ball joint, one body, 8 tendons)");
+        return fail(rc, "no HIP kernel for this robot structure: " + why);
     }
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -552,8 +573,21 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
     const int width = s->n_q > s->n_t ? s->n_q : s->n_t;
     RB_TRY(hipMalloc(&s->d_rows, plane * width));
     RB_TRY(hipMalloc(&s->d_u8, size_t(n_envs)));
-    RB_TRY(hipMalloc(&s->d_ten, sizeof(s->c8.ten)));
-    RB_TRY(hipMemcpyAsync(s->d_ten, s->c8.ten, sizeof(s->c8.ten), hipMemcpyHostToDevice, s->stream));
+    if (!s->tree) {
+        RB_TRY(hipMalloc(&s->d_ten, sizeof(s->c8.ten)));
+        RB_TRY(hipMemcpyAsync(s->d_ten, s->c8.ten, sizeof(s->c8.ten), hipMemcpyHostToDevice, s->stream));
+    } else {
+        rbt::TreeHost &th = s->tree_host;
+        RB_TRY(hipMalloc(&s->d_tree_ints, sizeof(int) * th.ints.size()));
+        RB_TRY(hipMalloc(&s->d_tree_floats, sizeof(float) * th.floats.size()));
+        RB_TRY(hipMemcpy(s->d_tree_ints, th.ints.data(), sizeof(int) * th.ints.size(), hipMemcpyHostToDevice));
+        RB_TRY(hipMemcpy(s->d_tree_floats, th.floats.data(), sizeof(float) * th.floats.size(), hipMemcpyHostToDevice));
+        rbt::tree_patch_pointers(th, s->d_tree_ints, s->d_tree_floats);
+        if (th.lds_floats * sizeof(float) > 160 * 1024) {
+            rb_destroy(s);
+            return fail(RB_EUNSUPPORTED, "robot working set exceeds the 160 KiB LDS of a CU");
+        }
+    }
     RB_TRY(hipMemsetAsync(s->d_goal_count, 0, sizeof(uint32_t) * size_t(n_envs), s->stream));
     RB_TRY(hipMalloc(&s->d_infeas_n, sizeof(uint32_t) * size_t(n_envs)));
     RB_TRY(hipMemsetAsync(s->d_infeas_n, 0, sizeof(uint32_t) * size_t(n_envs), s->stream));
@@ -573,6 +607,7 @@ void rb_destroy(rb_sim *s) {
     for (auto &kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     (void)hipFree(s->d_q); (void)hipFree(s->d_qd); (void)hipFree(s->d_feas);
     (void)hipFree(s->d_goal_count); (void)hipFree(s->d_rows); (void)hipFree(s->d_u8); (void)hipFree(s->d_ten);
+    (void)hipFree(s->d_tree_ints); (void)hipFree(s->d_tree_floats);
     (void)hipFree(s->d_goal); (void)hipFree(s->d_ep_ret); (void)hipFree(s->d_ep_acc);
     (void)hipFree(s->d_step_num); (void)hipFree(s->d_infeas_n); (void)hipFree(s->d_stats);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
@@ -591,9 +626,15 @@ int rb_info(const rb_sim *s, rb_sim_info *info) {
 
 int rb_select_kernel(rb_sim *s, int kernel) {
     if (check(s)) return RB_EINVAL;
-    if (kernel != RB_KERNEL_AUTO && kernel != RB_KERNEL_ENV_PER_LANE && kernel != RB_KERNEL_TENDON_PER_LANE)
-        return fail(RB_EINVAL, "unknown kernel variant");
+    if (kernel < RB_KERNEL_AUTO || kernel > RB_KERNEL_ENV_PER_WAVE) return fail(RB_EINVAL, "unknown kernel variant");
     s->kernel_choice = kernel;
+    if (s->tree) {
+        if (kernel != RB_KERNEL_AUTO && kernel != RB_KERNEL_ENV_PER_WAVE)
+            return fail(RB_EUNSUPPORTED, "joint-tree robots only have the env-per-wave kernel");
+        s->kernel = RB_KERNEL_ENV_PER_WAVE;
+        return RB_OK;
+    }
+    if (kernel == RB_KERNEL_ENV_PER_WAVE) return fail(RB_EUNSUPPORTED, "ball-joint robots have no env-per-wave kernel");
     s->kernel = kernel != RB_KERNEL_AUTO ? kernel
                 : (s->n <= (s->integrator == RB_EULER ? RB_TENDON_LANE_BATCH_EULER : RB_TENDON_LANE_BATCH_RK4)
                        ? RB_KERNEL_TENDON_PER_LANE : RB_KERNEL_ENV_PER_LANE);

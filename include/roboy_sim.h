@@ -54,7 +54,8 @@ enum rb_integrator { RB_EULER = 0, RB_RK4 = 1 };
 enum rb_kernel {
     RB_KERNEL_AUTO = 0,
     RB_KERNEL_ENV_PER_LANE = 1,    /* one env per lane: throughput form        */
-    RB_KERNEL_TENDON_PER_LANE = 2  /* 8 lanes per env + DPP reductions: latency form */
+    RB_KERNEL_TENDON_PER_LANE = 2, /* 8 lanes per env + DPP reductions: latency form */
+    RB_KERNEL_ENV_PER_WAVE = 3     /* generic joint-tree robots: 64 lanes per env, LDS */
 };
 
 /* Robot description, format "roboy-tendon-robot/1" (Python

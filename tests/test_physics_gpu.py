@@ -198,7 +198,8 @@ def test_unsupported_robot_is_refused_loudly(msj_robot):
     from gym_roboy_amd.envs.simulations import HipBatchSimulation
     from gym_roboy_amd._native import NativeError
     spec = msj_platform_spec()
-    spec["joints"][1]["origin"] = [0.0, 0.0, 0.05]   # no longer a ball joint
+    spec["joints"][1]["origin"] = [0.0, 0.0, 0.05]   # no longer a ball joint -> generic tree kernel
+    spec["tendons"] = [dict(t, name="t%d" % i) for i in range(9) for t in spec["tendons"]][:65]   # > 64 tendons
     class Odd:
         @staticmethod
         def get_description():

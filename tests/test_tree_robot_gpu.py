@@ -1,0 +1,132 @@
+"""GPU parity of the generic joint-tree kernel (one env per wave, LDS working
+set) against the fp64 oracle, on the synthetic 20-DOF / 38-tendon upper body
+(BASELINE.json configs[3]) and on an MSJ variant that is not a ball joint.
+Tolerance 2e-5 on the state after one env step (fp32 Cholesky of a 20x20 M)."""
+import numpy as np
+import pytest
+
+from conftest import random_states
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def upper_body():
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    return UpperBodyRobot()
+
+
+@pytest.fixture(scope="module")
+def upper_oracle(upper_body):
+    from oracle.c_oracle import COracle
+    return COracle(upper_body.get_description(), "f64")
+
+
+def _check(robot, oracle, n, integrator, nsub, seed):
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    desc = robot.get_description()
+    q, qd, sp = random_states(desc, n, seed)
+    sim = HipBatchSimulation(robot, n, integrator=integrator, n_substeps=nsub)
+    assert sim.info()["kernel"] == 3
+    sim.set_state(q, qd)
+    q1, qd1, f1 = sim.forward_step_command(sp)
+    qo, qdo, fo = oracle.step(q, qd, sp, integrator=0 if integrator == "euler" else 1, n_substeps=nsub)
+    assert np.abs(q1 - qo).max() < TOL, np.abs(q1 - qo).max()
+    assert np.abs(qd1 - qdo).max() < TOL, np.abs(qd1 - qdo).max()
+    near = np.minimum(np.abs(qo - desc.q_lo), np.abs(qo - desc.q_hi)).min(axis=1) < 1e-5
+    assert not np.any((f1 != fo) & ~near)
+    sim.close()
+
+
+@pytest.mark.parametrize("integrator", ["euler", "rk4"])
+@pytest.mark.parametrize("nsub", [1, 2])
+@pytest.mark.parametrize("n", [1, 257])
+def test_upper_body_step_matches_oracle(upper_body, upper_oracle, integrator, nsub, n):
+    _check(upper_body, upper_oracle, n, integrator, nsub, seed=n + nsub)
+
+
+def test_upper_body_numpy_oracle_agrees_too(upper_body):
+    """The C oracle used above against the numpy statement of the spec, on this robot."""
+    from oracle.c_oracle import COracle
+    from oracle.physics_np import TendonRobotOracle
+    desc = upper_body.get_description()
+    q, qd, sp = random_states(desc, 16, 3)
+    a = TendonRobotOracle(desc).step(q.astype(np.float64), qd.astype(np.float64), sp.astype(np.float64), integrator=1)
+    b = COracle(desc, "f64").step(q, qd, sp, integrator=1)
+    assert np.abs(a[0] - b[0]).max() < 1e-12 and np.abs(a[1] - b[1]).max() < 1e-11
+
+
+def test_upper_body_rest_pose_is_an_equilibrium_and_rollout_tracks_oracle(upper_body, upper_oracle):
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    n = 64
+    sim = HipBatchSimulation(upper_body, n)
+    q, qd, f = sim.forward_step_command(np.zeros((n, 38), np.float32))
+    # fp32 gravity terms cancel to ~1e-8 rad, not to an exact zero as in the closed form
+    assert np.abs(q).max() < 1e-6 and np.abs(qd).max() < 1e-5 and f.all()
+    sim.forward_reset_command()
+    rng = np.random.default_rng(2)
+    qo = np.zeros((n, 20)); qdo = np.zeros((n, 20))
+    worst = 0.0
+    for t in range(120):
+        if t % 20 == 0:
+            sp = rng.uniform(-0.3, 0.3, (n, 38)).astype(np.float32)
+        q, qd, f = sim.forward_step_command(sp)
+        qo, qdo, fo = upper_oracle.step(qo, qdo, sp)
+        worst = max(worst, np.abs(q - qo).max(), np.abs(qd - qdo).max())
+    assert worst < 1e-3, worst
+    assert np.abs(q).max() > 0.05
+    sim.close()
+
+
+def test_upper_body_boundary_behaviour_and_goals(upper_body):
+    """test_simulation_client.py:47-68 for the second robot."""
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    sim = HipBatchSimulation(upper_body, 2)
+    low = np.tile(upper_body.get_action_space().low, (2, 1))
+    for _ in range(1000):
+        q, qd, f = sim.forward_step_command(low)
+        if not f.any():
+            break
+    assert not f.any()
+    assert not sim.forward_step_command(low)[2].any()
+    desc = upper_body.get_description()
+    g1, g2 = sim.get_new_goal_joint_angles(), sim.get_new_goal_joint_angles()
+    assert g1.shape == (2, 20) and not np.allclose(g1, g2)
+    assert np.all(g1 >= desc.q_lo.astype(np.float32)) and np.all(g1 <= desc.q_hi.astype(np.float32))
+    sim.close()
+
+
+def test_msj_variant_outside_the_ball_joint_class_takes_the_tree_kernel(msj_robot):
+    """Same tendons, joint 1 moved 5 cm up: not a ball joint any more, so the
+    closed form refuses and the generic kernel must take over and still match."""
+    from gym_roboy_amd.envs.robots import RobotDescription, msj_platform_spec
+    from oracle.c_oracle import COracle
+    spec = msj_platform_spec()
+    spec["joints"][1]["origin"] = [0.0, 0.0, 0.05]
+    desc = RobotDescription(spec)
+
+    class OffsetMsj(type(msj_robot)):
+        @classmethod
+        def get_description(cls):
+            return desc
+    for integrator in ("euler", "rk4"):
+        _check(OffsetMsj(), COracle(desc, "f64"), 100, integrator, 1, seed=4)
+
+
+def test_tree_kernel_on_the_msj_robot_equals_the_closed_form(msj_robot, msj_oracle):
+    """A description that IS ball-joint class but carries an (inert) 4th joint is
+    routed to the tree kernel; its first three joints must follow the MSJ oracle."""
+    from gym_roboy_amd.envs.robots import RobotDescription, msj_platform_spec
+    from oracle.c_oracle import COracle
+    spec = msj_platform_spec()
+    spec["joints"].append({"name": "idle", "parent": 2, "axis": [1, 0, 0], "origin": [0, 0, 0.1], "mass": 0.01,
+                           "com": [0, 0, 0.0], "inertia": [1e-6] * 3 + [0, 0, 0], "armature": 0.2, "damping": 0.8,
+                           "limit": [-0.4, 0.4], "max_velocity": 0.5})
+    desc = RobotDescription(spec)
+
+    class Msj4(type(msj_robot)):
+        @classmethod
+        def get_description(cls):
+            return desc
+    _check(Msj4(), COracle(desc, "f64"), 65, "euler", 1, seed=8)
