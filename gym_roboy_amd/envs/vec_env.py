@@ -101,7 +101,10 @@ class RoboyVecEnv:
             raise ValueError("actions must be a contiguous float32 CUDA tensor of shape (%d, %d)" % (n, self.n_t))
         # run on torch's current stream so the policy's kernels and the env
         # step are ordered without a host sync
-        self.sim.set_stream(torch.cuda.current_stream(actions.device).cuda_stream)
+        stream = torch.cuda.current_stream(actions.device).cuda_stream
+        if stream != getattr(self, "_stream", None):   # rb_set_stream drains the old stream: only on change
+            self.sim.set_stream(stream)
+            self._stream = stream
         obs = torch.empty((n, 3 * self.n_q), dtype=torch.float32, device=actions.device)
         rew = torch.empty((n,), dtype=torch.float32, device=actions.device)
         done = torch.empty((n,), dtype=torch.int32, device=actions.device)

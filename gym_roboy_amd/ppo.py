@@ -1,0 +1,173 @@
+"""PPO (clipped surrogate) with an MLP policy, on torch-ROCm.
+
+Consumer of the env: the reference trains with
+stable_baselines' TF1 ``PPO2("MlpPolicy", env, ent_coef=0.1)`` over a
+``SubprocVecEnv`` (``/root/reference/gym_roboy/train_parallel.py:28-35``).  Here
+the rollout never leaves the GPU: ``RoboyVecEnv.step`` takes the policy's action
+tensor and returns observation / reward / done tensors on the same HIP stream.
+Hyper-parameters default to stable_baselines PPO2's (n_steps 128, 4 minibatches,
+4 epochs, gamma 0.99, lambda 0.95, lr 2.5e-4, clip 0.2, vf 0.5, max grad norm
+0.5) with the reference's ``ent_coef = 0.1``.  With several ranks (one per GPU)
+gradients are averaged with ``torch.distributed.all_reduce`` (RCCL over xGMI).
+"""
+import math
+
+import torch
+from torch import nn
+
+
+class MlpPolicy(nn.Module):
+    """Two tanh layers of 64 units for the policy and for the value function,
+    diagonal Gaussian with a state-independent log-std (stable_baselines' MlpPolicy)."""
+
+    def __init__(self, obs_dim: int, act_dim: int, hidden: int = 64):
+        super().__init__()
+        def mlp(out):
+            return nn.Sequential(nn.Linear(obs_dim, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(),
+                                 nn.Linear(hidden, out))
+        self.pi, self.vf = mlp(act_dim), mlp(1)
+        self.log_std = nn.Parameter(torch.zeros(act_dim))
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.orthogonal_(m.weight, math.sqrt(2))
+                nn.init.zeros_(m.bias)
+        nn.init.orthogonal_(self.pi[-1].weight, 0.01)
+        nn.init.orthogonal_(self.vf[-1].weight, 1.0)
+
+    def dist(self, obs):
+        return torch.distributions.Normal(self.pi(obs), self.log_std.exp())
+
+    def value(self, obs):
+        return self.vf(obs).squeeze(-1)
+
+    @torch.no_grad()
+    def act(self, obs, deterministic=False):
+        d = self.dist(obs)
+        a = d.mean if deterministic else d.sample()
+        return a, d.log_prob(a).sum(-1), self.value(obs)
+
+
+def gae(rewards, values, dones, last_value, gamma, lam):
+    """Generalised advantage estimation over a [T, N] rollout (dones[t] = the
+    step t ended an episode)."""
+    T = rewards.shape[0]
+    adv = torch.zeros_like(rewards)
+    last = torch.zeros_like(last_value)
+    next_value = last_value
+    for t in range(T - 1, -1, -1):
+        nonterminal = 1.0 - dones[t]
+        delta = rewards[t] + gamma * next_value * nonterminal - values[t]
+        last = delta + gamma * lam * nonterminal * last
+        adv[t] = last
+        next_value = values[t]
+    return adv, adv + values
+
+
+def average_gradients(module, dist=None):
+    if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    world = dist.get_world_size()
+    flat = torch.cat([p.grad.reshape(-1) for p in module.parameters() if p.grad is not None])
+    dist.all_reduce(flat)          # one bucket: the policy is ~10^4 parameters
+    flat /= world
+    off = 0
+    for p in module.parameters():
+        if p.grad is not None:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+
+
+class PPO:
+    def __init__(self, env, policy=None, n_steps=128, nminibatches=4, noptepochs=4, gamma=0.99, lam=0.95,
+                 learning_rate=2.5e-4, cliprange=0.2, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5,
+                 device="cuda", dist=None, reward_scale=1.0, seed=0):
+        self.env, self.dist, self.device = env, dist, torch.device(device)
+        torch.manual_seed(seed)
+        obs_dim = env.observation_space.shape[0]
+        act_dim = env.action_space.shape[0]
+        self.policy = (policy or MlpPolicy(obs_dim, act_dim)).to(self.device)
+        if dist is not None and dist.is_available() and dist.is_initialized():
+            for p in self.policy.parameters():          # same initial weights on every rank
+                dist.broadcast(p.data, 0)
+        self.opt = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5)
+        self.n_steps, self.nminibatches, self.noptepochs = n_steps, nminibatches, noptepochs
+        self.gamma, self.lam, self.cliprange = gamma, lam, cliprange
+        self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
+        self.reward_scale = reward_scale
+        self.num_timesteps = 0
+        self._obs = None
+
+    def _to_tensor(self, x, dtype=torch.float32):
+        return x.to(self.device, dtype) if torch.is_tensor(x) else torch.as_tensor(x, dtype=dtype, device=self.device)
+
+    def collect(self):
+        env, T = self.env, self.n_steps
+        if self._obs is None:
+            self._obs = self._to_tensor(env.reset())
+        N = self._obs.shape[0]
+        buf = {k: [] for k in ("obs", "act", "logp", "val", "rew", "done")}
+        for _ in range(T):
+            a, logp, v = self.policy.act(self._obs)
+            clipped = a.clamp(-1.0, 1.0).contiguous()        # the env's action box (roboy_env.py:31)
+            obs, rew, done, _ = env.step(clipped if self.device.type == "cuda" else clipped.cpu().numpy())
+            buf["obs"].append(self._obs); buf["act"].append(a); buf["logp"].append(logp); buf["val"].append(v)
+            buf["rew"].append(self._to_tensor(rew) * self.reward_scale)
+            buf["done"].append(self._to_tensor(done))
+            self._obs = self._to_tensor(obs)
+        roll = {k: torch.stack(v) for k, v in buf.items()}
+        with torch.no_grad():
+            last_value = self.policy.value(self._obs)
+        roll["adv"], roll["ret"] = gae(roll["rew"], roll["val"], roll["done"], last_value, self.gamma, self.lam)
+        self.num_timesteps += T * N
+        return roll
+
+    def update(self, roll):
+        flat = {k: v.reshape(-1, *v.shape[2:]) for k, v in roll.items()}
+        n = flat["obs"].shape[0]
+        mb = max(n // self.nminibatches, 1)
+        stats = {}
+        for _ in range(self.noptepochs):
+            perm = torch.randperm(n, device=self.device)
+            for s in range(0, n - mb + 1, mb):
+                idx = perm[s:s + mb]
+                obs, act = flat["obs"][idx], flat["act"][idx]
+                adv = flat["adv"][idx]
+                adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+                d = self.policy.dist(obs)
+                logp = d.log_prob(act).sum(-1)
+                ratio = (logp - flat["logp"][idx]).exp()
+                pg = torch.max(-adv * ratio, -adv * ratio.clamp(1 - self.cliprange, 1 + self.cliprange)).mean()
+                v = self.policy.value(obs)
+                v_clip = flat["val"][idx] + (v - flat["val"][idx]).clamp(-self.cliprange, self.cliprange)
+                vf = 0.5 * torch.max((v - flat["ret"][idx]) ** 2, (v_clip - flat["ret"][idx]) ** 2).mean()
+                ent = d.entropy().sum(-1).mean()
+                loss = pg - self.ent_coef * ent + self.vf_coef * vf
+                self.opt.zero_grad(set_to_none=True)
+                loss.backward()
+                average_gradients(self.policy, self.dist)
+                nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+                self.opt.step()
+                stats = {"loss": loss.item(), "pg_loss": pg.item(), "vf_loss": vf.item(), "entropy": ent.item()}
+        return stats
+
+    def learn(self, total_timesteps, log=None):
+        target = self.num_timesteps + total_timesteps
+        while self.num_timesteps < target:
+            roll = self.collect()
+            stats = self.update(roll)
+            stats["mean_reward"] = roll["rew"].mean().item() / self.reward_scale
+            stats["timesteps"] = self.num_timesteps
+            if log:
+                log(stats)
+        return self
+
+    def save(self, path):
+        torch.save({"policy": self.policy.state_dict(), "optimizer": self.opt.state_dict(),
+                    "num_timesteps": self.num_timesteps}, path)
+
+    def load(self, path):
+        ck = torch.load(path, map_location=self.device)
+        self.policy.load_state_dict(ck["policy"]); self.opt.load_state_dict(ck["optimizer"])
+        self.num_timesteps = ck["num_timesteps"]
+        return self
