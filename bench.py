@@ -78,8 +78,29 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
     ring = torch.empty(RING * slab, dtype=torch.float32, device="cuda")
     for r in range(RING):
         sim.fill_actions_dev(ring.data_ptr() + 4 * r * slab, r)
-    stats = torch.zeros(8, dtype=torch.float64, device="cuda")
+    # statistics all-reduce: double-buffered and asynchronous, so the launch stream
+    # never waits for the (latency-bound, 64-byte) collective of the previous chunk
+    stats_ring = [torch.zeros(8, dtype=torch.float64, device="cuda") for _ in range(2)]
+    pending = [None, None]
+    state = {"chunk": 0, "last": stats_ring[0]}
     act_scale = float(robot.get_action_space().high[0])
+
+    def reduce_stats():
+        from gym_roboy_amd import _native as nat
+        import ctypes
+        slot = state["chunk"] % 2
+        state["chunk"] += 1
+        if pending[slot] is not None:
+            pending[slot].wait()
+        buf = stats_ring[slot]
+        nat.check(sim._lib.rb_env_stats_dev(sim.handle, ctypes.c_void_p(buf.data_ptr()), 0))
+        if dist.get_backend() == "nccl":
+            pending[slot] = dist.all_reduce(buf, async_op=True)     # RCCL over xGMI
+        else:                                                       # rehearsal over gloo: through the host
+            host = buf.cpu()
+            dist.all_reduce(host)
+            buf.copy_(host)
+        state["last"] = buf
 
     def rollout(k):
         done = 0
@@ -88,11 +109,12 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
             sim.rollout_dev(ring.data_ptr(), RING, chunk, act_scale, use_graph=use_graph)
             done += chunk
             if world > 1 and chunk == STATS_EVERY:
-                # episode statistics of the shard -> sum over ranks (RCCL over xGMI)
-                from gym_roboy_amd import _native as nat
-                import ctypes
-                nat.check(sim._lib.rb_env_stats_dev(sim.handle, ctypes.c_void_p(stats.data_ptr()), 0))
-                dist.all_reduce(stats)
+                reduce_stats()
+
+    def drain():
+        for w in pending:
+            if w is not None:
+                w.wait()
 
     # 16 untimed steps from the reset state decorrelate the envs, then warm-up
     rollout(16)
@@ -105,6 +127,7 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
     t0 = time.perf_counter()
     ev0.record(stream)
     rollout(steps)
+    drain()
     ev1.record(stream)
     torch.cuda.synchronize()
     if world > 1:
@@ -113,7 +136,7 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     q, qd, feas = sim.read_state()
@@ -128,6 +151,7 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
         "launch_us_events": launch_s * 1e6, "bytes_per_launch": bytes_per_launch,
         "achieved_GBps": bytes_per_launch / launch_s / 1e9,
         "kernel": {1: "msj_step_env_per_lane", 2: "msj_step_tendon_per_lane", 3: "tree_step_wave_per_env"}[info["kernel"]],
+        "stats": [float(x) for x in state["last"].cpu()],
         "finite": bool(np.isfinite(q).all() and np.isfinite(qd).all()),
         "feasible_frac": float(feas.mean()),
     }
@@ -182,11 +206,18 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the physics step)")
+    # ROBOY_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than
+    # ranks: ranks share the visible GPUs and the tiny collectives go over gloo.
+    backend = os.environ.get("ROBOY_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from gym_roboy_amd.envs.robots import MsjRobot, UpperBodyRobot
     robot = UpperBodyRobot() if args.workload.startswith("upper-body") else MsjRobot()
@@ -232,7 +263,8 @@ def main():
             },
             "cpu_baseline": cpu,
             "also": also,
-            "sanity": {"finite": head["finite"], "feasible_frac": head["feasible_frac"]},
+            "sanity": {"finite": head["finite"], "feasible_frac": head["feasible_frac"],
+                       "allreduced_stats": head["stats"]},
         }
         print(json.dumps(line))
     if world > 1:

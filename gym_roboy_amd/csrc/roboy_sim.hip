@@ -738,6 +738,7 @@ int rb_state_ptrs(rb_sim *s, float **d_q, float **d_qd, uint32_t **d_feasible) {
 
 int rb_step_dev(rb_sim *s, const float *d_act, float act_scale) {
     if (check(s) || !d_act) return fail(RB_EINVAL, "null argument");
+    RB_HIP(hipSetDevice(s->device));
     if (reinterpret_cast<uintptr_t>(d_act) % 16) return fail(RB_EINVAL, "action slab must be 16-byte aligned");
     s->env_steps += double(s->n);
     return launch_step(s, d_act, act_scale);
@@ -745,6 +746,7 @@ int rb_step_dev(rb_sim *s, const float *d_act, float act_scale) {
 
 int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float act_scale, int use_graph) {
     if (check(s) || !d_ring) return fail(RB_EINVAL, "null argument");
+    RB_HIP(hipSetDevice(s->device));
     if (ring < 1 || n_steps < 0) return fail(RB_EINVAL, "ring must be >= 1 and n_steps >= 0");
     if (reinterpret_cast<uintptr_t>(d_ring) % 16) return fail(RB_EINVAL, "action ring must be 16-byte aligned");
     const size_t slab = size_t(s->n) * s->n_t;
@@ -784,6 +786,7 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
 
 int rb_fill_actions_dev(rb_sim *s, float *d_act, uint32_t step) {
     if (check(s) || !d_act) return fail(RB_EINVAL, "null argument");
+    RB_HIP(hipSetDevice(s->device));
     hipLaunchKernelGGL(fill_actions_kernel, dim3(blocks_for(s->n, 256)), dim3(256), 0, s->stream,
                        d_act, s->n_t, s->n, s->seed, uint64_t(s->env0), step);
     RB_HIP(hipGetLastError());
@@ -792,6 +795,7 @@ int rb_fill_actions_dev(rb_sim *s, float *d_act, uint32_t step) {
 
 int rb_sample_goals_dev(rb_sim *s, const uint8_t *d_mask, float *d_goal_q) {
     if (check(s) || !d_goal_q) return fail(RB_EINVAL, "null argument");
+    RB_HIP(hipSetDevice(s->device));
     hipLaunchKernelGGL(sample_goals_kernel, dim3(blocks_for(s->n, 256)), dim3(256), 0, s->stream,
                        d_goal_q, s->d_goal_count, d_mask, s->box, s->n_q, s->n, s->seed, uint64_t(s->env0), 0);
     RB_HIP(hipGetLastError());
@@ -830,6 +834,7 @@ int rb_env_configure(rb_sim *s, const rb_env_config *cfg) {
 
 int rb_env_reset_dev(rb_sim *s, float *d_obs) {
     if (check(s)) return RB_EINVAL;
+    RB_HIP(hipSetDevice(s->device));
     if (!s->env_ready) return fail(RB_EINVAL, "rb_env_configure has not been called");
     hipLaunchKernelGGL(env_reset_kernel, dim3(blocks_for(s->n, 256)), dim3(256), 0, s->stream,
                        s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, s->d_ep_ret,
@@ -840,6 +845,7 @@ int rb_env_reset_dev(rb_sim *s, float *d_obs) {
 
 int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward, uint32_t *d_done) {
     if (check(s) || !d_act || !d_obs || !d_reward || !d_done) return fail(RB_EINVAL, "null argument");
+    RB_HIP(hipSetDevice(s->device));
     if (!s->env_ready) return fail(RB_EINVAL, "rb_env_configure has not been called");
     if (reinterpret_cast<uintptr_t>(d_act) % 16) return fail(RB_EINVAL, "action slab must be 16-byte aligned");
     const long n = s->n;
@@ -877,6 +883,7 @@ static int stats_reset(rb_sim *s) {
 
 int rb_env_stats_dev(rb_sim *s, double *d_stats8, int reset) {
     if (check(s) || !d_stats8) return fail(RB_EINVAL, "null argument");
+    RB_HIP(hipSetDevice(s->device));
     int rc = stats_launch(s, reset);
     if (rc) return rc;
     RB_HIP(hipMemcpyAsync(d_stats8, s->d_stats, sizeof(double) * 8, hipMemcpyDeviceToDevice, s->stream));
@@ -885,6 +892,7 @@ int rb_env_stats_dev(rb_sim *s, double *d_stats8, int reset) {
 
 int rb_env_stats(rb_sim *s, double *stats8, int reset) {
     if (check(s) || !stats8) return fail(RB_EINVAL, "null argument");
+    RB_HIP(hipSetDevice(s->device));
     int rc = stats_launch(s, reset);
     if (rc) return rc;
     RB_HIP(hipMemcpyAsync(stats8, s->d_stats, sizeof(double) * 8, hipMemcpyDeviceToHost, s->stream));

@@ -48,7 +48,7 @@ struct TreeDev {
     float kp, fl_k2, pe_k2, inv_pe_den, fv_c1l, fv_c2l, fv_c2s;
     // int tables
     const int *parent, *anc_mask, *order, *level_start, *child_start, *child_list, *lvp_start, *lvp_list,
-        *vp_link, *t_first, *t_count;
+        *vp_link, *t_first, *t_count, *pair_ij, *pair_start;
     // float tables
     const float *axis, *origin, *mass, *com, *inertia, *armature, *damping, *qlo, *qhi, *qdmax, *vp_pos,
         *t_inv_l0, *t_sg_l0, *t_fmax, *t_inv_vl0;
@@ -58,7 +58,7 @@ struct TreeHost {
     std::vector<int> ints;
     std::vector<float> floats;
     // offsets into the two buffers, same order as the TreeDev pointers
-    size_t io[11], fo[15];
+    size_t io[13], fo[15];
     TreeDev dev;   // scalars filled; pointers patched after upload
     size_t lds_floats = 0;
 };
@@ -130,6 +130,15 @@ inline int tree_build(const rb_robot_desc *d, double step_size, int nsub, TreeHo
     push_i(0, parent); push_i(1, anc); push_i(2, order); push_i(3, level_start); push_i(4, child_start);
     push_i(5, child_list); push_i(6, lvp_start); push_i(7, lvp_list);
     push_i(8, std::vector<int>(d->vp_link, d->vp_link + nvp)); push_i(9, t_first); push_i(10, t_count);
+    // strictly-lower-triangle pairs (i > j) ordered by column j, then row i: the
+    // trailing block of Cholesky column c is the contiguous range from pair_start[c + 1]
+    std::vector<int> pair_ij, pair_start(nq + 1, 0);
+    for (int j = 0; j < nq; ++j) {
+        pair_start[j] = int(pair_ij.size());
+        for (int i = j; i < nq; ++i) pair_ij.push_back((i << 8) | j);   // diagonal included (i == j)
+    }
+    pair_start[nq] = int(pair_ij.size());
+    push_i(11, pair_ij); push_i(12, pair_start);
     push_d(0, d->axis, 3 * nq); push_d(1, d->origin, 3 * nq); push_d(2, d->mass, nq); push_d(3, d->com, 3 * nq);
     push_d(4, d->inertia, 6 * nq); push_d(5, d->armature, nq); push_d(6, d->damping, nq); push_d(7, d->q_lo, nq);
     push_d(8, d->q_hi, nq); push_d(9, d->qd_max, nq); push_d(10, d->vp_pos, 3 * nvp);
@@ -150,11 +159,11 @@ inline int tree_build(const rb_robot_desc *d, double step_size, int nsub, TreeHo
 
 inline void tree_patch_pointers(TreeHost &h, const int *d_ints, const float *d_floats) {
     TreeDev &t = h.dev;
-    const int **ip[11] = {&t.parent, &t.anc_mask, &t.order, &t.level_start, &t.child_start, &t.child_list,
-                          &t.lvp_start, &t.lvp_list, &t.vp_link, &t.t_first, &t.t_count};
+    const int **ip[13] = {&t.parent, &t.anc_mask, &t.order, &t.level_start, &t.child_start, &t.child_list,
+                          &t.lvp_start, &t.lvp_list, &t.vp_link, &t.t_first, &t.t_count, &t.pair_ij, &t.pair_start};
     const float **fp[15] = {&t.axis, &t.origin, &t.mass, &t.com, &t.inertia, &t.armature, &t.damping, &t.qlo,
                             &t.qhi, &t.qdmax, &t.vp_pos, &t.t_inv_l0, &t.t_sg_l0, &t.t_fmax, &t.t_inv_vl0};
-    for (int i = 0; i < 11; ++i) *ip[i] = d_ints + h.io[i];
+    for (int i = 0; i < 13; ++i) *ip[i] = d_ints + h.io[i];
     for (int i = 0; i < 15; ++i) *fp[i] = d_floats + h.fo[i];
 }
 
@@ -386,28 +395,32 @@ __device__ __forceinline__ float tree_accel(const TreeDev &t, const Lds &s, int 
         s.M[e] = val;
     }
     __syncthreads();
-    // ---- Cholesky M = L L^T in place (lower triangle), wave-parallel ----
+    // ---- Cholesky M = L L^T in place (lower triangle), wave-parallel.  The
+    //      trailing update of column c touches the pairs (i >= j > c): one
+    //      contiguous range of the pair table, 64 pairs per pass.  1/L_cc is
+    //      kept in RHS-adjacent scratch (SQ is free by now) for the solves. ----
+    const int n_pairs = t.pair_start[nq];
     for (int c = 0; c < nq; ++c) {
         const float inv = __builtin_amdgcn_rsqf(s.M[c * nq + c]);
         __syncthreads();
         if (lane > c && lane < nq) s.M[lane * nq + c] *= inv;
-        if (lane == c) s.M[c * nq + c] = s.M[c * nq + c] * inv;   // sqrt(d) = d * rsqrt(d)
+        if (lane == c) { s.M[c * nq + c] = s.M[c * nq + c] * inv; s.SQ[c] = inv; }   // sqrt(d) = d * rsqrt(d)
         __syncthreads();
-        for (int i = c + 1; i < nq; ++i) {
-            // row i of the trailing block: lanes c < j <= i
-            if (lane > c && lane <= i) s.M[i * nq + lane] -= s.M[i * nq + c] * s.M[lane * nq + c];
+        for (int idx = t.pair_start[c + 1] + lane; idx < n_pairs; idx += 64) {
+            const int ij = t.pair_ij[idx], i = ij >> 8, j = ij & 255;
+            s.M[i * nq + j] -= s.M[i * nq + c] * s.M[j * nq + c];
         }
         __syncthreads();
     }
     // ---- forward and backward substitution on RHS (lane i owns row i) ----
     float bi = lane < nq ? s.RHS[lane] : 0.0f;
     for (int c = 0; c < nq; ++c) {
-        const float yc = __shfl(bi, c, 64) / s.M[c * nq + c];
+        const float yc = __shfl(bi, c, 64) * s.SQ[c];
         if (lane == c) bi = yc;
         else if (lane > c && lane < nq) bi -= s.M[lane * nq + c] * yc;
     }
     for (int c = nq - 1; c >= 0; --c) {
-        const float xc = __shfl(bi, c, 64) / s.M[c * nq + c];
+        const float xc = __shfl(bi, c, 64) * s.SQ[c];
         if (lane == c) bi = xc;
         else if (lane < c) bi -= s.M[c * nq + lane] * xc;
     }

@@ -1,0 +1,21 @@
+"""Throughput of the fused env layer (RoboyVecEnv.step_dev) at a few batch sizes (not the headline metric)."""
+import sys, time
+sys.path.insert(0, "/root/repo")
+import torch
+from gym_roboy_amd.envs.robots import MsjRobot
+from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+for n in (4096, 65536, 262144, 2097152):
+    with torch.cuda.stream(torch.cuda.Stream()):
+        env = RoboyVecEnv(MsjRobot(), n)
+        st = torch.cuda.current_stream(); env.sim.set_stream(st.cuda_stream)
+        acts = [torch.rand((n, 8), device="cuda") * 2 - 1 for _ in range(4)]
+        obs = torch.empty((n, 9), device="cuda"); rew = torch.empty(n, device="cuda"); done = torch.empty(n, dtype=torch.int32, device="cuda")
+        steps = 2000 if n <= 65536 else 300
+        for t in range(50): env.step_dev(acts[t % 4].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
+        torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter(); e0.record(st)
+        for t in range(steps): env.step_dev(acts[t % 4].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
+        e1.record(st); torch.cuda.synchronize(); wall = time.perf_counter() - t0
+        us = e0.elapsed_time(e1) * 1e3 / steps
+        print("fused env step n=%d: %.2f us/step (events), %.3e env-steps/s wall, %.1f GB/s at 156 B/env-step" % (n, us, n * steps / wall, n * 156 / us / 1e3))
+        env.close()
