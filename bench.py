@@ -44,6 +44,20 @@ HBM_PEAK = 8.0e12          # B/s, spec (MI355X_MICROARCH.md "HBM3E peak BW")
 HBM_COPY = 6.29e12         # B/s, measured float4 copy (same table)
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC
+    passes (profiles/r1_b/hbm_traffic_pmc.json: separate --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE runs of this workload, FETCH_SIZE doubled as the gfx950
+    guide prescribes).  PMC collection cannot run inside the timed bench, so the
+    number is the profiled one, not a live one; None if the workload was not profiled."""
+    path = os.path.join(ROOT, "profiles", "r1_b", "hbm_traffic_pmc.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh)[workload]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -255,7 +269,9 @@ def main():
                                       % (world, STATS_EVERY) if world > 1 else "single GPU"},
             "roofline": {
                 "bound": "hbm", "achieved": head["achieved_GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": head["achieved_GBps"] * 1e9 / HBM_PEAK, "traffic": None,
+                "frac": head["achieved_GBps"] * 1e9 / HBM_PEAK,
+                "traffic": pmc_traffic(args.workload) if args.envs is None and args.substeps is None else None,
+                "traffic_source": "rocprofv3 --pmc passes committed in profiles/r1_b/hbm_traffic_pmc.json (bytes per launch)",
                 "kernel": head["kernel"], "bytes_per_env_step": head["bytes_per_launch"] // head["envs_per_gpu"],
                 "bytes_per_launch": head["bytes_per_launch"], "launch_us_events": head["launch_us_events"],
                 "note": "events bracket the whole timed region on the launch stream, so the per-launch "

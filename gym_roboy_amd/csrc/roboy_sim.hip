@@ -135,7 +135,15 @@ __global__ void __launch_bounds__(64)
 msj_step_tendon_per_lane(const Const8 c, const rb::MsjTendon<float> *__restrict__ ten,
                          float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
                          const float *__restrict__ act, float act_scale, long n) {
-    const long t = long(blockIdx.x) * 64 + threadIdx.x;
+    // XCD-aware block -> env-group map.  A wave touches only 32 bytes of each
+    // state plane, so four consecutive waves share every 128-byte line; workgroups
+    // are dealt round-robin over the 8 XCDs (private L2s), which made each line
+    // travel to four L2s (PMC: 2.5x the algorithmic read bytes).  Blocks that share
+    // an XCD (equal blockIdx % 8) now take one contiguous range of env groups
+    // (bijective form of cdna_hip_programming.md T1; affects traffic only).
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7u, qn = nb >> 3, rn = nb & 7u;
+    const unsigned blk = (xcd < rn ? xcd * (qn + 1u) : rn * (qn + 1u) + (xcd - rn) * qn) + (blockIdx.x >> 3);
+    const long t = long(blk) * 64 + threadIdx.x;
     const int k = threadIdx.x & 7;
     long e = t >> 3;
     const bool live = e < n;          // whole 8-lane groups are live or not; dead groups

@@ -1,0 +1,87 @@
+"""BASELINE.json's full batch sizes (262 144 envs RK4; 2 097 152 envs Euler),
+checked through size-independent properties - the oracle cannot run 2M envs in
+seconds, so: a strided sample of the full batch against the oracle, env
+permutation equivariance, shard invariance, determinism, the rest equilibrium,
+and the boundary behaviour, all on the full-size launch configuration."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _states(desc, n, seed):
+    rng = np.random.default_rng(seed)
+    q = rng.uniform(0.98 * desc.q_lo, 0.98 * desc.q_hi, (n, desc.n_q)).astype(np.float32)
+    qd = rng.uniform(-desc.qd_max, desc.qd_max, (n, desc.n_q)).astype(np.float32)
+    sp = rng.uniform(-0.3, 0.3, (n, desc.n_t)).astype(np.float32)
+    return q, qd, sp
+
+
+@pytest.mark.parametrize("n,integrator", [(262144, "rk4"), (2097152, "euler")])
+def test_full_batch_sample_matches_oracle_and_is_permutation_equivariant(msj_robot, n, integrator):
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    from oracle.c_oracle import COracle
+    desc = msj_robot.get_description()
+    q, qd, sp = _states(desc, n, 1)
+    sim = HipBatchSimulation(msj_robot, n, integrator=integrator)
+    sim.set_state(q, qd)
+    q1, qd1, f1 = sim.forward_step_command(sp)
+    # (a) every 509th env against the fp64 oracle (509 is prime: all lanes / waves / workgroup slots get hit)
+    idx = np.arange(0, n, 509)
+    qo, qdo, fo = COracle(desc, "f64").step(q[idx], qd[idx], sp[idx], integrator=0 if integrator == "euler" else 1)
+    assert np.abs(q1[idx] - qo).max() < 2e-5 and np.abs(qd1[idx] - qdo).max() < 2e-5
+    assert np.mean(f1[idx] == fo) > 0.999
+    # (b) determinism: the same launch again gives the same bits
+    sim.set_state(q, qd)
+    q2, qd2, f2 = sim.forward_step_command(sp)
+    assert np.array_equal(q1, q2) and np.array_equal(qd1, qd2) and np.array_equal(f1, f2)
+    # (c) envs are independent: permuting the batch permutes the result, bit for bit
+    perm = np.random.default_rng(2).permutation(n)
+    sim.set_state(q[perm], qd[perm])
+    q3, qd3, f3 = sim.forward_step_command(sp[perm])
+    assert np.array_equal(q3, q1[perm]) and np.array_equal(qd3, qd1[perm]) and np.array_equal(f3, f1[perm])
+    sim.close()
+
+
+def test_full_batch_shards_reproduce_the_whole(msj_robot):
+    """configs[4]: 2 097 152 envs = 8 shards of 262 144; two of the shards here,
+    driven by the device action stream, against the same rows of one big batch."""
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    n_shard, seed = 262144, 4
+    whole = HipBatchSimulation(msj_robot, 2 * n_shard, seed=seed)
+    parts = [HipBatchSimulation(msj_robot, n_shard, seed=seed, env_id_offset=r * n_shard) for r in (0, 1)]
+    def run(sim):
+        d = sim.malloc(4 * sim.n_envs * 8)
+        for t in range(12):
+            sim.fill_actions_dev(d, t)
+            sim.step_dev(d, 0.3)
+        sim.synchronize()
+        return sim.read_state()
+    qw, qdw, fw = run(whole)
+    for r, p in enumerate(parts):
+        qp, qdp, fp = run(p)
+        sl = slice(r * n_shard, (r + 1) * n_shard)
+        assert np.array_equal(qw[sl], qp) and np.array_equal(qdw[sl], qdp) and np.array_equal(fw[sl], fp)
+        p.close()
+    assert np.abs(qw).max() > 0.01
+    whole.close()
+
+
+def test_full_batch_rest_equilibrium_and_boundary(msj_robot):
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    n = 2097152
+    sim = HipBatchSimulation(msj_robot, n)
+    d = sim.malloc(4 * n * 8)
+    sim.upload(d, np.zeros((n, 8), np.float32))
+    sim.rollout_dev(d, 1, 20, 1.0, use_graph=True)
+    sim.synchronize()
+    q, qd, f = sim.read_state()
+    assert not q.any() and not qd.any() and f.all()          # exact equilibrium, every env
+    sim.upload(d, np.tile(msj_robot.get_action_space().low, (n, 1)))
+    sim.rollout_dev(d, 1, 40, 1.0, use_graph=False)
+    sim.synchronize()
+    q, qd, f = sim.read_state()
+    assert not f.any()                                        # all pushed into a limit and stay there
+    assert np.all(np.abs(q) <= np.float32(0.6) + 1e-6)
+    assert np.array_equal(q[0], q[-1]) and np.array_equal(q[0], q[n // 2])   # identical inputs, identical outputs
+    sim.close()
