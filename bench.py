@@ -173,23 +173,26 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
 
 def cpu_baseline(robot, seconds, name):
     """The C restatement of the same step (oracle/roboy_oracle.c, fp32 build)
-    timed on this box's host cores on a bounded sample of the workload."""
+    timed on this box's host cores on a bounded sample of the workload: first
+    one thread (the scalar port), then OpenMP over envs on up to 64 cores with
+    a sample large enough (>= 256 envs per thread) for the threads to pay off."""
     from oracle.c_oracle import COracle
     from oracle import philox_np as ph
     n_envs, integrator, nsub, *_ = WORKLOADS[name]
-    n = min(n_envs, 4096 if robot.get_description().n_q <= 3 else 512)
     desc = robot.get_description()
     orc = COracle(desc, "f32")
     integ = 0 if integrator == "euler" else 1
-    ids = np.arange(n, dtype=np.uint64)
-    slabs = [np.ascontiguousarray(ph.actions(0, ids, r, desc.n_t) * np.float32(0.3)) for r in range(RING)]
-    q = np.zeros((n, desc.n_q), np.float32)
-    qd = np.zeros((n, desc.n_q), np.float32)
-    feas = np.zeros(n, np.uint8)
-    out = {}
+    small = desc.n_q <= 3
     cores_avail = len(os.sched_getaffinity(0))
-    for threads in sorted({1, cores_avail}):
-        for t in range(16):
+    out = {}
+    for threads in sorted({1, min(cores_avail, 64)}):
+        n = min(n_envs, 4096 if small else 512) if threads == 1 else min(max(n_envs, 256 * threads), 65536 if small else 16384)
+        ids = np.arange(n, dtype=np.uint64)
+        slabs = [np.ascontiguousarray(ph.actions(0, ids, r, desc.n_t) * np.float32(0.3)) for r in range(RING)]
+        q = np.zeros((n, desc.n_q), np.float32)
+        qd = np.zeros((n, desc.n_q), np.float32)
+        feas = np.zeros(n, np.uint8)
+        for t in range(4):
             orc.step_inplace(q, qd, slabs[t % RING], feas, integrator=integ, n_substeps=nsub, threads=threads)
         budget = seconds / 2
         t0 = time.perf_counter()
@@ -197,12 +200,12 @@ def cpu_baseline(robot, seconds, name):
         while time.perf_counter() - t0 < budget:
             orc.step_inplace(q, qd, slabs[k % RING], feas, integrator=integ, n_substeps=nsub, threads=threads)
             k += 1
-        out[threads] = (n * k / (time.perf_counter() - t0), k)
+        out[threads] = (n * k / (time.perf_counter() - t0), k, n)
     best = max(out, key=lambda th: out[th][0])
     return {
         "value": out[best][0], "unit": "env-steps/s", "cores": best, "kind": "port",
-        "sample": "%d envs x %d steps of %s, C fp32 restatement (oracle/roboy_oracle.c), OpenMP over envs"
-                  % (n, out[best][1], name),
+        "sample": "%d envs x %d steps of %s, C fp32 restatement (oracle/roboy_oracle.c), %s"
+                  % (out[best][2], out[best][1], name, "OpenMP over envs" if best > 1 else "one thread"),
         "value_1_core": out[1][0], "host_cores_available": cores_avail,
     }
 

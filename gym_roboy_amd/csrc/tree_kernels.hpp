@@ -256,40 +256,50 @@ __device__ __forceinline__ float tree_accel(const TreeDev &t, const Lds &s, int 
             const V3 api = app + cross(alp, r) + cross(wp, cross(wp, r));
             const V3 wi = wp + zi * qd;
             const V3 ali = alp + cross(wp, zi) * qd;
-            const V3 rc = mul(Ri, ld3(t.com + 3 * i));
-            const V3 ac = api + cross(ali, rc) + cross(wi, cross(wi, rc));
             const float m = t.mass[i];
-            const V3 F = ac * m;
-            // Iw = R I R^T (symmetric)
             const float *I6 = t.inertia + 6 * i;
-            M3 RI;
-#pragma unroll
-            for (int rr = 0; rr < 3; ++rr) {
-                const V3 row = {Ri.m[3 * rr], Ri.m[3 * rr + 1], Ri.m[3 * rr + 2]};
-                const V3 ri = symmul(I6, row);     // (R I)_row = I row (I symmetric)
-                RI.m[3 * rr] = ri.x; RI.m[3 * rr + 1] = ri.y; RI.m[3 * rr + 2] = ri.z;
-            }
-            float Iw[6];
-            {
-                auto rowdot = [&](int r1, int r2) {
-                    return RI.m[3 * r1] * Ri.m[3 * r2] + RI.m[3 * r1 + 1] * Ri.m[3 * r2 + 1] + RI.m[3 * r1 + 2] * Ri.m[3 * r2 + 2];
-                };
-                Iw[0] = rowdot(0, 0); Iw[1] = rowdot(1, 1); Iw[2] = rowdot(2, 2);
-                Iw[3] = rowdot(0, 1); Iw[4] = rowdot(0, 2); Iw[5] = rowdot(1, 2);
-            }
-            const V3 N = symmul(Iw, ali) + cross(wi, symmul(Iw, wi));
 #pragma unroll
             for (int e = 0; e < 9; ++e) s.R[9 * i + e] = Ri.m[e];
             st3(s.P + 3 * i, pi); st3(s.Z + 3 * i, zi); st3(s.W + 3 * i, wi); st3(s.VP + 3 * i, vpi);
             st3(s.AL + 3 * i, ali); st3(s.AP + 3 * i, api);
-            st3(s.FF + 3 * i, F); st3(s.NN + 3 * i, N + cross(rc, F));
-            // composite-inertia seed, about the world origin
-            const V3 cw = pi + rc;
-            const float c2 = dot(cw, cw);
-            s.CM[i] = m; st3(s.CH + 3 * i, cw * m);
             float *ci = s.CI + 6 * i;
-            ci[0] = Iw[0] + m * (c2 - cw.x * cw.x); ci[1] = Iw[1] + m * (c2 - cw.y * cw.y); ci[2] = Iw[2] + m * (c2 - cw.z * cw.z);
-            ci[3] = Iw[3] - m * cw.x * cw.y; ci[4] = Iw[4] - m * cw.x * cw.z; ci[5] = Iw[5] - m * cw.y * cw.z;
+            // massless virtual links (the x/y joints of a ball joint) skip the
+            // inertia arithmetic; whole levels of them take the branch uniformly
+            if (m != 0.0f || I6[0] != 0.0f || I6[1] != 0.0f || I6[2] != 0.0f) {
+                const V3 rc = mul(Ri, ld3(t.com + 3 * i));
+                const V3 ac = api + cross(ali, rc) + cross(wi, cross(wi, rc));
+                const V3 F = ac * m;
+                // Iw = R I R^T (symmetric)
+                M3 RI;
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) {
+                    const V3 row = {Ri.m[3 * rr], Ri.m[3 * rr + 1], Ri.m[3 * rr + 2]};
+                    const V3 ri = symmul(I6, row);     // (R I)_row = I row (I symmetric)
+                    RI.m[3 * rr] = ri.x; RI.m[3 * rr + 1] = ri.y; RI.m[3 * rr + 2] = ri.z;
+                }
+                float Iw[6];
+                {
+                    auto rowdot = [&](int r1, int r2) {
+                        return RI.m[3 * r1] * Ri.m[3 * r2] + RI.m[3 * r1 + 1] * Ri.m[3 * r2 + 1] + RI.m[3 * r1 + 2] * Ri.m[3 * r2 + 2];
+                    };
+                    Iw[0] = rowdot(0, 0); Iw[1] = rowdot(1, 1); Iw[2] = rowdot(2, 2);
+                    Iw[3] = rowdot(0, 1); Iw[4] = rowdot(0, 2); Iw[5] = rowdot(1, 2);
+                }
+                const V3 N = symmul(Iw, ali) + cross(wi, symmul(Iw, wi));
+                st3(s.FF + 3 * i, F); st3(s.NN + 3 * i, N + cross(rc, F));
+                // composite-inertia seed, about the world origin
+                const V3 cw = pi + rc;
+                const float c2 = dot(cw, cw);
+                s.CM[i] = m; st3(s.CH + 3 * i, cw * m);
+                ci[0] = Iw[0] + m * (c2 - cw.x * cw.x); ci[1] = Iw[1] + m * (c2 - cw.y * cw.y); ci[2] = Iw[2] + m * (c2 - cw.z * cw.z);
+                ci[3] = Iw[3] - m * cw.x * cw.y; ci[4] = Iw[4] - m * cw.x * cw.z; ci[5] = Iw[5] - m * cw.y * cw.z;
+            } else {
+                const V3 zero = {0.0f, 0.0f, 0.0f};
+                st3(s.FF + 3 * i, zero); st3(s.NN + 3 * i, zero); st3(s.CH + 3 * i, zero);
+                s.CM[i] = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 6; ++e) ci[e] = 0.0f;
+            }
         }
         __syncthreads();
     }

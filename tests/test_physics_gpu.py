@@ -234,3 +234,42 @@ def test_random_streams_match_the_numpy_restatement_bit_for_bit(msj_robot):
         seen.append(got)
     assert not np.allclose(seen[0], seen[1]) and not np.allclose(seen[1], seen[2])
     sim.close()
+
+
+def test_states_outside_the_feasible_region_are_clamped_and_flagged(msj_robot):
+    """An env handed a pose beyond a joint limit comes back clamped onto the
+    limit with the outward velocity removed and is flagged infeasible; angles
+    always satisfy RoboyRobot.new_state's assert (roboy_robot.py:76)."""
+    desc = msj_robot.get_description()
+    n = 64
+    q = np.zeros((n, 3), np.float32); qd = np.zeros((n, 3), np.float32)
+    q[:, 0] = 3.0; qd[:, 0] = 0.5          # far beyond +0.45, moving outward
+    q[1::2, 1] = -3.0; qd[1::2, 1] = -0.5  # and beyond the lower limit for half of them
+    for kernel in (1, 2):
+        sim = _sim(msj_robot, n)
+        sim.select_kernel(kernel)
+        sim.set_state(q, qd)
+        q1, qd1, f1 = sim.forward_step_command(np.zeros((n, 8), np.float32))
+        assert not f1.any()
+        assert np.all(q1[:, 0] == np.float32(desc.q_hi[0])) and np.all(qd1[:, 0] <= 0)
+        assert np.all(q1[1::2, 1] == np.float32(desc.q_lo[1])) and np.all(qd1[1::2, 1] >= 0)
+        assert msj_robot.get_joint_angles_space().contains(q1[0])
+        sim.close()
+
+
+def test_bad_arguments_raise(msj_robot):
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    with pytest.raises(ValueError):
+        HipBatchSimulation(msj_robot, 0)
+    with pytest.raises(ValueError):
+        HipBatchSimulation(msj_robot, 8, integrator="verlet")
+    sim = _sim(msj_robot, 8)
+    with pytest.raises(ValueError):
+        sim.forward_step_command(np.zeros((7, 8), np.float32))      # wrong batch
+    with pytest.raises(ValueError):
+        sim.set_state(np.zeros((8, 2), np.float32), np.zeros((8, 3), np.float32))
+    with pytest.raises(ValueError):
+        sim.step_dev(0)                                             # null device pointer
+    with pytest.raises(ValueError):
+        sim.select_kernel(9)
+    sim.close()
