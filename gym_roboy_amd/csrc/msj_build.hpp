@@ -64,10 +64,12 @@ int msj_build(const rb_robot_desc *d, double step_size, int nsub, MsjConst<T, NT
         const double l0 = lc + moving0;
         MsjTendon<T> &t = c.ten[k];
         for (int a = 0; a < 3; ++a) { t.A[a] = T(d->vp_pos[3 * va + a]); t.B[a] = T(d->vp_pos[3 * vb + a]); }
-        t.lc = T(lc); t.inv_l0 = T(1.0 / l0); t.sg_l0 = T(d->setpoint_scale / l0);
+        double ab2 = 0.0;
+        for (int a = 0; a < 3; ++a) ab2 += d->vp_pos[3 * va + a] * d->vp_pos[3 * va + a] + d->vp_pos[3 * vb + a] * d->vp_pos[3 * vb + a];
+        t.ab2 = T(ab2); t.inv_l0 = T(1.0 / l0); t.e_lc = T(lc / l0 - 1.0); t.sg_l0 = T(d->setpoint_scale / l0);
         t.fmax = T(d->f_max[k]);
         t.inv_vl0 = T(1.0 / (d->v_max * l0));
-        for (int a = 0; a < 5; ++a) t.pad[a] = T(0);
+        for (int a = 0; a < 4; ++a) t.pad[a] = T(0);
     }
     const double m = d->mass[2];
     const double *cm = d->com + 6, *ic = d->inertia + 12;
@@ -94,6 +96,8 @@ int msj_build(const rb_robot_desc *d, double step_size, int nsub, MsjConst<T, NT
     c.fv_c2s = T(-1.0 / d->fv_a);
     c.fv_c1l = T(d->fv_n * c2l); c.fv_c2l = T(c2l);
     c.h = T(step_size / nsub); c.nsub = nsub;
+    c.simple = (ic[3] == 0.0 && ic[4] == 0.0 && ic[5] == 0.0 && cm[0] == 0.0 && cm[1] == 0.0 &&
+                d->gravity[0] == 0.0 && d->gravity[1] == 0.0) ? 1 : 0;
     return RB_OK;
 }
 

@@ -98,12 +98,13 @@ template <typename T>
 struct alignas(64) MsjTendon {
     T A[3];        // last base via-point, world = base frame
     T B[3];        // first body via-point, body frame
-    T lc;          // summed length of the segments that do not move
+    T ab2;         // |A|^2 + |B|^2
     T inv_l0;      // 1 / rest length
+    T e_lc;        // lc / l0 - 1  (lc = summed length of the segments that do not move)
     T sg_l0;       // setpoint_scale / rest length
     T fmax;        // maximum isometric force
     T inv_vl0;     // 1 / (v_max * rest length)
-    T pad[5];
+    T pad[4];
 };
 
 template <typename T, int NT>
@@ -121,6 +122,7 @@ struct MsjConst {
     T fv_c2s;
     T h;              // integrator substep
     int32_t nsub;
+    int32_t simple;   // 1: principal-axis inertia, COM on body z, gravity along world z (fast path)
 };
 
 // set-points held in a per-lane register array (compile-time indices only)
@@ -160,21 +162,21 @@ struct MsjModel {
     // one tendon: routing, Hill-type force, torque about the joint centre (body
     // frame) subtracted from (tx,ty,tz)
     static RB_HD void tendon(const C &c, const Frame &f, const MsjTendon<T> &t, T spk, T &tx, T &ty, T &tz) {
+        // a = R^T A (body frame).  With |a| = |A|:  |B - a|^2 = (|A|^2 + |B|^2) - 2 a.B,
+        // and the torque arm w = B x (B - a)/|d| = (a x B)/|d|, so neither the
+        // difference vector nor the unit vector is formed.
         const T ax = f.r00 * t.A[0] + f.r10 * t.A[1] + f.r20 * t.A[2];
         const T ay = f.r01 * t.A[0] + f.r11 * t.A[1] + f.r21 * t.A[2];
         const T az = f.r02 * t.A[0] + f.r12 * t.A[1] + f.r22 * t.A[2];
-        const T dx = t.B[0] - ax, dy = t.B[1] - ay, dz = t.B[2] - az;
-        const T d2 = dx * dx + dy * dy + dz * dz;
+        const T d2 = t.ab2 - T(2) * (ax * t.B[0] + ay * t.B[1] + az * t.B[2]);
         const T inv = Fast<T>::rsqrt(d2);
-        const T len = d2 * inv + t.lc;
-        const T ux = dx * inv, uy = dy * inv, uz = dz * inv;
-        // w = B x u
-        const T mx = t.B[1] * uz - t.B[2] * uy;
-        const T my = t.B[2] * ux - t.B[0] * uz;
-        const T mz = t.B[0] * uy - t.B[1] * ux;
-        const T ldot = f.wx * mx + f.wy * my + f.wz * mz;
-        // Hill-type muscle: e = l/l0 - 1, err = e - (sigma/l0) s
-        const T e = len * t.inv_l0 - T(1);
+        // cr = a x B;  w = cr * inv
+        const T mx = ay * t.B[2] - az * t.B[1];
+        const T my = az * t.B[0] - ax * t.B[2];
+        const T mz = ax * t.B[1] - ay * t.B[0];
+        const T ldot = (f.wx * mx + f.wy * my + f.wz * mz) * inv;
+        // Hill-type muscle: e = l/l0 - 1 = |d|/l0 + (lc/l0 - 1), err = e - (sigma/l0) s
+        const T e = (d2 * inv) * t.inv_l0 + t.e_lc;
         const T act = tclamp(c.kp * (e - t.sg_l0 * spk), T(0), T(1));
         const T fl = Fast<T>::exp2(c.fl_k2 * (e * e));
         // f_V = (1 + c1 v)/(1 + c2 v) per branch, written branch-free with
@@ -185,32 +187,17 @@ struct MsjModel {
         const T den = c.fv_c2l * vp + (c.fv_c2s * vm + T(1));
         const T fv = num * Fast<T>::rcp(den);          // >= 0: num >= 0, den >= 1
         const T fpe = tmax((Fast<T>::exp2(c.pe_k2 * e) - T(1)) * c.inv_pe_den, T(0));
-        const T F = t.fmax * (act * fl * fv + fpe);
-        tx -= F * mx; ty -= F * my; tz -= F * mz;
+        const T Fs = t.fmax * (act * fl * fv + fpe) * inv;     // tension / |d|
+        tx -= Fs * mx; ty -= Fs * my; tz -= Fs * mz;
     }
 
-    // rigid body about the joint centre: qdd from the summed tendon torque
+    // rigid body about the joint centre: qdd from the summed tendon torque.
+    // c.simple (wave-uniform) marks the common case - principal-axis inertia,
+    // centre of mass on the body z axis, gravity along world z - in which a
+    // third of the terms vanish; the branch is a scalar one.
     static RB_HD void rigid_body(const C &c, const Frame &f, const T qd[3], T tx, T ty, T tz, T qdd[3]) {
         const T r00 = f.r00, r01 = f.r01, r02 = f.r02, s2 = f.s2, c2 = f.c2;
-        const T Ixx = c.IO[0], Iyy = c.IO[1], Izz = c.IO[2], Ixy = c.IO[3], Ixz = c.IO[4], Iyz = c.IO[5];
-        // columns I_O zeta_j
-        const T a0x = Ixx * r00 + Ixy * r01 + Ixz * r02;
-        const T a0y = Ixy * r00 + Iyy * r01 + Iyz * r02;
-        const T a0z = Ixz * r00 + Iyz * r01 + Izz * r02;
-        const T a1x = Ixx * s2 + Ixy * c2;
-        const T a1y = Ixy * s2 + Iyy * c2;
-        const T a1z = Ixz * s2 + Iyz * c2;
-        // M = zeta^T I_O zeta + armature
-        const T m00 = r00 * a0x + r01 * a0y + r02 * a0z + c.arm[0];
-        const T m01 = s2 * a0x + c2 * a0y;
-        const T m02 = a0z;
-        const T m11 = s2 * a1x + c2 * a1y + c.arm[1];
-        const T m12 = a1z;
-        const T m22 = Izz + c.arm[2];
-        // angular momentum and gyroscopic term
-        const T hx = a0x * qd[0] + a1x * qd[1] + Ixz * qd[2];
-        const T hy = a0y * qd[0] + a1y * qd[1] + Iyz * qd[2];
-        const T hz = a0z * qd[0] + a1z * qd[1] + Izz * qd[2];
+        const T Ixx = c.IO[0], Iyy = c.IO[1], Izz = c.IO[2];
         // zeta_dot qd
         const T z0x = -f.s1 * c2 * qd[1] - f.c1 * s2 * qd[2];
         const T z0y = f.s1 * s2 * qd[1] - f.c1 * c2 * qd[2];
@@ -218,16 +205,56 @@ struct MsjModel {
         const T bx = z0x * qd[0] + c2 * qd[2] * qd[1];
         const T by = z0y * qd[0] - s2 * qd[2] * qd[1];
         const T bz = z0z * qd[0];
-        const T nx = Ixx * bx + Ixy * by + Ixz * bz + (f.wy * hz - f.wz * hy);
-        const T ny = Ixy * bx + Iyy * by + Iyz * bz + (f.wz * hx - f.wx * hz);
-        const T nz = Ixz * bx + Iyz * by + Izz * bz + (f.wx * hy - f.wy * hx);
-        // gravity torque (m c) x R^T g
-        const T gx = r00 * c.g[0] + f.r10 * c.g[1] + f.r20 * c.g[2];
-        const T gy = r01 * c.g[0] + f.r11 * c.g[1] + f.r21 * c.g[2];
-        const T gz = r02 * c.g[0] + f.r12 * c.g[1] + f.r22 * c.g[2];
-        const T vx = tx + (c.mc[1] * gz - c.mc[2] * gy) - nx;
-        const T vy = ty + (c.mc[2] * gx - c.mc[0] * gz) - ny;
-        const T vz = tz + (c.mc[0] * gy - c.mc[1] * gx) - nz;
+        T m00, m01, m02, m11, m12, m22, vx, vy, vz;
+        if (c.simple) {
+            // I_O = diag(Ixx, Iyy, Izz), m c = (0, 0, mcz), g = (0, 0, gz)
+            const T a0x = Ixx * r00, a0y = Iyy * r01, a0z = Izz * r02;
+            const T a1x = Ixx * s2, a1y = Iyy * c2;
+            m00 = r00 * a0x + r01 * a0y + r02 * a0z + c.arm[0];
+            m01 = s2 * a0x + c2 * a0y;
+            m02 = a0z;
+            m11 = s2 * a1x + c2 * a1y + c.arm[1];
+            m12 = T(0);
+            m22 = Izz + c.arm[2];
+            const T hx = Ixx * f.wx, hy = Iyy * f.wy, hz = Izz * f.wz;      // I_O w
+            const T nx = Ixx * bx + (f.wy * hz - f.wz * hy);
+            const T ny = Iyy * by + (f.wz * hx - f.wx * hz);
+            const T nz = Izz * bz + (f.wx * hy - f.wy * hx);
+            const T k = c.mc[2] * c.g[2];                                   // (m c) x R^T g
+            vx = tx - k * f.r21 - nx;
+            vy = ty + k * f.r20 - ny;
+            vz = tz - nz;
+        } else {
+            const T Ixy = c.IO[3], Ixz = c.IO[4], Iyz = c.IO[5];
+            // columns I_O zeta_j
+            const T a0x = Ixx * r00 + Ixy * r01 + Ixz * r02;
+            const T a0y = Ixy * r00 + Iyy * r01 + Iyz * r02;
+            const T a0z = Ixz * r00 + Iyz * r01 + Izz * r02;
+            const T a1x = Ixx * s2 + Ixy * c2;
+            const T a1y = Ixy * s2 + Iyy * c2;
+            const T a1z = Ixz * s2 + Iyz * c2;
+            // M = zeta^T I_O zeta + armature
+            m00 = r00 * a0x + r01 * a0y + r02 * a0z + c.arm[0];
+            m01 = s2 * a0x + c2 * a0y;
+            m02 = a0z;
+            m11 = s2 * a1x + c2 * a1y + c.arm[1];
+            m12 = a1z;
+            m22 = Izz + c.arm[2];
+            // angular momentum and gyroscopic term
+            const T hx = a0x * qd[0] + a1x * qd[1] + Ixz * qd[2];
+            const T hy = a0y * qd[0] + a1y * qd[1] + Iyz * qd[2];
+            const T hz = a0z * qd[0] + a1z * qd[1] + Izz * qd[2];
+            const T nx = Ixx * bx + Ixy * by + Ixz * bz + (f.wy * hz - f.wz * hy);
+            const T ny = Ixy * bx + Iyy * by + Iyz * bz + (f.wz * hx - f.wx * hz);
+            const T nz = Ixz * bx + Iyz * by + Izz * bz + (f.wx * hy - f.wy * hx);
+            // gravity torque (m c) x R^T g
+            const T gx = r00 * c.g[0] + f.r10 * c.g[1] + f.r20 * c.g[2];
+            const T gy = r01 * c.g[0] + f.r11 * c.g[1] + f.r21 * c.g[2];
+            const T gz = r02 * c.g[0] + f.r12 * c.g[1] + f.r22 * c.g[2];
+            vx = tx + (c.mc[1] * gz - c.mc[2] * gy) - nx;
+            vy = ty + (c.mc[2] * gx - c.mc[0] * gz) - ny;
+            vz = tz + (c.mc[0] * gy - c.mc[1] * gx) - nz;
+        }
         const T t0 = r00 * vx + r01 * vy + r02 * vz - c.damp[0] * qd[0];
         const T t1 = s2 * vx + c2 * vy - c.damp[1] * qd[1];
         const T t2 = vz - c.damp[2] * qd[2];

@@ -187,3 +187,30 @@ def test_empty_batch_is_handled(msj_oracle, desc):
     q, qd, ok = msj_oracle.step(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 8)))
     assert q.shape == (0, 3) and ok.shape == (0,)
     assert COracle(desc).step(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 8)))[0].shape == (0, 3)
+
+
+def _skewed_msj():
+    """MSJ variant with a full inertia tensor, an off-axis centre of mass and tilted
+    gravity: exercises the general branch of the closed form (c.simple == 0)."""
+    from gym_roboy_amd.envs.robots import RobotDescription, msj_platform_spec
+    spec = msj_platform_spec()
+    spec["joints"][2]["com"] = [0.012, -0.02, 0.06]
+    spec["joints"][2]["inertia"] = [3.0e-4, 3.5e-4, 5.0e-4, 4.0e-5, -3.0e-5, 2.0e-5]
+    spec["gravity"] = [1.0, -2.0, -9.0]
+    return RobotDescription(spec)
+
+
+@pytest.mark.parametrize("integ", [0, 1])
+def test_kernel_arithmetic_general_inertia_branch_agrees_with_the_oracle(hostmath_lib, integ):
+    desc = _skewed_msj()
+    oracle = TendonRobotOracle(desc)
+    P = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))
+    q, qd, sp = random_states(desc, 800, 13)
+    want = oracle.step(q.astype(np.float64), qd.astype(np.float64), sp.astype(np.float64), integrator=integ)
+    q1, qd1, sp1 = q.astype(np.float64), qd.astype(np.float64), sp.astype(np.float64)
+    f1 = np.zeros(len(q), np.uint8)
+    rc = hostmath_lib.hm_step_f64(ctypes.byref(desc.as_c_struct()), ctypes.c_double(0.1), 1, integ,
+                                  ctypes.c_long(len(q)), P(q1, ctypes.c_double), P(qd1, ctypes.c_double),
+                                  P(sp1, ctypes.c_double), P(f1, ctypes.c_ubyte))
+    assert rc == 0
+    assert np.abs(q1 - want[0]).max() < 1e-13 and np.abs(qd1 - want[1]).max() < 1e-12
