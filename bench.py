@@ -202,11 +202,30 @@ def cpu_baseline(robot, seconds, name):
             k += 1
         out[threads] = (n * k / (time.perf_counter() - t0), k, n)
     best = max(out, key=lambda th: out[th][0])
+    # the reference's architecture: one Python RoboyEnv per env (train_parallel.py:19-29), one core
+    py_loop = None
+    if small:
+        from gym_roboy_amd.envs import RoboyEnv
+        from oracle.cpu_simulation_client import CpuSimulationClient
+        import contextlib
+        import io
+        env = RoboyEnv(simulation_client=CpuSimulationClient(robot))
+        acts = [a for a in ph.actions(0, np.arange(256, dtype=np.uint64), 0, desc.n_t)]
+        with contextlib.redirect_stdout(io.StringIO()):
+            env.reset()
+            t0 = time.perf_counter()
+            k = 0
+            while time.perf_counter() - t0 < 2.0:
+                if env.step(acts[k % 256])[2]:
+                    env.reset()
+                k += 1
+        py_loop = k / (time.perf_counter() - t0)
     return {
         "value": out[best][0], "unit": "env-steps/s", "cores": best, "kind": "port",
         "sample": "%d envs x %d steps of %s, C fp32 restatement (oracle/roboy_oracle.c), %s"
                   % (out[best][2], out[best][1], name, "OpenMP over envs" if best > 1 else "one thread"),
         "value_1_core": out[1][0], "host_cores_available": cores_avail,
+        "python_env_loop_1_core": py_loop,   # RoboyEnv.step over the oracle-backed client, per process
     }
 
 

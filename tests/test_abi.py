@@ -85,7 +85,8 @@ def test_without_a_gpu_the_product_path_fails_loudly():
 
 
 def test_product_never_imports_the_oracle():
-    """The oracle is test infrastructure: nothing under gym_roboy_amd/ may name it."""
+    """The oracle is test infrastructure: nothing under gym_roboy_amd/ may name it
+    (the oracle-backed CpuSimulationClient lives in oracle/ for that reason)."""
     pkg = os.path.join(ROOT, "gym_roboy_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
