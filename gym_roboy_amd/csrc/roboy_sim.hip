@@ -243,13 +243,9 @@ struct EnvParams {
     float penalty, bonus_val;
     float a_lo, a_hi, v_lo, v_hi;    // joint angle / velocity boxes
     float act_hi, slope;             // set-point box upper bound, (hi-lo)/(1-(-1)) in fp32
-    float tol_a, tol_v;
+    float tol_a2, tol_v2;            // squared goal tolerances
+    float a_scale, v_scale;          // 2 / (hi - lo) of the angle / velocity box
 };
-
-__device__ __forceinline__ float norm_pm1(float v, float hi, float lo) {
-    // (2 v - max - min) / (max - min), roboy_robot.py:93-95
-    return (2.0f * v - hi - lo) / (hi - lo);
-}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -292,22 +288,23 @@ msj_env_step_kernel(const Const8 c, const EnvParams e, const GoalBox box,
     const bool ok = rb::MsjModel<float, NT8>::template step<INTEG, UNROLL>(c, qq, vv, sp);
     uint32_t sn = step_num[i] + 1u;
 
-    // reward (roboy_env.py:92-112), fp32
-    float d2 = 0.0f, dq2 = 0.0f, dv2 = 0.0f, vn2 = 0.0f;
+    // reward (roboy_env.py:92-112), fp32.  The normalisation (2v - hi - lo)/(hi - lo)
+    // (roboy_robot.py:93-95) is affine, so a difference of two normalised values is
+    // 2 (v1 - v2)/(hi - lo): one multiply by a host-computed scale instead of two
+    // divisions per joint; compares use squared distances (no sqrt); exp is exp2.
+    float dq2 = 0.0f, dv2 = 0.0f;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const float dn = norm_pm1(qq[j], e.a_hi, e.a_lo) - norm_pm1(gg[j], e.a_hi, e.a_lo);
-        d2 += dn * dn;
         const float dq = qq[j] - gg[j];
         dq2 += dq * dq;
         dv2 += vv[j] * vv[j];
-        const float vn = norm_pm1(vv[j], e.v_hi, e.v_lo) - norm_pm1(0.0f, e.v_hi, e.v_lo);
-        vn2 += vn * vn;
     }
-    float r = -expf(sqrtf(d2));
-    if (e.vel_penalty) r = (sqrtf(vn2) + 1.0f) * (r - expf(r));
+    const float LOG2E = 1.4426950408889634f;
+    float r = -__builtin_amdgcn_exp2f(LOG2E * e.a_scale * __builtin_amdgcn_sqrtf(dq2));
+    if (e.vel_penalty)
+        r = (e.v_scale * __builtin_amdgcn_sqrtf(dv2) + 1.0f) * (r - __builtin_amdgcn_exp2f(LOG2E * r));
     if (!ok) r -= fabsf(e.penalty);
-    const bool reached = (sqrtf(dq2) < e.tol_a) && (sqrtf(dv2) < e.tol_v);
+    const bool reached = (dq2 < e.tol_a2) && (dv2 < e.tol_v2);
     if (reached && e.bonus) r += e.bonus_val;
     const bool dn = reached || (sn > uint32_t(e.max_len));
 
@@ -338,8 +335,13 @@ msj_env_step_kernel(const Const8 c, const EnvParams e, const GoalBox box,
 #pragma unroll
     for (int j = 0; j < 3; ++j) { q[j * n + i] = qq[j]; qd[j * n + i] = vv[j]; }
     feas[i] = fz; step_num[i] = sn; ep_ret[i] = ret;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) obs[i * 9 + j] = o[j];
+    // 36-byte observation record: two 16-byte stores and one dword (dword-aligned
+    // vector stores are legal for global memory) instead of nine strided dwords
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    float *orow = obs + i * 9;
+    *reinterpret_cast<f4u *>(orow) = f4u{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f4u *>(orow + 4) = f4u{o[4], o[5], o[6], o[7]};
+    orow[8] = o[8];
     reward[i] = r; done[i] = dn ? 1u : 0u;
 }
 
@@ -825,7 +827,8 @@ int rb_env_configure(rb_sim *s, const rb_env_config *cfg) {
     e.act_hi = cfg->action_hi;
     // (out.high - out.low) / (in.high - in.low) evaluated in fp32 like the reference's float32 Boxes
     e.slope = (cfg->action_hi - cfg->action_lo) / (1.0f - (-1.0f));
-    e.tol_a = cfg->goal_angle_tol; e.tol_v = cfg->goal_vel_tol;
+    e.tol_a2 = cfg->goal_angle_tol * cfg->goal_angle_tol; e.tol_v2 = cfg->goal_vel_tol * cfg->goal_vel_tol;
+    e.a_scale = 2.0f / (cfg->angle_hi - cfg->angle_lo); e.v_scale = 2.0f / (cfg->vel_hi - cfg->vel_lo);
     if (!s->d_goal) {
         const size_t plane = sizeof(float) * size_t(s->n);
         RB_HIP(hipMalloc(&s->d_goal, plane * s->n_q));
