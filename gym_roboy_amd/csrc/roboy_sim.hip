@@ -171,20 +171,19 @@ __global__ void reset_kernel(float *q, float *qd, uint32_t *feas, const uint8_t 
     feas[i] = 1u;
 }
 
-// SoA planes -> row-major [n][n_q] staging (host I/O only)
-__global__ void pack_rows_kernel(const float *planes, float *rows, int n_q, long n) {
+// read-back staging: [n][n_q] q rows | [n][n_q] qd rows | [n] feasibility bytes in
+// one buffer: one kernel, one device-to-host copy, one synchronisation
+__global__ void pack_state_kernel(const float *q, const float *qd, const uint32_t *feas, float *rows, int n_q, long n) {
     const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    for (int j = 0; j < n_q; ++j) rows[i * n_q + j] = planes[j * n + i];
+    float *rq = rows + i * n_q, *rv = rows + n * n_q + i * n_q;
+    for (int j = 0; j < n_q; ++j) { rq[j] = q[j * n + i]; rv[j] = qd[j * n + i]; }
+    reinterpret_cast<uint8_t *>(rows + 2 * n * n_q)[i] = feas[i] ? 1 : 0;
 }
 __global__ void unpack_rows_kernel(const float *rows, float *planes, int n_q, long n) {
     const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     for (int j = 0; j < n_q; ++j) planes[j * n + i] = rows[i * n_q + j];
-}
-__global__ void feas_to_u8_kernel(const uint32_t *f, uint8_t *o, long n) {
-    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < n) o[i] = f[i] ? 1 : 0;
 }
 __global__ void feas_from_u8_kernel(const uint8_t *f, uint32_t *o, long n) {
     const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -430,6 +429,7 @@ struct rb_sim {
     double env_steps = 0.0;      // env steps issued since the statistics were reset
     // host I/O staging
     float *d_rows = nullptr;   // [n][max(n_q, n_t)]
+    float *d_state_rows = nullptr, *h_state_rows = nullptr;   // read-back staging, device / pinned host
     uint8_t *d_u8 = nullptr;   // [n]
     // rollout graph cache
     struct GraphKey {
@@ -485,23 +485,16 @@ int check(const rb_sim *s) {
 
 int read_state_host(rb_sim *s, float *q, float *qd, uint8_t *feasible) {
     const long n = s->n;
-    const unsigned g = blocks_for(n, 256);
-    if (q) {
-        hipLaunchKernelGGL(pack_rows_kernel, dim3(g), dim3(256), 0, s->stream, s->d_q, s->d_rows, s->n_q, n);
-        RB_HIP(hipMemcpyAsync(q, s->d_rows, sizeof(float) * n * s->n_q, hipMemcpyDeviceToHost, s->stream));
-        RB_HIP(hipStreamSynchronize(s->stream));
-    }
-    if (qd) {
-        hipLaunchKernelGGL(pack_rows_kernel, dim3(g), dim3(256), 0, s->stream, s->d_qd, s->d_rows, s->n_q, n);
-        RB_HIP(hipMemcpyAsync(qd, s->d_rows, sizeof(float) * n * s->n_q, hipMemcpyDeviceToHost, s->stream));
-        RB_HIP(hipStreamSynchronize(s->stream));
-    }
-    if (feasible) {
-        hipLaunchKernelGGL(feas_to_u8_kernel, dim3(g), dim3(256), 0, s->stream, s->d_feas, s->d_u8, n);
-        RB_HIP(hipMemcpyAsync(feasible, s->d_u8, size_t(n), hipMemcpyDeviceToHost, s->stream));
-        RB_HIP(hipStreamSynchronize(s->stream));
-    }
+    const size_t plane = sizeof(float) * size_t(n) * s->n_q;
+    hipLaunchKernelGGL(pack_state_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s->stream,
+                       s->d_q, s->d_qd, s->d_feas, s->d_state_rows, s->n_q, n);
     RB_HIP(hipGetLastError());
+    RB_HIP(hipMemcpyAsync(s->h_state_rows, s->d_state_rows, 2 * plane + size_t(n), hipMemcpyDeviceToHost, s->stream));
+    RB_HIP(hipStreamSynchronize(s->stream));
+    const char *h = reinterpret_cast<const char *>(s->h_state_rows);
+    if (q) std::memcpy(q, h, plane);
+    if (qd) std::memcpy(qd, h + plane, plane);
+    if (feasible) std::memcpy(feasible, h + 2 * plane, size_t(n));
     return RB_OK;
 }
 
@@ -583,6 +576,8 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
     const int width = s->n_q > s->n_t ? s->n_q : s->n_t;
     RB_TRY(hipMalloc(&s->d_rows, plane * width));
     RB_TRY(hipMalloc(&s->d_u8, size_t(n_envs)));
+    RB_TRY(hipMalloc(&s->d_state_rows, plane * (2 * s->n_q + 1)));   // q rows | qd rows | n bytes
+    RB_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_state_rows), plane * (2 * s->n_q + 1), hipHostMallocDefault));
     if (!s->tree) {
         RB_TRY(hipMalloc(&s->d_ten, sizeof(s->c8.ten)));
         RB_TRY(hipMemcpyAsync(s->d_ten, s->c8.ten, sizeof(s->c8.ten), hipMemcpyHostToDevice, s->stream));
@@ -618,6 +613,7 @@ void rb_destroy(rb_sim *s) {
     (void)hipFree(s->d_q); (void)hipFree(s->d_qd); (void)hipFree(s->d_feas);
     (void)hipFree(s->d_goal_count); (void)hipFree(s->d_rows); (void)hipFree(s->d_u8); (void)hipFree(s->d_ten);
     (void)hipFree(s->d_tree_ints); (void)hipFree(s->d_tree_floats);
+    (void)hipFree(s->d_state_rows); (void)hipHostFree(s->h_state_rows);
     (void)hipFree(s->d_goal); (void)hipFree(s->d_ep_ret); (void)hipFree(s->d_ep_acc);
     (void)hipFree(s->d_step_num); (void)hipFree(s->d_infeas_n); (void)hipFree(s->d_stats);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
@@ -717,7 +713,6 @@ int rb_step(rb_sim *s, const float *act, float act_scale, float *q, float *qd, u
     int rc = launch_step(s, s->d_rows, act_scale);
     if (rc) return rc;
     s->env_steps += double(s->n);
-    RB_HIP(hipStreamSynchronize(s->stream));   // d_rows is reused by the read-back
     return read_state_host(s, q, qd, feasible);
 }
 
