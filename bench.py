@@ -209,9 +209,11 @@ def cpu_baseline(robot, seconds, name):
         from oracle.cpu_simulation_client import CpuSimulationClient
         import contextlib
         import io
-        env = RoboyEnv(simulation_client=CpuSimulationClient(robot))
         acts = [a for a in ph.actions(0, np.arange(256, dtype=np.uint64), 0, desc.n_t)]
+        # RoboyEnv prints a banner whenever a goal is reached (also while it
+        # derives its reward range): keep stdout to the one JSON line
         with contextlib.redirect_stdout(io.StringIO()):
+            env = RoboyEnv(simulation_client=CpuSimulationClient(robot))
             env.reset()
             t0 = time.perf_counter()
             k = 0

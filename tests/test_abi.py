@@ -96,3 +96,13 @@ def test_product_never_imports_the_oracle():
                     s = line.strip()
                     if s.startswith(("import ", "from ", "#include")):
                         assert "oracle" not in s, (f, s)
+
+
+def test_bench_never_prints_outside_its_json_line():
+    """bench.py's stdout is one JSON line; anything that can print (the RoboyEnv
+    goal banner in the python-loop baseline) must run under redirect_stdout."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def cpu_baseline"):src.index("def main")]
+    guarded = body[body.index("with contextlib.redirect_stdout"):]
+    assert "RoboyEnv(simulation_client" in guarded and "RoboyEnv(simulation_client" not in body[:body.index("with contextlib.redirect_stdout")]
+    assert src.count("print(") == 1 and "print(json.dumps(line))" in src
