@@ -1,0 +1,56 @@
+// env_common.hpp - definitions shared by the fused env-layer kernels of both
+// robot classes (roboy_sim.hip: ball-joint robots; tree_kernels.hpp: joint trees).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "philox.hpp"
+
+namespace rbe {
+
+// a * b + c with two roundings.  hipcc contracts a*b+c into one fma by default
+// (-ffp-contract=fast) and HIP's __fmul_rn/__fadd_rn are plain operators, so
+// the contraction has to be switched off for this statement.
+__device__ __forceinline__ float mul_then_add(float a, float b, float c) {
+#pragma clang fp contract(off)
+    const float p = a * b;
+    return p + c;
+}
+__device__ __forceinline__ float goal_value(float lo, float hi, uint32_t u) {
+    return mul_then_add(hi - lo, rb::u01(u), lo);
+}
+struct GoalBox { float lo[32]; float hi[32]; };
+
+struct EnvParams {
+    int vel_penalty, bonus, max_len, auto_reset;
+    float penalty, bonus_val;
+    float a_lo, a_hi, v_lo, v_hi;    // joint angle / velocity boxes
+    float act_hi, slope;             // set-point box upper bound, (hi-lo)/(1-(-1)) in fp32
+    float tol_a2, tol_v2;            // squared goal tolerances
+    float a_scale, v_scale;          // 2 / (hi - lo) of the angle / velocity box
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+
+// reward / done of RoboyEnv.step (roboy_env.py:92-112,125-134) from the squared
+// joint-space distances; fp32.  The normalisation (2v - hi - lo)/(hi - lo)
+// (roboy_robot.py:93-95) is affine, so the distance of two normalised vectors is
+// 2/(hi - lo) times the plain distance; compares use squared distances.
+__device__ __forceinline__ float env_reward(const EnvParams &e, float dq2, float dv2, bool feasible, bool &reached) {
+    const float LOG2E = 1.4426950408889634f;
+    float r = -__builtin_amdgcn_exp2f(LOG2E * e.a_scale * __builtin_amdgcn_sqrtf(dq2));
+    if (e.vel_penalty)
+        r = (e.v_scale * __builtin_amdgcn_sqrtf(dv2) + 1.0f) * (r - __builtin_amdgcn_exp2f(LOG2E * r));
+    if (!feasible) r -= fabsf(e.penalty);
+    reached = (dq2 < e.tol_a2) && (dv2 < e.tol_v2);
+    if (reached && e.bonus) r += e.bonus_val;
+    return r;
+}
+
+}  // namespace rbe

@@ -18,6 +18,7 @@
 #include "msj_build.hpp"
 #include "msj_math.hpp"
 #include "philox.hpp"
+#include "env_common.hpp"
 #include "tree_kernels.hpp"
 
 namespace {
@@ -45,6 +46,11 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #ifndef RB_TENDON_LANE_BATCH_RK4
 #define RB_TENDON_LANE_BATCH_RK4 16384
 #endif
+using rbe::EnvParams;
+using rbe::GoalBox;
+using rbe::goal_value;
+using rbe::mul_then_add;
+
 constexpr int NT8 = 8;
 using Const8 = rb::MsjConst<float, NT8>;
 
@@ -202,18 +208,6 @@ __global__ void fill_actions_kernel(float *act, int n_t, long n, uint64_t seed, 
 
 // goal = lo + (hi - lo) * u, both operations rounded separately in fp32 so the
 // numpy restatement reproduces it bit for bit
-// a * b + c with two roundings.  hipcc contracts a*b+c into one fma by default
-// (-ffp-contract=fast) and HIP's __fmul_rn/__fadd_rn are plain operators, so
-// the contraction has to be switched off for this statement.
-__device__ __forceinline__ float mul_then_add(float a, float b, float c) {
-#pragma clang fp contract(off)
-    const float p = a * b;
-    return p + c;
-}
-__device__ __forceinline__ float goal_value(float lo, float hi, uint32_t u) {
-    return mul_then_add(hi - lo, rb::u01(u), lo);
-}
-struct GoalBox { float lo[32]; float hi[32]; };
 __global__ void sample_goals_kernel(float *goal, uint32_t *count, const uint8_t *mask, GoalBox box,
                                     int n_q, long n, uint64_t seed, uint64_t env0, int rows) {
     const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -237,21 +231,6 @@ __global__ void sample_goals_kernel(float *goal, uint32_t *count, const uint8_t 
 // rescale action -> physics step -> obs / reward / done -> goal resampling,
 // plus the reset the reference's SubprocVecEnv workers apply on done
 // (train_parallel.py:29) when auto_reset is set.  DESIGN.md §6.
-struct EnvParams {
-    int vel_penalty, bonus, max_len, auto_reset;
-    float penalty, bonus_val;
-    float a_lo, a_hi, v_lo, v_hi;    // joint angle / velocity boxes
-    float act_hi, slope;             // set-point box upper bound, (hi-lo)/(1-(-1)) in fp32
-    float tol_a2, tol_v2;            // squared goal tolerances
-    float a_scale, v_scale;          // 2 / (hi - lo) of the angle / velocity box
-};
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 // obs/goal helper: draw goal number `draw` of env `gid`
 __device__ __forceinline__ void draw_goal3(const GoalBox &box, uint64_t seed, uint64_t gid, uint32_t draw, float g[3]) {
     const rb::Philox4 r = rb::philox_draw(seed, gid, draw, rb::STREAM_GOALS, 0u);
@@ -298,13 +277,8 @@ msj_env_step_kernel(const Const8 c, const EnvParams e, const GoalBox box,
         dq2 += dq * dq;
         dv2 += vv[j] * vv[j];
     }
-    const float LOG2E = 1.4426950408889634f;
-    float r = -__builtin_amdgcn_exp2f(LOG2E * e.a_scale * __builtin_amdgcn_sqrtf(dq2));
-    if (e.vel_penalty)
-        r = (e.v_scale * __builtin_amdgcn_sqrtf(dv2) + 1.0f) * (r - __builtin_amdgcn_exp2f(LOG2E * r));
-    if (!ok) r -= fabsf(e.penalty);
-    const bool reached = (dq2 < e.tol_a2) && (dv2 < e.tol_v2);
-    if (reached && e.bonus) r += e.bonus_val;
+    bool reached;
+    float r = rbe::env_reward(e, dq2, dv2, ok, reached);
     const bool dn = reached || (sn > uint32_t(e.max_len));
 
     float o[9] = {qq[0], qq[1], qq[2], vv[0], vv[1], vv[2], gg[0], gg[1], gg[2]};
@@ -809,7 +783,7 @@ int rb_sample_goals_dev(rb_sim *s, const uint8_t *d_mask, float *d_goal_q) {
 
 int rb_env_configure(rb_sim *s, const rb_env_config *cfg) {
     if (check(s) || !cfg) return fail(RB_EINVAL, "null argument");
-    if (s->n_q != 3 || s->n_t != NT8) return fail(RB_EUNSUPPORTED, "fused env layer is built for 3-DOF / 8-tendon robots");
+    if (!s->tree && (s->n_q != 3 || s->n_t != NT8)) return fail(RB_EUNSUPPORTED, "fused env layer: unsupported robot");
     if (cfg->max_episode_length < 1) return fail(RB_EINVAL, "max_episode_length must be >= 1");
     if (!(cfg->angle_hi > cfg->angle_lo) || !(cfg->vel_hi > cfg->vel_lo) || !(cfg->action_hi > cfg->action_lo))
         return fail(RB_EINVAL, "empty box in env config");
@@ -842,9 +816,14 @@ int rb_env_reset_dev(rb_sim *s, float *d_obs) {
     if (check(s)) return RB_EINVAL;
     RB_HIP(hipSetDevice(s->device));
     if (!s->env_ready) return fail(RB_EINVAL, "rb_env_configure has not been called");
-    hipLaunchKernelGGL(env_reset_kernel, dim3(blocks_for(s->n, 256)), dim3(256), 0, s->stream,
-                       s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, s->d_ep_ret,
-                       s->d_goal_count, d_obs, s->n, s->seed, uint64_t(s->env0));
+    if (s->tree)
+        hipLaunchKernelGGL(rbt::tree_env_reset_kernel, dim3(blocks_for(s->n, 256)), dim3(256), 0, s->stream,
+                           s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, s->d_ep_ret,
+                           s->d_goal_count, d_obs, s->n_q, s->n, s->seed, uint64_t(s->env0));
+    else
+        hipLaunchKernelGGL(env_reset_kernel, dim3(blocks_for(s->n, 256)), dim3(256), 0, s->stream,
+                           s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, s->d_ep_ret,
+                           s->d_goal_count, d_obs, s->n, s->seed, uint64_t(s->env0));
     RB_HIP(hipGetLastError());
     return RB_OK;
 }
@@ -853,8 +832,21 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
     if (check(s) || !d_act || !d_obs || !d_reward || !d_done) return fail(RB_EINVAL, "null argument");
     RB_HIP(hipSetDevice(s->device));
     if (!s->env_ready) return fail(RB_EINVAL, "rb_env_configure has not been called");
-    if (reinterpret_cast<uintptr_t>(d_act) % 16) return fail(RB_EINVAL, "action slab must be 16-byte aligned");
+    if (!s->tree && reinterpret_cast<uintptr_t>(d_act) % 16) return fail(RB_EINVAL, "action slab must be 16-byte aligned");
     const long n = s->n;
+    if (s->tree) {
+        const size_t lds = s->tree_host.lds_floats * sizeof(float);
+#define RB_TREE_ENV_LAUNCH(INTEG)                                                                          \
+    hipLaunchKernelGGL((rbt::tree_env_step_wave_per_env<INTEG>), dim3(unsigned(n)), dim3(64), lds, s->stream, \
+                       s->tree_host.dev, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, \
+                       s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done, s->d_ep_acc, s->d_infeas_n, \
+                       n, s->seed, uint64_t(s->env0))
+        if (s->integrator == RB_EULER) RB_TREE_ENV_LAUNCH(0); else RB_TREE_ENV_LAUNCH(1);
+#undef RB_TREE_ENV_LAUNCH
+        RB_HIP(hipGetLastError());
+        s->env_steps += double(n);
+        return RB_OK;
+    }
 #define RB_ENV_LAUNCH(INTEG, B, U)                                                                       \
     hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, U>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream, \
                        s->c8, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num,      \

@@ -33,6 +33,8 @@
 #include <vector>
 
 #include "../../include/roboy_sim.h"
+#include "env_common.hpp"
+#include "philox.hpp"
 
 namespace rbt {
 
@@ -438,19 +440,12 @@ __device__ __forceinline__ float tree_accel(const TreeDev &t, const Lds &s, int 
     return bi;
 }
 
+// one env step of the own joint (lane < n_q): n_substeps integrator substeps with
+// the set-points held, velocity saturation and joint limits; returns false in
+// the lanes whose joint hit a limit
 template <int INTEG>
-__global__ void __launch_bounds__(64)
-tree_step_wave_per_env(const TreeDev t, float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
-                       const float *__restrict__ act, float act_scale, long n) {
-    extern __shared__ float lds_raw[];
-    const Lds s(lds_raw, t.n_q, t.n_vp);
-    const int lane = threadIdx.x;
-    const long e = blockIdx.x;
-    const int nq = t.n_q;
-    const bool joint = lane < nq;
-    float qj = joint ? q[long(lane) * n + e] : 0.0f;
-    float vj = joint ? qd[long(lane) * n + e] : 0.0f;
-    const float spk = lane < t.n_t ? act[e * t.n_t + lane] * act_scale : 0.0f;
+__device__ __forceinline__ bool tree_integrate(const TreeDev &t, const Lds &s, int lane, float &qj, float &vj, float spk) {
+    const bool joint = lane < t.n_q;
     const float vmax = joint ? t.qdmax[lane] : 0.0f, lo = joint ? t.qlo[lane] : 0.0f, hi = joint ? t.qhi[lane] : 0.0f;
     const float h = t.h;
     bool ok = true;
@@ -482,9 +477,113 @@ tree_step_wave_per_env(const TreeDev t, float *__restrict__ q, float *__restrict
         vj = v;
         ok = ok && !(joint && (over || under));
     }
-    const bool all_ok = __all(ok);
+    return ok;
+}
+
+template <int INTEG>
+__global__ void __launch_bounds__(64)
+tree_step_wave_per_env(const TreeDev t, float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
+                       const float *__restrict__ act, float act_scale, long n) {
+    extern __shared__ float lds_raw[];
+    const Lds s(lds_raw, t.n_q, t.n_vp);
+    const int lane = threadIdx.x;
+    const long e = blockIdx.x;
+    const bool joint = lane < t.n_q;
+    float qj = joint ? q[long(lane) * n + e] : 0.0f;
+    float vj = joint ? qd[long(lane) * n + e] : 0.0f;
+    const float spk = lane < t.n_t ? act[e * t.n_t + lane] * act_scale : 0.0f;
+    const bool all_ok = __all(tree_integrate<INTEG>(t, s, lane, qj, vj, spk));
     if (joint) { q[long(lane) * n + e] = qj; qd[long(lane) * n + e] = vj; }
     if (lane == 0) feas[e] = all_ok ? 1u : 0u;
+}
+
+// RoboyEnv.step fused around the tree step (the env layer of roboy_sim.hip's
+// msj_env_step_kernel for joint-tree robots; same semantics):
+// lane k rescales action k, lanes j hold joint j and its goal, the distances are
+// wave sums, every lane evaluates the (wave-uniform) reward / done, lane j draws
+// its own goal component on done.
+template <int INTEG>
+__global__ void __launch_bounds__(64)
+tree_env_step_wave_per_env(const TreeDev t, const rbe::EnvParams ep, const rbe::GoalBox box,
+                           float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
+                           float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
+                           uint32_t *__restrict__ goal_count, const float *__restrict__ act,
+                           float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
+                           float *__restrict__ ep_acc, uint32_t *__restrict__ infeas_n,
+                           long n, uint64_t seed, uint64_t env0) {
+    extern __shared__ float lds_raw[];
+    const Lds s(lds_raw, t.n_q, t.n_vp);
+    const int lane = threadIdx.x, nq = t.n_q;
+    const long e = blockIdx.x;
+    const bool joint = lane < nq;
+    float qj = joint ? q[long(lane) * n + e] : 0.0f;
+    float vj = joint ? qd[long(lane) * n + e] : 0.0f;
+    float gj = joint ? goal[long(lane) * n + e] : 0.0f;
+    float spk = 0.0f;
+    if (lane < t.n_t) {
+        // clamp to the action box, then slope * (x - in_high) + out_high with two roundings (roboy_env.py:157-158)
+        const float x = fminf(fmaxf(act[e * t.n_t + lane], -1.0f), 1.0f);
+        spk = rbe::mul_then_add(ep.slope, x - 1.0f, ep.act_hi);
+    }
+    const bool ok = __all(tree_integrate<INTEG>(t, s, lane, qj, vj, spk));
+    uint32_t sn = step_num[e] + 1u;
+    const float dq = joint ? qj - gj : 0.0f;
+    const float dq2 = rbe::wave_sum(dq * dq), dv2 = rbe::wave_sum(joint ? vj * vj : 0.0f);
+    bool reached;
+    const float r = rbe::env_reward(ep, dq2, dv2, ok, reached);
+    const bool dn = reached || (sn > uint32_t(ep.max_len));
+    float oq = qj, ov = vj, og = gj, ret = ep_ret[e] + r;
+    uint32_t fz = ok ? 1u : 0u;
+    if (dn) {   // wave-uniform
+        const uint64_t gid = env0 + uint64_t(e);
+        uint32_t draw = goal_count[e];
+        auto draw_goal = [&](uint32_t d) {
+            const rb::Philox4 rnd = rb::philox_draw(seed, gid, d, rb::STREAM_GOALS, uint32_t(lane >> 2));
+            return joint ? rbe::goal_value(box.lo[lane], box.hi[lane], rnd.v[lane & 3]) : 0.0f;
+        };
+        gj = draw_goal(draw++);                       // RoboyEnv.step: _set_new_goal (:67-68)
+        if (lane == 0) {
+            ep_acc[0 * n + e] += ret; ep_acc[1 * n + e] += ret * ret; ep_acc[2 * n + e] += 1.0f;
+            ep_acc[3 * n + e] += float(sn - 1u); ep_acc[4 * n + e] += reached ? 1.0f : 0.0f;
+        }
+        if (ep.auto_reset) {                          // VecEnv worker: env.reset() (:82-87)
+            gj = draw_goal(draw++);
+            qj = 0.0f; vj = 0.0f; oq = 0.0f; ov = 0.0f; og = gj;
+            sn = 1u; fz = 1u;
+        }
+        ret = 0.0f;
+        if (lane == 0) goal_count[e] = draw;
+        if (joint) goal[long(lane) * n + e] = gj;
+    }
+    if (joint) {
+        q[long(lane) * n + e] = qj; qd[long(lane) * n + e] = vj;
+        float *orow = obs + e * (3 * nq);
+        orow[lane] = oq; orow[nq + lane] = ov; orow[2 * nq + lane] = og;
+    }
+    if (lane == 0) {
+        feas[e] = fz; step_num[e] = sn; ep_ret[e] = ret; reward[e] = r; done[e] = dn ? 1u : 0u;
+        if (!ok) infeas_n[e] += 1u;
+    }
+}
+
+// reset of the env layer for any n_q: zero pose, counter 1, a fresh goal, reset observation
+__global__ void tree_env_reset_kernel(const rbe::GoalBox box, float *q, float *qd, uint32_t *feas, float *goal,
+                                      uint32_t *step_num, float *ep_ret, uint32_t *goal_count, float *obs,
+                                      int n_q, long n, uint64_t seed, uint64_t env0) {
+    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t draw = goal_count[i];
+    goal_count[i] = draw + 1u;
+    for (int b = 0; 4 * b < n_q; ++b) {
+        const rb::Philox4 r = rb::philox_draw(seed, env0 + uint64_t(i), draw, rb::STREAM_GOALS, uint32_t(b));
+        for (int k = 0; k < 4 && 4 * b + k < n_q; ++k) {
+            const int j = 4 * b + k;
+            const float g = rbe::goal_value(box.lo[j], box.hi[j], r.v[k]);
+            q[j * n + i] = 0.0f; qd[j * n + i] = 0.0f; goal[j * n + i] = g;
+            if (obs) { obs[i * 3 * n_q + j] = 0.0f; obs[i * 3 * n_q + n_q + j] = 0.0f; obs[i * 3 * n_q + 2 * n_q + j] = g; }
+        }
+    }
+    feas[i] = 1u; step_num[i] = 1u; ep_ret[i] = 0.0f;
 }
 
 }  // namespace rbt

@@ -17,7 +17,8 @@ class HipStepper:
         # the fused env kernel evaluates the env-per-lane arithmetic; use the same
         # form here so states can be compared bit for bit (the tendon-per-lane
         # form sums the 8 tendon torques in a different order)
-        self.sim.select_kernel(1)
+        if robot.get_description().n_q == 3:
+            self.sim.select_kernel(1)   # joint-tree robots have a single kernel form
 
     def step(self, sp):
         return self.sim.forward_step_command(sp)
@@ -33,8 +34,9 @@ class COracleStepper:
     def __init__(self, robot, n):
         from oracle.c_oracle import COracle
         self.orc = COracle(robot.get_description(), "f32")
-        self.q = np.zeros((n, 3), np.float32)
-        self.qd = np.zeros((n, 3), np.float32)
+        n_q = robot.get_description().n_q
+        self.q = np.zeros((n, n_q), np.float32)
+        self.qd = np.zeros((n, n_q), np.float32)
         self.f = np.ones(n, np.uint8)
 
     def step(self, sp):
@@ -65,7 +67,7 @@ class HostEnvModel:
         self.goal = self.draw(np.ones(n, bool))
 
     def draw(self, mask):
-        g = np.zeros((self.n, 3), np.float32)
+        g = np.zeros((self.n, self.desc.n_q), np.float32)
         idx = np.nonzero(mask)[0]
         for d in np.unique(self.draws[idx]):
             sel = idx[self.draws[idx] == d]
@@ -75,7 +77,7 @@ class HostEnvModel:
         return g
 
     def step(self, action):
-        one = np.ones(8, np.float32)
+        one = np.ones(self.desc.n_t, np.float32)
         sp = rw.rescale_between_boxes(action.astype(np.float32), -one, one, self.acts.low, self.acts.high)
         q, qd, feas = self.stepper.step(sp.astype(np.float32))
         self.step_num += 1
@@ -104,6 +106,6 @@ class HostEnvModel:
                 self.step_num[done] = 1
                 new_goal = self.draw(done)
                 self.goal = np.where(done[:, None], new_goal, self.goal)
-                obs[done, :6] = 0.0
-                obs[done, 6:] = self.goal[done]
+                obs[done, :2 * self.desc.n_q] = 0.0
+                obs[done, 2 * self.desc.n_q:] = self.goal[done]
         return obs, reward, done, margin

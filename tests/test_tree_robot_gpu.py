@@ -130,3 +130,39 @@ def test_tree_kernel_on_the_msj_robot_equals_the_closed_form(msj_robot, msj_orac
         def get_description(cls):
             return desc
     _check(Msj4(), COracle(desc, "f64"), 65, "euler", 1, seed=8)
+
+
+@pytest.mark.parametrize("auto_reset", [True, False])
+def test_fused_env_layer_on_the_upper_body_matches_host_replay(upper_body, auto_reset):
+    """RoboyVecEnv over the joint-tree kernel: same replay check as for MsjRobot
+    (tests/test_env_layer_gpu.py): states and goals bit for bit against the plain
+    tree kernel + numpy Philox, reward/done against reward.py in float64."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from host_env_model import HipStepper, HostEnvModel
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    n, seed, max_len = 130, 3, 9
+    vec = RoboyVecEnv(upper_body, n, seed=seed, auto_reset=auto_reset, max_episode_length=max_len, joint_vel_penalty=True)
+    host = HostEnvModel(upper_body, HipStepper(upper_body, n, seed), n, seed, max_len, True, True, auto_reset)
+    obs0 = vec.reset()
+    host.goal = host.draw(np.ones(n, bool))
+    assert obs0.shape == (n, 60) and not obs0[:, :40].any() and np.array_equal(obs0[:, 40:], host.goal)
+    rng = np.random.default_rng(1)
+    n_done = 0
+    for t in range(25):
+        a = rng.uniform(-1, 1, (n, 38)).astype(np.float32)
+        obs, rew, done, _ = vec.step(a)
+        h_obs, h_rew, h_done, margin = host.step(a)
+        assert np.array_equal(done, h_done) or (margin[done != h_done] < 1e-5).all()
+        same = done == h_done
+        assert same.all()
+        assert np.array_equal(obs, h_obs.astype(np.float32))
+        np.testing.assert_allclose(rew, h_rew, rtol=3e-5, atol=3e-4)
+        n_done += int(done.sum())
+    assert n_done >= 2 * n
+    st = vec.stats()
+    assert st["n_env_steps"] == 25 * n and st["n_episodes"] == n_done
+    got = np.array([st[k] for k in ("sum_return", "sum_return_sq", "n_episodes", "sum_length", "n_goal_reached",
+                                    "n_infeasible_steps", "n_env_steps", "sum_reward")])
+    np.testing.assert_allclose(got, host.stats, rtol=1e-4, atol=5e-2)
+    vec.close(); host.stepper.close()
