@@ -133,6 +133,11 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
     # 16 untimed steps from the reset state decorrelate the envs, then warm-up
     rollout(16)
     rollout(warmup)
+    # untimed rehearsal of the chunk sizes the timed region will use, so that no
+    # hipGraph is captured / instantiated inside it (graphs are cached per chunk size)
+    rollout(min(steps, STATS_EVERY))
+    if steps > STATS_EVERY and steps % STATS_EVERY:
+        rollout(steps % STATS_EVERY)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

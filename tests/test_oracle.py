@@ -214,3 +214,47 @@ def test_kernel_arithmetic_general_inertia_branch_agrees_with_the_oracle(hostmat
                                   P(sp1, ctypes.c_double), P(f1, ctypes.c_ubyte))
     assert rc == 0
     assert np.abs(q1 - want[0]).max() < 1e-13 and np.abs(qd1 - want[1]).max() < 1e-12
+
+
+def _random_ball_joint_robot(rng):
+    """A random robot of the ball-joint class: 8 tendons with 1-3 base via-points
+    and 1-3 body via-points each (constant segments on both sides), random
+    inertia, COM, armature, damping, gravity direction and muscle constants."""
+    from gym_roboy_amd.envs.robots import RobotDescription, msj_platform_spec
+    spec = msj_platform_spec()
+    for t in spec["tendons"]:
+        base = [{"link": -1, "pos": (rng.uniform(-0.12, 0.12, 3) + [0, 0, -0.12]).tolist()} for _ in range(rng.integers(1, 4))]
+        body = [{"link": 2, "pos": (rng.uniform(-0.08, 0.08, 3) + [0, 0, 0.12]).tolist()} for _ in range(rng.integers(1, 4))]
+        t["via_points"] = base + body
+        t["f_max"] = float(rng.uniform(5, 40))
+    j = spec["joints"][2]
+    j["mass"] = float(rng.uniform(0.1, 0.5)); j["com"] = rng.uniform(-0.02, 0.02, 3).tolist()
+    a = rng.uniform(-1, 1, (3, 3)); I = (a @ a.T + 3 * np.eye(3)) * 1e-4
+    j["inertia"] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
+    for jj in spec["joints"]:
+        jj["armature"] = float(rng.uniform(0.1, 0.3)); jj["damping"] = float(rng.uniform(0.3, 1.0))
+    spec["gravity"] = rng.uniform(-5, 5, 3).tolist()
+    spec["muscle"].update(kp=float(rng.uniform(4, 12)), v_max=float(rng.uniform(4, 10)),
+                          fl_width=float(rng.uniform(0.3, 0.6)), setpoint_scale=float(rng.uniform(0.05, 0.1)))
+    return RobotDescription(spec)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_closed_form_equals_generic_tree_on_random_ball_joint_robots(hostmath_lib, seed):
+    """msj_build.hpp's folding (moving segment, constant segments, |A|^2+|B|^2,
+    inertia about the joint centre, fast-path detection) on arbitrary geometry."""
+    rng = np.random.default_rng(100 + seed)
+    desc = _random_ball_joint_robot(rng)
+    oracle = TendonRobotOracle(desc)
+    P = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))
+    q, qd, sp = random_states(desc, 300, seed)
+    for integ in (0, 1):
+        want = oracle.step(q.astype(np.float64), qd.astype(np.float64), sp.astype(np.float64), integrator=integ)
+        q1, qd1, sp1 = q.astype(np.float64), qd.astype(np.float64), sp.astype(np.float64)
+        f1 = np.zeros(len(q), np.uint8)
+        rc = hostmath_lib.hm_step_f64(ctypes.byref(desc.as_c_struct()), ctypes.c_double(0.1), 1, integ,
+                                      ctypes.c_long(len(q)), P(q1, ctypes.c_double), P(qd1, ctypes.c_double),
+                                      P(sp1, ctypes.c_double), P(f1, ctypes.c_ubyte))
+        assert rc == 0
+        assert np.abs(q1 - want[0]).max() < 1e-12 and np.abs(qd1 - want[1]).max() < 1e-11
+        assert np.array_equal(f1.astype(bool), want[2])

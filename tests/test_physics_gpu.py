@@ -294,3 +294,23 @@ def test_general_inertia_branch_matches_oracle(msj_robot):
     for kernel in (1, 2):
         for integrator in ("euler", "rk4"):
             _check_step(Skewed(), oracle, 1000, integrator, 1, seed=17, kernel=kernel)
+
+
+@pytest.mark.parametrize("integrator", ["euler", "rk4"])
+def test_long_rollout_with_extreme_actions_stays_finite_and_inside_the_boxes(msj_robot, integrator):
+    """2 000 steps of i.i.d. full-range actions (5 episodes' worth): no NaN/inf,
+    angles inside the feasible region, velocities inside the speed limit."""
+    n = 4096
+    desc = msj_robot.get_description()
+    sim = _sim(msj_robot, n, integrator=integrator, seed=99)
+    d_ring = sim.malloc(4 * 8 * n * 8)
+    for r in range(8):
+        sim.fill_actions_dev(d_ring + 4 * r * n * 8, r)
+    sim.rollout_dev(d_ring, 8, 2000, 0.3, use_graph=True)
+    sim.synchronize()
+    q, qd, f = sim.read_state()
+    assert np.isfinite(q).all() and np.isfinite(qd).all()
+    assert np.all(q >= desc.q_lo.astype(np.float32)) and np.all(q <= desc.q_hi.astype(np.float32))
+    assert np.all(np.abs(qd) <= np.float32(desc.qd_max) + 1e-7)
+    assert q.std() > 0.01
+    sim.close()
