@@ -176,6 +176,37 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
     }
 
 
+def run_fused_env(torch, robot, n_envs, steps=300, warmup=30):
+    """Secondary line: the fused env layer (rb_env_step_dev: rescale + physics +
+    obs/reward/done/goal, 84 + 72 algorithmic bytes per env step), eager launches."""
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    env = RoboyVecEnv(robot, n_envs)
+    st = torch.cuda.current_stream()
+    env.sim.set_stream(st.cuda_stream)
+    acts = [torch.rand((n_envs, env.n_t), device="cuda") * 2 - 1 for _ in range(RING)]
+    obs = torch.empty((n_envs, 3 * env.n_q), device="cuda")
+    rew = torch.empty(n_envs, device="cuda")
+    done = torch.empty(n_envs, dtype=torch.int32, device="cuda")
+    for t in range(warmup):
+        env.step_dev(acts[t % RING].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(st)
+    for t in range(steps):
+        env.step_dev(acts[t % RING].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
+    e1.record(st)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    us = e0.elapsed_time(e1) * 1e3 / steps
+    bytes_per = 4 * (4 * env.n_q + env.n_t + 1) + 4 * (3 * env.n_q + env.n_q + 6)   # + obs, goal, counter x2, return x2, reward, done
+    env.close()
+    return {"workload": "fused-env-%d" % n_envs, "label": "fused env layer (RoboyVecEnv.step), %d envs, Euler fp32" % n_envs,
+            "value": n_envs * steps / wall, "ms_per_step": wall * 1e3 / steps, "launch_us_events": us,
+            "achieved_GBps": n_envs * bytes_per / us / 1e3, "steps": steps, "bytes_per_env_step": bytes_per,
+            "frac_of_hbm_peak": n_envs * bytes_per / us / 1e3 * 1e9 / HBM_PEAK}
+
+
 def cpu_baseline(robot, seconds, name):
     """The C restatement of the same step (oracle/roboy_oracle.c, fp32 build)
     timed on this box's host cores on a bounded sample of the workload: first
@@ -278,6 +309,7 @@ def main():
                     also.append({k: r[k] for k in ("workload", "label", "value", "ms_per_step", "launch_us_events",
                                                    "achieved_GBps", "steps")} |
                                 {"frac_of_hbm_peak": r["achieved_GBps"] * 1e9 / HBM_PEAK})
+            also.append(run_fused_env(torch, MsjRobot(), 2097152))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(robot, args.cpu_seconds, args.workload)
