@@ -750,6 +750,10 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
                 e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
                 (void)hipGraphDestroy(graph);
                 if (e != hipSuccess) return fail(RB_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+                if (s->graphs.size() >= 16) {   // bound the cache: callers that keep changing slabs get re-captures, not a leak
+                    for (auto &kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
+                    s->graphs.clear();
+                }
                 it = s->graphs.emplace(key, exec).first;
             }
             for (; t + chunk <= n_steps; t += chunk) RB_HIP(hipGraphLaunch(it->second, s->stream));
