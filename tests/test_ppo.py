@@ -100,3 +100,15 @@ def test_ppo_runs_on_the_device_env_without_host_copies():
     st = env.stats()
     assert st["n_env_steps"] == 256 * 16 * 3
     env.close()
+
+
+@pytest.mark.gpu
+def test_train_then_play_back(tmp_path, capsys):
+    """train_parallel.py -> model.pkl -> visualize_agent.py, the reference's two drivers."""
+    from gym_roboy_amd import train_parallel, visualize_agent
+    out = str(tmp_path / "results")
+    train_parallel.main(["256", out, "--rounds", "1", "--steps-per-round", str(256 * 128)])
+    assert os.path.exists(os.path.join(out, "model.pkl"))
+    total = visualize_agent.main([os.path.join(out, "model.pkl"), "--steps", "20", "--pause", "0"])
+    assert np.isfinite(total)
+    assert "reward" in capsys.readouterr().out
