@@ -428,11 +428,12 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale) {
                        s->stream, s->c8, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n)
     if (s->tree) {
         const size_t lds = s->tree_host.lds_floats * sizeof(float);
+        const unsigned tree_blocks = unsigned((n + rbt::TREE_WAVES - 1) / rbt::TREE_WAVES);
         if (s->integrator == RB_EULER)
-            hipLaunchKernelGGL((rbt::tree_step_wave_per_env<0>), dim3(unsigned(n)), dim3(64), lds, s->stream,
+            hipLaunchKernelGGL((rbt::tree_step_wave_per_env<0>), dim3(tree_blocks), dim3(64 * rbt::TREE_WAVES), lds, s->stream,
                                s->tree_host.dev, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
         else
-            hipLaunchKernelGGL((rbt::tree_step_wave_per_env<1>), dim3(unsigned(n)), dim3(64), lds, s->stream,
+            hipLaunchKernelGGL((rbt::tree_step_wave_per_env<1>), dim3(tree_blocks), dim3(64 * rbt::TREE_WAVES), lds, s->stream,
                                s->tree_host.dev, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
     } else if (s->kernel == RB_KERNEL_TENDON_PER_LANE) {
         const unsigned g = blocks_for(n * NT8, 64);
@@ -557,8 +558,11 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
         RB_TRY(hipMemcpyAsync(s->d_ten, s->c8.ten, sizeof(s->c8.ten), hipMemcpyHostToDevice, s->stream));
     } else {
         rbt::TreeHost &th = s->tree_host;
-        RB_TRY(hipMalloc(&s->d_tree_ints, sizeof(int) * th.ints.size()));
-        RB_TRY(hipMalloc(&s->d_tree_floats, sizeof(float) * th.floats.size()));
+        // one allocation: [ints | floats | pad to 16 B]; d_tree_floats points into it
+        const size_t words = rbt::tree_table_words(th);
+        RB_TRY(hipMalloc(&s->d_tree_ints, sizeof(int) * words));
+        RB_TRY(hipMemset(s->d_tree_ints, 0, sizeof(int) * words));
+        s->d_tree_floats = reinterpret_cast<float *>(s->d_tree_ints) + th.ints.size();
         RB_TRY(hipMemcpy(s->d_tree_ints, th.ints.data(), sizeof(int) * th.ints.size(), hipMemcpyHostToDevice));
         RB_TRY(hipMemcpy(s->d_tree_floats, th.floats.data(), sizeof(float) * th.floats.size(), hipMemcpyHostToDevice));
         rbt::tree_patch_pointers(th, s->d_tree_ints, s->d_tree_floats);
@@ -586,7 +590,7 @@ void rb_destroy(rb_sim *s) {
     for (auto &kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     (void)hipFree(s->d_q); (void)hipFree(s->d_qd); (void)hipFree(s->d_feas);
     (void)hipFree(s->d_goal_count); (void)hipFree(s->d_rows); (void)hipFree(s->d_u8); (void)hipFree(s->d_ten);
-    (void)hipFree(s->d_tree_ints); (void)hipFree(s->d_tree_floats);
+    (void)hipFree(s->d_tree_ints);   // d_tree_floats points into the same allocation
     (void)hipFree(s->d_state_rows); (void)hipHostFree(s->h_state_rows);
     (void)hipFree(s->d_goal); (void)hipFree(s->d_ep_ret); (void)hipFree(s->d_ep_acc);
     (void)hipFree(s->d_step_num); (void)hipFree(s->d_infeas_n); (void)hipFree(s->d_stats);
@@ -841,7 +845,7 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
     if (s->tree) {
         const size_t lds = s->tree_host.lds_floats * sizeof(float);
 #define RB_TREE_ENV_LAUNCH(INTEG)                                                                          \
-    hipLaunchKernelGGL((rbt::tree_env_step_wave_per_env<INTEG>), dim3(unsigned(n)), dim3(64), lds, s->stream, \
+    hipLaunchKernelGGL((rbt::tree_env_step_wave_per_env<INTEG>), dim3(unsigned((n + rbt::TREE_WAVES - 1) / rbt::TREE_WAVES)), dim3(64 * rbt::TREE_WAVES), lds, s->stream, \
                        s->tree_host.dev, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, \
                        s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done, s->d_ep_acc, s->d_infeas_n, \
                        n, s->seed, uint64_t(s->env0))

@@ -18,9 +18,12 @@
 //   lanes = joints    integrator, velocity/joint limits
 //
 // No atomics anywhere: every accumulation is a gather by its owner lane, so
-// results are bit-reproducible.  One workgroup = one wave = one env, hence
-// __syncthreads() between phases is a single-wave barrier (it only orders the
-// LDS traffic).  Algorithmic HBM bytes per env step: 4*(4 n_q + n_t + 1).
+// results are bit-reproducible.  A workgroup is TREE_WAVES waves = TREE_WAVES envs
+// that share one LDS copy of the robot tables (staged once, behind the only
+// workgroup barrier); each wave then works in its own LDS working set, and the
+// phases of a wave are ordered by wave_sync() alone (LDS instructions of one
+// wave execute in issue order).  Algorithmic HBM bytes per env step:
+// 4*(4 n_q + n_t + 1).
 //
 // The model is the one of DESIGN.md §2; the oracle evaluates it with the
 // textbook Jacobian-sum M and is what this file is checked against.
@@ -54,7 +57,14 @@ struct TreeDev {
     // float tables
     const float *axis, *origin, *mass, *com, *inertia, *armature, *damping, *qlo, *qhi, *qdmax, *vp_pos,
         *t_inv_l0, *t_sg_l0, *t_fmax, *t_inv_vl0;
+    // all tables as one device buffer of 32-bit words ([ints | floats], padded to 16 bytes):
+    // a workgroup copies it to LDS once, shared by its TREE_WAVES envs
+    const float4 *g_words;
+    int n_vec4;               // 16-byte chunks in g_words
+    int io[13], fo[15];       // word offset of each table in the buffer
 };
+
+constexpr int TREE_WAVES = 4;   // envs (= waves) per workgroup, sharing one LDS copy of the tables
 
 struct TreeHost {
     std::vector<int> ints;
@@ -64,6 +74,9 @@ struct TreeHost {
     TreeDev dev;   // scalars filled; pointers patched after upload
     size_t lds_floats = 0;
 };
+
+// words of the combined [ints | floats] table buffer, padded to a 16-byte multiple
+inline size_t tree_table_words(const TreeHost &h) { return (h.ints.size() + h.floats.size() + 3) / 4 * 4; }
 
 inline size_t tree_lds_floats(int nq, int nvp) {
     // R 9, P Z W VP AL AP FF NN CH FK FL VO 3 each (12*3), CM 1, CI 6, SQ SQD RHS 3
@@ -155,9 +168,12 @@ inline int tree_build(const rb_robot_desc *d, double step_size, int nsub, TreeHo
     t.inv_pe_den = float(1.0 / (std::exp(d->kpe) - 1.0));
     const double c2l = (1.0 + 1.0 / d->fv_a) / (d->fv_n - 1.0);
     t.fv_c2s = float(-1.0 / d->fv_a); t.fv_c1l = float(d->fv_n * c2l); t.fv_c2l = float(c2l);
-    out.lds_floats = tree_lds_floats(nq, nvp);
+    // per workgroup: one table copy + TREE_WAVES working sets
+    out.lds_floats = tree_table_words(out) + size_t(TREE_WAVES) * tree_lds_floats(nq, nvp);
     return RB_OK;
 }
+
+__host__ __device__ inline int tree_lds_floats_dev(int nq, int nvp) { return nq * (9 + 36 + 1 + 6 + 3) + nvp * 3 + nq * nq; }
 
 inline void tree_patch_pointers(TreeHost &h, const int *d_ints, const float *d_floats) {
     TreeDev &t = h.dev;
@@ -165,8 +181,10 @@ inline void tree_patch_pointers(TreeHost &h, const int *d_ints, const float *d_f
                           &t.lvp_start, &t.lvp_list, &t.vp_link, &t.t_first, &t.t_count, &t.pair_ij, &t.pair_start};
     const float **fp[15] = {&t.axis, &t.origin, &t.mass, &t.com, &t.inertia, &t.armature, &t.damping, &t.qlo,
                             &t.qhi, &t.qdmax, &t.vp_pos, &t.t_inv_l0, &t.t_sg_l0, &t.t_fmax, &t.t_inv_vl0};
-    for (int i = 0; i < 13; ++i) *ip[i] = d_ints + h.io[i];
-    for (int i = 0; i < 15; ++i) *fp[i] = d_floats + h.fo[i];
+    for (int i = 0; i < 13; ++i) { *ip[i] = d_ints + h.io[i]; t.io[i] = int(h.io[i]); }
+    for (int i = 0; i < 15; ++i) { *fp[i] = d_floats + h.fo[i]; t.fo[i] = int(h.ints.size() + h.fo[i]); }
+    t.g_words = reinterpret_cast<const float4 *>(d_ints);   // the floats follow the ints in the same allocation
+    t.n_vec4 = int(tree_table_words(h) / 4);
 }
 
 // ------------------------------------------------------------------ device
@@ -221,11 +239,55 @@ __device__ __forceinline__ void via_point(const TreeDev &t, const Lds &s, int v,
     xd = ld3(s.VP + 3 * link) + cross(ld3(s.W + 3 * link), r);
 }
 
+// Phases of one env exchange data through the wave's own LDS working set only.
+// LDS instructions of one wave execute in issue order, so a later ds_read sees an
+// earlier ds_write of another lane of the same wave; all that is needed between
+// phases is that the compiler keeps that order.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Copy the robot tables to LDS (16-byte loads, issued in batches before their
+// stores) and return a TreeDev whose tables point at the copy: later table reads
+// are ds_reads instead of dependent global loads (257 per wave and evaluation
+// before; they were the largest share of the wave's s_waitcnt time).
+__device__ __forceinline__ TreeDev stage_tables(const TreeDev &g, float *lds_tab, int tid, int nthreads) {
+    float4 *dst = reinterpret_cast<float4 *>(lds_tab);
+    for (int base = 0; base < g.n_vec4; base += 4 * nthreads) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = base + u * nthreads + tid;
+            v[u] = k < g.n_vec4 ? g.g_words[k] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = base + u * nthreads + tid;
+            if (k < g.n_vec4) dst[k] = v[u];
+        }
+    }
+    __syncthreads();
+    TreeDev t = g;
+    const int *li = reinterpret_cast<const int *>(lds_tab);
+    const float *lf = lds_tab;
+    t.parent = li + g.io[0]; t.anc_mask = li + g.io[1]; t.order = li + g.io[2]; t.level_start = li + g.io[3];
+    t.child_start = li + g.io[4]; t.child_list = li + g.io[5]; t.lvp_start = li + g.io[6]; t.lvp_list = li + g.io[7];
+    t.vp_link = li + g.io[8]; t.t_first = li + g.io[9]; t.t_count = li + g.io[10]; t.pair_ij = li + g.io[11];
+    t.pair_start = li + g.io[12];
+    t.axis = lf + g.fo[0]; t.origin = lf + g.fo[1]; t.mass = lf + g.fo[2]; t.com = lf + g.fo[3]; t.inertia = lf + g.fo[4];
+    t.armature = lf + g.fo[5]; t.damping = lf + g.fo[6]; t.qlo = lf + g.fo[7]; t.qhi = lf + g.fo[8]; t.qdmax = lf + g.fo[9];
+    t.vp_pos = lf + g.fo[10]; t.t_inv_l0 = lf + g.fo[11]; t.t_sg_l0 = lf + g.fo[12]; t.t_fmax = lf + g.fo[13];
+    t.t_inv_vl0 = lf + g.fo[14];
+    return t;
+}
+
 // qdd of the own joint (lane < n_q); spk = set-point of the own tendon (lane < n_t)
 __device__ __forceinline__ float tree_accel(const TreeDev &t, const Lds &s, int lane, float qj, float vj, float spk) {
     const int nq = t.n_q, nt = t.n_t;
     if (lane < nq) { s.SQ[lane] = qj; s.SQD[lane] = vj; }
-    __syncthreads();
+    wave_sync();
     // ---- forward pass, one tree level at a time ----
     for (int L = 0; L < t.n_levels; ++L) {
         const int a = t.level_start[L], b = t.level_start[L + 1];
@@ -303,7 +365,7 @@ __device__ __forceinline__ float tree_accel(const TreeDev &t, const Lds &s, int 
                 for (int e = 0; e < 6; ++e) ci[e] = 0.0f;
             }
         }
-        __syncthreads();
+        wave_sync();
     }
     // ---- tendons: one lane each ----
     if (lane < nt) {
@@ -340,7 +402,7 @@ __device__ __forceinline__ float tree_accel(const TreeDev &t, const Lds &s, int 
         }
         st3(s.FV + 3 * (first + cnt - 1), uprev * (-F));
     }
-    __syncthreads();
+    wave_sync();
     // ---- links gather the tendon forces applied to them (subtracted: the
     //      backward pass then yields bias - tendon generalized force) ----
     if (lane < nq) {
@@ -357,7 +419,7 @@ __device__ __forceinline__ float tree_accel(const TreeDev &t, const Lds &s, int 
         }
         st3(s.FF + 3 * i, f); st3(s.NN + 3 * i, n);
     }
-    __syncthreads();
+    wave_sync();
     // ---- backward pass: parents gather wrenches and composite inertias ----
     for (int L = t.n_levels - 2; L >= 0; --L) {
         const int a = t.level_start[L], b = t.level_start[L + 1];
@@ -381,7 +443,7 @@ __device__ __forceinline__ float tree_accel(const TreeDev &t, const Lds &s, int 
 #pragma unroll
             for (int e = 0; e < 6; ++e) s.CI[6 * i + e] = ci[e];
         }
-        __syncthreads();
+        wave_sync();
     }
     if (lane < nq) {
         const int i = lane;
@@ -394,7 +456,7 @@ __device__ __forceinline__ float tree_accel(const TreeDev &t, const Lds &s, int 
         st3(s.FK + 3 * i, symmul(s.CI + 6 * i, z) + cross(ch, vo));
         st3(s.FL + 3 * i, vo * s.CM[i] - cross(ch, z));
     }
-    __syncthreads();
+    wave_sync();
     // ---- mass matrix: M[a][b] = z_b . K_a + vO_b . Lf_a for b on the path to a ----
     for (int e = lane; e < nq * nq; e += 64) {
         const int i = e / nq, j = e - i * nq;
@@ -406,7 +468,7 @@ __device__ __forceinline__ float tree_accel(const TreeDev &t, const Lds &s, int 
         }
         s.M[e] = val;
     }
-    __syncthreads();
+    wave_sync();
     // ---- Cholesky M = L L^T in place (lower triangle), wave-parallel.  The
     //      trailing update of column c touches the pairs (i >= j > c): one
     //      contiguous range of the pair table, 64 pairs per pass.  1/L_cc is
@@ -414,15 +476,15 @@ __device__ __forceinline__ float tree_accel(const TreeDev &t, const Lds &s, int 
     const int n_pairs = t.pair_start[nq];
     for (int c = 0; c < nq; ++c) {
         const float inv = __builtin_amdgcn_rsqf(s.M[c * nq + c]);
-        __syncthreads();
+        wave_sync();
         if (lane > c && lane < nq) s.M[lane * nq + c] *= inv;
         if (lane == c) { s.M[c * nq + c] = s.M[c * nq + c] * inv; s.SQ[c] = inv; }   // sqrt(d) = d * rsqrt(d)
-        __syncthreads();
+        wave_sync();
         for (int idx = t.pair_start[c + 1] + lane; idx < n_pairs; idx += 64) {
             const int ij = t.pair_ij[idx], i = ij >> 8, j = ij & 255;
             s.M[i * nq + j] -= s.M[i * nq + c] * s.M[j * nq + c];
         }
-        __syncthreads();
+        wave_sync();
     }
     // ---- forward and backward substitution on RHS (lane i owns row i) ----
     float bi = lane < nq ? s.RHS[lane] : 0.0f;
@@ -436,7 +498,7 @@ __device__ __forceinline__ float tree_accel(const TreeDev &t, const Lds &s, int 
         if (lane == c) bi = xc;
         else if (lane < c) bi -= s.M[c * nq + lane] * xc;
     }
-    __syncthreads();
+    wave_sync();
     return bi;
 }
 
@@ -481,20 +543,24 @@ __device__ __forceinline__ bool tree_integrate(const TreeDev &t, const Lds &s, i
 }
 
 template <int INTEG>
-__global__ void __launch_bounds__(64)
-tree_step_wave_per_env(const TreeDev t, float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
+__global__ void __launch_bounds__(64 * TREE_WAVES)
+tree_step_wave_per_env(const TreeDev tg, float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
                        const float *__restrict__ act, float act_scale, long n) {
-    extern __shared__ float lds_raw[];
-    const Lds s(lds_raw, t.n_q, t.n_vp);
-    const int lane = threadIdx.x;
-    const long e = blockIdx.x;
+    extern __shared__ float4 lds_raw4[];
+    float *lds_raw = reinterpret_cast<float *>(lds_raw4);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const TreeDev t = stage_tables(tg, lds_raw, threadIdx.x, 64 * TREE_WAVES);
+    const Lds s(lds_raw + 4 * tg.n_vec4 + wave * tree_lds_floats_dev(t.n_q, t.n_vp), t.n_q, t.n_vp);
+    long e = long(blockIdx.x) * TREE_WAVES + wave;
+    const bool live = e < n;          // a dead wave shadows the last env and stores nothing
+    if (!live) e = n - 1;
     const bool joint = lane < t.n_q;
     float qj = joint ? q[long(lane) * n + e] : 0.0f;
     float vj = joint ? qd[long(lane) * n + e] : 0.0f;
     const float spk = lane < t.n_t ? act[e * t.n_t + lane] * act_scale : 0.0f;
     const bool all_ok = __all(tree_integrate<INTEG>(t, s, lane, qj, vj, spk));
-    if (joint) { q[long(lane) * n + e] = qj; qd[long(lane) * n + e] = vj; }
-    if (lane == 0) feas[e] = all_ok ? 1u : 0u;
+    if (live && joint) { q[long(lane) * n + e] = qj; qd[long(lane) * n + e] = vj; }
+    if (live && lane == 0) feas[e] = all_ok ? 1u : 0u;
 }
 
 // RoboyEnv.step fused around the tree step (the env layer of roboy_sim.hip's
@@ -503,18 +569,22 @@ tree_step_wave_per_env(const TreeDev t, float *__restrict__ q, float *__restrict
 // wave sums, every lane evaluates the (wave-uniform) reward / done, lane j draws
 // its own goal component on done.
 template <int INTEG>
-__global__ void __launch_bounds__(64)
-tree_env_step_wave_per_env(const TreeDev t, const rbe::EnvParams ep, const rbe::GoalBox box,
+__global__ void __launch_bounds__(64 * TREE_WAVES)
+tree_env_step_wave_per_env(const TreeDev tg, const rbe::EnvParams ep, const rbe::GoalBox box,
                            float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
                            float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
                            uint32_t *__restrict__ goal_count, const float *__restrict__ act,
                            float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
                            float *__restrict__ ep_acc, uint32_t *__restrict__ infeas_n,
                            long n, uint64_t seed, uint64_t env0) {
-    extern __shared__ float lds_raw[];
-    const Lds s(lds_raw, t.n_q, t.n_vp);
-    const int lane = threadIdx.x, nq = t.n_q;
-    const long e = blockIdx.x;
+    extern __shared__ float4 lds_raw4[];
+    float *lds_raw = reinterpret_cast<float *>(lds_raw4);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const TreeDev t = stage_tables(tg, lds_raw, threadIdx.x, 64 * TREE_WAVES);
+    const int nq = t.n_q;
+    const Lds s(lds_raw + 4 * tg.n_vec4 + wave * tree_lds_floats_dev(nq, t.n_vp), nq, t.n_vp);
+    const long e = long(blockIdx.x) * TREE_WAVES + wave;
+    if (e >= n) return;               // whole wave leaves together (after the staging barrier)
     const bool joint = lane < nq;
     float qj = joint ? q[long(lane) * n + e] : 0.0f;
     float vj = joint ? qd[long(lane) * n + e] : 0.0f;
