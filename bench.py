@@ -207,6 +207,37 @@ def run_fused_env(torch, robot, n_envs, steps=300, warmup=30):
             "frac_of_hbm_peak": n_envs * bytes_per / us / 1e3 * 1e9 / HBM_PEAK}
 
 
+def run_fused_rollout(torch, robot, n_envs, steps_per_launch=100, launches=20):
+    """Secondary line, never the headline: open-loop rollout with the steps fused
+    into one launch (rb_rollout_fused_dev).  State stays in registers, only the
+    32-byte action record is read per env step; not the per-step contract
+    (no policy can run between steps)."""
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    sim = HipBatchSimulation(robot, n_envs)
+    st = torch.cuda.current_stream()
+    sim.set_stream(st.cuda_stream)
+    ring = torch.rand((RING, n_envs, sim.n_t), device="cuda") * 2 - 1
+    sim.rollout_fused_dev(ring.data_ptr(), RING, steps_per_launch, 0.3)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(st)
+    for _ in range(launches):
+        sim.rollout_fused_dev(ring.data_ptr(), RING, steps_per_launch, 0.3)
+    e1.record(st)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    steps = steps_per_launch * launches
+    us = e0.elapsed_time(e1) * 1e3 / steps
+    q, _, _ = sim.read_state()
+    sim.close()
+    return {"workload": "fused-rollout-%d" % n_envs,
+            "label": "open-loop rollout, %d steps fused per launch, %d envs, Euler fp32 (not the per-step contract)"
+                     % (steps_per_launch, n_envs),
+            "value": n_envs * steps / wall, "ms_per_step": wall * 1e3 / steps, "us_per_step_events": us,
+            "steps": steps, "bytes_per_env_step": 4 * sim.n_t, "finite": bool(np.isfinite(q).all())}
+
+
 def cpu_baseline(robot, seconds, name):
     """The C restatement of the same step (oracle/roboy_oracle.c, fp32 build)
     timed on this box's host cores on a bounded sample of the workload: first
@@ -310,6 +341,8 @@ def main():
                                                    "achieved_GBps", "steps")} |
                                 {"frac_of_hbm_peak": r["achieved_GBps"] * 1e9 / HBM_PEAK})
             also.append(run_fused_env(torch, MsjRobot(), 2097152))
+            for n_fused in (4096, 2097152):
+                also.append(run_fused_rollout(torch, MsjRobot(), n_fused))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(robot, args.cpu_seconds, args.workload)

@@ -169,6 +169,47 @@ msj_step_tendon_per_lane(const Const8 c, const rb::MsjTendon<float> *__restrict_
     if (live && k == 6) feas[e] = ok ? 1u : 0u;
 }
 
+
+// Open-loop rollout fused into one launch (rb_rollout_fused_dev): the env-per-lane
+// step applied n_steps times with the state held in registers; per step only the
+// env's 32-byte action record is read.  Instantiated with the same BLOCK/UNROLL
+// (and the same set-point source) as msj_step_env_per_lane uses for the batch
+// size, so the arithmetic and hence the result is bit-identical to n_steps single steps.
+template <int INTEG, int BLOCK, int UNROLL>
+__global__ void __launch_bounds__(BLOCK)
+msj_rollout_fused(const Const8 c, float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
+                  const float *__restrict__ act_ring, int ring, int n_steps, float act_scale, long n) {
+    const long i = long(blockIdx.x) * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float qq[3], vv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { qq[j] = q[j * n + i]; vv[j] = qd[j * n + i]; }
+    bool ok = true;
+    const float4 *rec = reinterpret_cast<const float4 *>(act_ring) + 2 * i;
+    float4 a0 = rec[0], a1 = rec[1];
+    __shared__ float lds_sp[UNROLL >= NT8 ? 1 : NT8][BLOCK];
+    int slab = 0;
+    for (int t = 0; t < n_steps; ++t) {
+        const float sp[NT8] = {a0.x * act_scale, a0.y * act_scale, a0.z * act_scale, a0.w * act_scale,
+                               a1.x * act_scale, a1.y * act_scale, a1.z * act_scale, a1.w * act_scale};
+        if (t + 1 < n_steps) {   // next step's action: in flight under this step's arithmetic
+            slab = slab + 1 == ring ? 0 : slab + 1;
+            const float4 *nx = rec + long(slab) * 2 * n;
+            a0 = nx[0]; a1 = nx[1];
+        }
+        if (UNROLL >= NT8) {
+            ok = rb::MsjModel<float, NT8>::template step<INTEG, UNROLL>(c, qq, vv, sp);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NT8; ++k) lds_sp[k][threadIdx.x] = sp[k];   // lane-private column: no barrier
+            ok = rb::MsjModel<float, NT8>::template step_sp<INTEG, UNROLL>(c, qq, vv, SpLds{&lds_sp[0][threadIdx.x], BLOCK});
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { q[j * n + i] = qq[j]; qd[j * n + i] = vv[j]; }
+    feas[i] = ok ? 1u : 0u;    // feasibility of the last step, as after n_steps single steps
+}
+
 __global__ void reset_kernel(float *q, float *qd, uint32_t *feas, const uint8_t *mask, int n_q, long n) {
     const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -768,6 +809,26 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
         if (rc) return rc;
     }
     s->env_steps += double(s->n) * n_steps;
+    return RB_OK;
+}
+
+int rb_rollout_fused_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float act_scale) {
+    if (check(s) || !d_ring) return fail(RB_EINVAL, "null argument");
+    RB_HIP(hipSetDevice(s->device));
+    if (ring < 1 || n_steps < 0) return fail(RB_EINVAL, "ring must be >= 1 and n_steps >= 0");
+    if (reinterpret_cast<uintptr_t>(d_ring) % 16) return fail(RB_EINVAL, "action ring must be 16-byte aligned");
+    if (s->tree) return fail(RB_EUNSUPPORTED, "fused rollout is built for ball-joint robots");
+    if (n_steps == 0) return RB_OK;
+    const long n = s->n;
+#define RB_FUSED_LAUNCH(INTEG, B, U)                                                                  \
+    hipLaunchKernelGGL((msj_rollout_fused<INTEG, B, U>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream, \
+                       s->c8, s->d_q, s->d_qd, s->d_feas, d_ring, ring, n_steps, act_scale, n)
+    const bool euler = s->integrator == RB_EULER;
+    if (n <= RB_SMALL_BATCH) { if (euler) RB_FUSED_LAUNCH(0, 64, 8); else RB_FUSED_LAUNCH(1, 64, 8); }
+    else                     { if (euler) RB_FUSED_LAUNCH(0, 256, 1); else RB_FUSED_LAUNCH(1, 256, 1); }
+#undef RB_FUSED_LAUNCH
+    RB_HIP(hipGetLastError());
+    s->env_steps += double(n) * n_steps;
     return RB_OK;
 }
 

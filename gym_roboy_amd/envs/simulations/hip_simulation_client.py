@@ -140,6 +140,11 @@ class HipBatchSimulation:
         nat.check(self._lib.rb_rollout_dev(self._h, ctypes.c_void_p(d_act_ring), int(ring),
                                            int(n_steps), float(act_scale), int(bool(use_graph))))
 
+    def rollout_fused_dev(self, d_act_ring: int, ring: int, n_steps: int, act_scale: float = 1.0):
+        """Open-loop rollout in one launch (state in registers across the steps)."""
+        nat.check(self._lib.rb_rollout_fused_dev(self._h, ctypes.c_void_p(d_act_ring), int(ring),
+                                                 int(n_steps), float(act_scale)))
+
     def fill_actions_dev(self, d_act: int, step: int):
         nat.check(self._lib.rb_fill_actions_dev(self._h, ctypes.c_void_p(d_act), int(step)))
 

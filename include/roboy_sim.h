@@ -153,6 +153,14 @@ int rb_step_dev(rb_sim *sim, const float *d_act, float act_scale);
  * One kernel per env step either way (a policy sits between steps in real use). */
 int rb_rollout_dev(rb_sim *sim, const float *d_act_ring, int ring, int n_steps,
                    float act_scale, int use_graph);
+/* Open-loop rollout fused into ONE launch: every env advances n_steps steps, the
+ * state stays in registers in between and only the action of each step is read
+ * (slab t % ring of d_act_ring).  For action sequences that are known up front
+ * (random-action rollouts, sampling-based planning); NOT the per-step contract of
+ * rb_step_dev / rb_rollout_dev (no policy can sit between steps), so bench.py
+ * reports it separately and never as the headline.  Bit-identical to n_steps
+ * calls of rb_step_dev.  Ball-joint robots only. */
+int rb_rollout_fused_dev(rb_sim *sim, const float *d_act_ring, int ring, int n_steps, float act_scale);
 /* synthetic i.i.d. U[-1,1) actions: Philox4x32-10, key = seed,
  * counter = (env id, step, stream 0) */
 int rb_fill_actions_dev(rb_sim *sim, float *d_act, uint32_t step);

@@ -156,6 +156,44 @@ def test_rollout_dev_equals_repeated_step_dev(msj_robot):
         s.close()
 
 
+@pytest.mark.parametrize("integrator", ["euler", "rk4"])
+@pytest.mark.parametrize("n", [4096, 100001])
+def test_fused_open_loop_rollout_equals_single_steps(msj_robot, integrator, n):
+    """rb_rollout_fused_dev (state in registers across steps, one launch) is
+    bit-identical to the same number of rb_step_dev launches, for both batch
+    regimes of the env-per-lane kernel, including the last step's feasibility."""
+    ring, steps = 3, 41
+    sims = [_sim(msj_robot, n, seed=11, integrator=integrator, n_substeps=2) for _ in range(2)]
+    outs = []
+    for mode, sim in enumerate(sims):
+        sim.select_kernel(KERNELS["env_per_lane"])
+        d_ring = sim.malloc(4 * ring * n * 8)
+        for r in range(ring):
+            sim.fill_actions_dev(d_ring + 4 * r * n * 8, r)
+        if mode == 0:
+            for t in range(steps):
+                sim.step_dev(d_ring + 4 * (t % ring) * n * 8, 0.9)
+        else:
+            sim.rollout_fused_dev(d_ring, ring, steps, 0.9)
+            sim.rollout_fused_dev(d_ring, ring, 0, 0.9)     # zero steps: a no-op
+        sim.synchronize()
+        outs.append(sim.read_state())
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2])
+    assert 0 < outs[0][2].sum() < n       # some envs ended infeasible, some not
+    for s in sims:
+        s.close()
+
+
+def test_fused_rollout_is_refused_for_tree_robots():
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    sim = _sim(UpperBodyRobot(), 8)
+    d = sim.malloc(4 * 8 * sim.n_t)
+    with pytest.raises(Exception, match="ball-joint"):
+        sim.rollout_fused_dev(d, 1, 2, 1.0)
+    sim.close()
+
+
 def test_sharding_is_invisible(msj_robot):
     """Two handles of 512 envs with env_id_offset 0 / 512 reproduce one handle
     of 1024 (random streams are keyed by the global env id)."""
