@@ -39,7 +39,9 @@ WORKLOADS = {
     "upper-body-8192-rk4": (8192, "rk4", 1, 100, 10, "configs[3]: upper body (20 DOF / 38 tendons) 8 192 envs, RK4 fp32"),
 }
 RING = 4
-STATS_EVERY = 100
+# Steps between two all-reduces of the statistics block: one episode horizon
+# (RoboyEnv.max_episode_length = 400 env steps, roboy_env.py:23).
+STATS_EVERY = int(os.environ.get("ROBOY_BENCH_STATS_EVERY", "400"))
 HBM_PEAK = 8.0e12          # B/s, spec (MI355X_MICROARCH.md "HBM3E peak BW")
 HBM_COPY = 6.29e12         # B/s, measured float4 copy (same table)
 
@@ -92,24 +94,24 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
     ring = torch.empty(RING * slab, dtype=torch.float32, device="cuda")
     for r in range(RING):
         sim.fill_actions_dev(ring.data_ptr() + 4 * r * slab, r)
-    # statistics all-reduce: double-buffered and asynchronous, so the launch stream
-    # never waits for the (latency-bound, 64-byte) collective of the previous chunk
+    # statistics all-reduce: 64 bytes, enqueued IN-LINE on the launch stream (a non-async
+    # c10d op runs on the current stream).  Measured on one MI355X (profiles/r1_b/
+    # rccl_one_rank_rehearsal.log): letting the collective run concurrently on a second
+    # stream (async_op=True, or an own side stream) slows the graph-replayed step kernels
+    # from 2.2 to 3.7 us per step for the whole rollout, independent of how often it runs;
+    # in line it costs its own ~20 us per call and nothing else.
     stats_ring = [torch.zeros(8, dtype=torch.float64, device="cuda") for _ in range(2)]
-    pending = [None, None]
     state = {"chunk": 0, "last": stats_ring[0]}
     act_scale = float(robot.get_action_space().high[0])
 
     def reduce_stats():
         from gym_roboy_amd import _native as nat
         import ctypes
-        slot = state["chunk"] % 2
+        buf = stats_ring[state["chunk"] % 2]
         state["chunk"] += 1
-        if pending[slot] is not None:
-            pending[slot].wait()
-        buf = stats_ring[slot]
         nat.check(sim._lib.rb_env_stats_dev(sim.handle, ctypes.c_void_p(buf.data_ptr()), 0))
         if dist.get_backend() == "nccl":
-            pending[slot] = dist.all_reduce(buf, async_op=True)     # RCCL over xGMI
+            dist.all_reduce(buf)                                    # RCCL over xGMI
         else:                                                       # rehearsal over gloo: through the host
             host = buf.cpu()
             dist.all_reduce(host)
@@ -122,13 +124,8 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
             chunk = min(STATS_EVERY, k - done)
             sim.rollout_dev(ring.data_ptr(), RING, chunk, act_scale, use_graph=use_graph)
             done += chunk
-            if world > 1 and chunk == STATS_EVERY:
+            if dist is not None and chunk == STATS_EVERY:
                 reduce_stats()
-
-    def drain():
-        for w in pending:
-            if w is not None:
-                w.wait()
 
     # 16 untimed steps from the reset state decorrelate the envs, then warm-up
     rollout(16)
@@ -139,22 +136,21 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
     if steps > STATS_EVERY and steps % STATS_EVERY:
         rollout(steps % STATS_EVERY)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
     rollout(steps)
-    drain()
     ev1.record(stream)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
@@ -300,6 +296,12 @@ def cpu_baseline(robot, seconds, name):
 
 def main():
     args = parse()
+    # stdout carries exactly one JSON line.  Libraries below write there on their own
+    # (RCCL prints a version banner on stdout when its first communicator comes up), so
+    # file descriptor 1 points at stderr until the line is ready.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -317,7 +319,10 @@ def main():
     local_rank = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # ROBOY_BENCH_DIST_AT_1=1 with RANK/WORLD_SIZE=1/MASTER_* set drives the whole collective
+    # path (RCCL init, statistics all-reduce, barrier, max-reduce) on a one-GPU box; the
+    # multi-GPU launches always take it
+    if world > 1 or (os.environ.get("ROBOY_BENCH_DIST_AT_1") == "1" and "RANK" in os.environ):
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -376,8 +381,9 @@ def main():
             "sanity": {"finite": head["finite"], "feasible_frac": head["feasible_frac"],
                        "allreduced_stats": head["stats"]},
         }
-        print(json.dumps(line))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -775,34 +775,35 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
     if (reinterpret_cast<uintptr_t>(d_ring) % 16) return fail(RB_EINVAL, "action ring must be 16-byte aligned");
     const size_t slab = size_t(s->n) * s->n_t;
     int t = 0;
-    if (use_graph) {
-        // one graph of up to 128 per-step kernel nodes (a whole number of ring turns)
-        const int chunk = ((n_steps < 128 ? n_steps : 128) / ring) * ring;
-        if (chunk >= 8) {
-            rb_sim::GraphKey key;
-            std::memset(&key, 0, sizeof(key));
-            key.ring_ptr = d_ring; key.ring = ring; key.chunk = chunk; key.scale = act_scale; key.kernel = s->kernel;
-            auto it = s->graphs.find(key);
-            if (it == s->graphs.end()) {
-                hipGraph_t graph = nullptr;
-                hipGraphExec_t exec = nullptr;
-                RB_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-                int rc = RB_OK;
-                for (int k = 0; k < chunk && rc == RB_OK; ++k) rc = launch_step(s, d_ring + size_t(k % ring) * slab, act_scale);
-                hipError_t e = hipStreamEndCapture(s->stream, &graph);
-                if (rc != RB_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-                if (e != hipSuccess) return fail(RB_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-                e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(graph);
-                if (e != hipSuccess) return fail(RB_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-                if (s->graphs.size() >= 16) {   // bound the cache: callers that keep changing slabs get re-captures, not a leak
-                    for (auto &kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
-                    s->graphs.clear();
-                }
-                it = s->graphs.emplace(key, exec).first;
+    // graphs of up to 128 per-step kernel nodes, each a whole number of ring turns (so every
+    // graph starts at ring slot 0); what is left over (< 8 steps or a partial turn) is launched eagerly
+    while (use_graph) {
+        const int left = n_steps - t;
+        const int chunk = ((left < 128 ? left : 128) / ring) * ring;
+        if (chunk < 8) break;
+        rb_sim::GraphKey key;
+        std::memset(&key, 0, sizeof(key));
+        key.ring_ptr = d_ring; key.ring = ring; key.chunk = chunk; key.scale = act_scale; key.kernel = s->kernel;
+        auto it = s->graphs.find(key);
+        if (it == s->graphs.end()) {
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            RB_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+            int rc = RB_OK;
+            for (int k = 0; k < chunk && rc == RB_OK; ++k) rc = launch_step(s, d_ring + size_t(k % ring) * slab, act_scale);
+            hipError_t e = hipStreamEndCapture(s->stream, &graph);
+            if (rc != RB_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            if (e != hipSuccess) return fail(RB_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) return fail(RB_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+            if (s->graphs.size() >= 16) {   // bound the cache: callers that keep changing slabs get re-captures, not a leak
+                for (auto &kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
+                s->graphs.clear();
             }
-            for (; t + chunk <= n_steps; t += chunk) RB_HIP(hipGraphLaunch(it->second, s->stream));
+            it = s->graphs.emplace(key, exec).first;
         }
+        for (; t + chunk <= n_steps; t += chunk) RB_HIP(hipGraphLaunch(it->second, s->stream));
     }
     for (; t < n_steps; ++t) {
         int rc = launch_step(s, d_ring + size_t(t % ring) * slab, act_scale);

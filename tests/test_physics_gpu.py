@@ -131,10 +131,11 @@ def test_rollout_tracks_oracle_over_an_episode(msj_robot, msj_oracle, integrator
     sim.close()
 
 
-def test_rollout_dev_equals_repeated_step_dev(msj_robot):
+@pytest.mark.parametrize("steps", [100, 403])     # 403 = 3 graphs of 128 + one of 16 + 3 eager steps
+def test_rollout_dev_equals_repeated_step_dev(msj_robot, steps):
     """The rollout entry point (eager and hipGraph) is bit-identical to
     single-step launches over the same action ring."""
-    n, ring, steps = 4096, 4, 100
+    n, ring = 4096, 4
     sims = [_sim(msj_robot, n, seed=7) for _ in range(3)]
     outs = []
     for mode, sim in enumerate(sims):
