@@ -37,3 +37,24 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert c["kind"] == "port" and c["unit"] == "env-steps/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 1e7          # BASELINE.json's target for one MI355X
     assert d["sanity"]["finite"]
+
+
+def test_bench_collective_path_with_one_rccl_rank():
+    """The multi-rank code path (process group over RCCL, in-line statistics all-reduce
+    every STATS_EVERY steps, barrier, max-reduce) rehearsed with world size 1: still one
+    JSON line on stdout (RCCL's banner must not reach it), the all-reduced statistics
+    count every env step up to the last reduce, and the collective costs no throughput."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29633", ROBOY_BENCH_DIST_AT_1="1", ROBOY_BENCH_STATS_EVERY="400")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1600",
+                          "--warmup", "100", "--no-also", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 1600
+    stats = d["sanity"]["allreduced_stats"]
+    # n_env_steps at the last reduce: 16 decorrelation + 100 warm-up + 400 rehearsal + 1600 timed steps
+    assert stats[6] == 4096.0 * (16 + 100 + 400 + 1600)
+    assert d["ms_per_step"] < 0.0035      # 2.2-2.3 us per step without a process group; 3.7 with a concurrent collective
