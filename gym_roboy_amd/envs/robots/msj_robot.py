@@ -20,8 +20,6 @@ so that
 """
 import math
 
-import numpy as np
-
 from ..._gymcompat import spaces
 from .description import FORMAT_TAG, RobotDescription
 from .roboy_robot import RoboyRobot
@@ -82,31 +80,19 @@ def msj_platform_spec() -> dict:
 
 
 class MsjRobot(RoboyRobot):
+    """Boxes of the reference's MsjRobot (msj_robot.py:8-16); accessors live in the base class."""
 
-    _DIM_JOINT_ANGLE = 3
-    _DIM_ACTION = 8
-    _MAX_TENDON_VEL = 0.02      # unused by the reference as well (msj_robot.py:13)
+    _DIM_JOINT_ANGLE, _DIM_ACTION = 3, 8
     _MAX_TENDON_LENGHT = 0.3    # sic: the reference's spelling, kept for drop-in
+    _MAX_TENDON_VEL = 0.02      # unused by the reference as well (msj_robot.py:13)
 
-    _JOINT_ANGLE_SPACE = spaces.Box(low=-np.pi, high=np.pi,
-                                    shape=(_DIM_JOINT_ANGLE,), dtype="float32")
-    _JOINT_VEL_SPACE = spaces.Box(low=-np.pi / 6, high=np.pi / 6,
-                                  shape=(_DIM_JOINT_ANGLE,), dtype="float32")
     _ACTION_SPACE = spaces.Box(low=-_MAX_TENDON_LENGHT, high=_MAX_TENDON_LENGHT,
                                shape=(_DIM_ACTION,), dtype="float32")
+    _JOINT_ANGLE_SPACE = spaces.Box(low=-math.pi, high=math.pi,
+                                    shape=(_DIM_JOINT_ANGLE,), dtype="float32")
+    _JOINT_VEL_SPACE = spaces.Box(low=-math.pi / 6, high=math.pi / 6,
+                                  shape=(_DIM_JOINT_ANGLE,), dtype="float32")
     _DESCRIPTION = None
-
-    @classmethod
-    def get_action_space(cls) -> spaces.Box:
-        return cls._ACTION_SPACE
-
-    @classmethod
-    def get_joint_angles_space(cls) -> spaces.Box:
-        return cls._JOINT_ANGLE_SPACE
-
-    @classmethod
-    def get_joint_vels_space(cls) -> spaces.Box:
-        return cls._JOINT_VEL_SPACE
 
     @classmethod
     def get_description(cls) -> RobotDescription:

@@ -51,17 +51,30 @@ class RobotState:
 class RoboyRobot:
     """Abstract robot: three spaces, state factories and normalisation."""
 
+    # A concrete robot declares its three boxes as class attributes; the
+    # accessors below are the reference's interface (roboy_robot.py:24-33).
+    _ACTION_SPACE = None
+    _JOINT_ANGLE_SPACE = None
+    _JOINT_VEL_SPACE = None
+
+    @classmethod
+    def _declared(cls, attribute) -> spaces.Box:
+        box = getattr(cls, attribute)
+        if box is None:
+            raise NotImplementedError("%s does not declare %s" % (cls.__name__, attribute))
+        return box
+
     @classmethod
     def get_action_space(cls) -> spaces.Box:
-        raise NotImplementedError
+        return cls._declared("_ACTION_SPACE")
 
     @classmethod
     def get_joint_angles_space(cls) -> spaces.Box:
-        raise NotImplementedError
+        return cls._declared("_JOINT_ANGLE_SPACE")
 
     @classmethod
     def get_joint_vels_space(cls) -> spaces.Box:
-        raise NotImplementedError
+        return cls._declared("_JOINT_VEL_SPACE")
 
     @classmethod
     def get_description(cls):

@@ -129,18 +129,6 @@ class UpperBodyRobot(RoboyRobot):
     _DESCRIPTION = None
 
     @classmethod
-    def get_action_space(cls) -> spaces.Box:
-        return cls._ACTION_SPACE
-
-    @classmethod
-    def get_joint_angles_space(cls) -> spaces.Box:
-        return cls._JOINT_ANGLE_SPACE
-
-    @classmethod
-    def get_joint_vels_space(cls) -> spaces.Box:
-        return cls._JOINT_VEL_SPACE
-
-    @classmethod
     def get_description(cls) -> RobotDescription:
         if UpperBodyRobot._DESCRIPTION is None:
             UpperBodyRobot._DESCRIPTION = (RobotDescription.from_json(_DATA) if os.path.exists(_DATA)
