@@ -463,7 +463,7 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale) {
     // Small batches are latency-bound (a few waves per CU): one wave per
     // workgroup spread over the CUs, tendon loop fully unrolled for ILP.
     // Large batches are VALU-issue-bound: rolled tendon loop (one 16-dword
-    // scalar load per trip, ~70 VGPRs, 7 waves/SIMD).  Measured: DESIGN.md §7.
+    // scalar load per trip, 53 VGPRs, 8 waves/SIMD).  Measured: DESIGN.md §7.
 #define RB_STEP_LAUNCH(INTEG, B, U)                                                                   \
     hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U>), dim3(blocks_for(n, B)), dim3(B), 0,      \
                        s->stream, s->c8, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n)
