@@ -159,7 +159,9 @@ int rb_rollout_dev(rb_sim *sim, const float *d_act_ring, int ring, int n_steps,
  * (random-action rollouts, sampling-based planning); NOT the per-step contract of
  * rb_step_dev / rb_rollout_dev (no policy can sit between steps), so bench.py
  * reports it separately and never as the headline.  Bit-identical to n_steps
- * calls of rb_step_dev.  Ball-joint robots only. */
+ * calls of rb_step_dev with the env-per-lane kernel form selected (the
+ * tendon-per-lane form RB_KERNEL_AUTO picks for small batches sums the tendon
+ * torques in another order: same result to ~1e-6).  Ball-joint robots only. */
 int rb_rollout_fused_dev(rb_sim *sim, const float *d_act_ring, int ring, int n_steps, float act_scale);
 /* synthetic i.i.d. U[-1,1) actions: Philox4x32-10, key = seed,
  * counter = (env id, step, stream 0) */
