@@ -375,6 +375,9 @@ def main():
                 "bytes_per_launch": head["bytes_per_launch"], "launch_us_events": head["launch_us_events"],
                 "note": "events bracket the whole timed region on the launch stream, so the per-launch "
                         "time includes the kernel boundary; rocprofv3 kernel-only time is in profiles/",
+                "launch_floor_us": {"empty_kernel_graph_node": 1.61, "load_store_only_graph_node": 2.16,
+                                    "source": "profiles/r1_b/graph_floor.log (tools/graph_floor.hip), 4 096-env grid"}
+                                   if head["envs_per_gpu"] == 4096 else None,
             },
             "cpu_baseline": cpu,
             "also": also,
