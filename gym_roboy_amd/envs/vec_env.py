@@ -69,6 +69,8 @@ class RoboyVecEnv:
         self._d_obs = self.sim.malloc(4 * n * 3 * self.n_q)
         self._d_rew = self.sim.malloc(4 * n)
         self._d_done = self.sim.malloc(4 * n)
+        self._pending_actions = None
+        self._seed = int(seed)
 
     # ------------------------------------------------------------------
     def reset(self):
@@ -110,6 +112,34 @@ class RoboyVecEnv:
         done = torch.empty((n,), dtype=torch.int32, device=actions.device)
         self.step_dev(actions.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
         return obs, rew, done.bool(), [{}] * n
+
+    # -- the rest of stable_baselines' VecEnv surface (what PPO2 / wrappers call on the
+    #    reference's SubprocVecEnv, train_parallel.py:29) ---------------------------------
+    def step_async(self, actions):
+        self._pending_actions = actions
+
+    def step_wait(self):
+        actions, self._pending_actions = self._pending_actions, None
+        if actions is None:
+            raise RuntimeError("step_wait() without step_async()")
+        return self.step(actions)
+
+    def seed(self, seed=None):
+        """The random streams are keyed at construction (seed, global env id); a VecEnv
+        cannot be re-seeded in place.  Returns one entry per env like SubprocVecEnv."""
+        if seed is not None and int(seed) != self._seed:
+            raise NotImplementedError("construct RoboyVecEnv(seed=%d) instead of re-seeding" % int(seed))
+        return [None] * self.num_envs
+
+    def get_attr(self, attr_name, indices=None):
+        n = self.num_envs if indices is None else len(list(indices))
+        return [getattr(self, attr_name)] * n
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        raise NotImplementedError("the envs of a RoboyVecEnv are not separate Python objects (no %s)" % method_name)
+
+    def render(self, mode="human"):
+        pass        # RoboyEnv.render is a no-op too (roboy_env.py:89-90)
 
     def stats(self, reset: bool = False) -> dict:
         out = (ctypes.c_double * 8)()

@@ -114,3 +114,26 @@ def test_torch_tensor_path_is_zero_copy_and_equal(msj_robot):
     assert np.array_equal(r1, r2.cpu().numpy())
     assert np.array_equal(d1, d2.cpu().numpy())
     v1.close(); v2.close()
+
+
+def test_vec_env_surface_of_stable_baselines(msj_robot):
+    """step_async/step_wait, seed, get_attr, render: what PPO2 calls on the reference's SubprocVecEnv."""
+    from gym_roboy_amd.envs import RoboyVecEnv
+    a = RoboyVecEnv(msj_robot, 64, seed=5)
+    b = RoboyVecEnv(msj_robot, 64, seed=5)
+    a.reset(); b.reset()
+    acts = np.random.default_rng(0).uniform(-1, 1, (64, 8)).astype(np.float32)
+    a.step_async(acts)
+    oa, ra, da, _ = a.step_wait()
+    ob, rb_, db, _ = b.step(acts)
+    assert np.array_equal(oa, ob) and np.array_equal(ra, rb_) and np.array_equal(da, db)
+    with pytest.raises(RuntimeError):
+        a.step_wait()
+    assert a.seed() == [None] * 64 and a.seed(5) == [None] * 64
+    with pytest.raises(NotImplementedError):
+        a.seed(6)
+    assert a.get_attr("num_envs") == [64] * 64 and a.get_attr("num_envs", indices=[0, 3]) == [64, 64]
+    with pytest.raises(NotImplementedError):
+        a.env_method("reset")
+    assert a.render() is None
+    a.close(); b.close()
