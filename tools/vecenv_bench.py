@@ -1,12 +1,14 @@
 """Throughput of the fused env layer (RoboyVecEnv.step_dev) at a few batch sizes (not the headline metric)."""
-import sys, time
+import os, sys, time
 sys.path.insert(0, "/root/repo")
 import torch
 from gym_roboy_amd.envs.robots import MsjRobot
 from gym_roboy_amd.envs.vec_env import RoboyVecEnv
-for n in (4096, 65536, 262144, 2097152):
+INTEG = os.environ.get("VECENV_INTEGRATOR", "euler")
+SIZES = [int(x) for x in os.environ.get("VECENV_SIZES", "4096,65536,262144,2097152").split(",")]
+for n in SIZES:
     with torch.cuda.stream(torch.cuda.Stream()):
-        env = RoboyVecEnv(MsjRobot(), n)
+        env = RoboyVecEnv(MsjRobot(), n, integrator=INTEG)
         st = torch.cuda.current_stream(); env.sim.set_stream(st.cuda_stream)
         acts = [torch.rand((n, 8), device="cuda") * 2 - 1 for _ in range(4)]
         obs = torch.empty((n, 9), device="cuda"); rew = torch.empty(n, device="cuda"); done = torch.empty(n, dtype=torch.int32, device="cuda")
@@ -17,5 +19,5 @@ for n in (4096, 65536, 262144, 2097152):
         for t in range(steps): env.step_dev(acts[t % 4].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
         e1.record(st); torch.cuda.synchronize(); wall = time.perf_counter() - t0
         us = e0.elapsed_time(e1) * 1e3 / steps
-        print("fused env step n=%d: %.2f us/step (events), %.3e env-steps/s wall, %.1f GB/s at 156 B/env-step" % (n, us, n * steps / wall, n * 156 / us / 1e3))
+        print(INTEG, "fused env step n=%d: %.2f us/step (events), %.3e env-steps/s wall, %.1f GB/s at 156 B/env-step" % (n, us, n * steps / wall, n * 156 / us / 1e3))
         env.close()
