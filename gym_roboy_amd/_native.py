@@ -23,6 +23,9 @@ INTEGRATORS = {"euler": RB_EULER, "semi-implicit-euler": RB_EULER, "rk4": RB_RK4
                RB_EULER: RB_EULER, RB_RK4: RB_RK4}
 
 
+STREAM_DEVICE_DEFAULT = ctypes.c_void_p(-1).value     # RB_STREAM_DEVICE_DEFAULT in include/roboy_sim.h
+
+
 class SimInfo(ctypes.Structure):
     _fields_ = [("n_envs", ctypes.c_int64), ("n_q", ctypes.c_int32), ("n_t", ctypes.c_int32),
                 ("integrator", ctypes.c_int32), ("n_substeps", ctypes.c_int32),

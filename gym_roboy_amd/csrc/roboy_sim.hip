@@ -673,7 +673,8 @@ int rb_set_stream(rb_sim *s, void *hip_stream) {
     if (check(s)) return RB_EINVAL;
     RB_HIP(hipSetDevice(s->device));
     RB_HIP(hipStreamSynchronize(s->stream));
-    s->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->own_stream;
+    if (hip_stream == RB_STREAM_DEVICE_DEFAULT) s->stream = nullptr;     // the null stream
+    else s->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->own_stream;
     return RB_OK;
 }
 
@@ -788,6 +789,7 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
         if (it == s->graphs.end()) {
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
+            if (!s->stream) return fail(RB_EINVAL, "hipGraph capture needs a non-default stream (rb_set_stream)");
             RB_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
             int rc = RB_OK;
             for (int k = 0; k < chunk && rc == RB_OK; ++k) rc = launch_step(s, d_ring + size_t(k % ring) * slab, act_scale);

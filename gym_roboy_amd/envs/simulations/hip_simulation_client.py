@@ -67,7 +67,16 @@ class HipBatchSimulation:
         nat.check(self._lib.rb_select_kernel(self._h, int(kernel)))
 
     def set_stream(self, stream_ptr):
-        nat.check(self._lib.rb_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)))
+        """``None``: the handle's own stream; ``0``: the device's default (null) stream, which is
+        what ``torch.cuda.current_stream().cuda_stream`` is unless another stream was made
+        current; otherwise a ``hipStream_t`` value."""
+        if stream_ptr is None:
+            arg = ctypes.c_void_p(0)
+        elif int(stream_ptr) == 0:
+            arg = ctypes.c_void_p(nat.STREAM_DEVICE_DEFAULT)
+        else:
+            arg = ctypes.c_void_p(int(stream_ptr))
+        nat.check(self._lib.rb_set_stream(self._h, arg))
 
     def synchronize(self):
         nat.check(self._lib.rb_synchronize(self._h))

@@ -71,6 +71,8 @@ class RoboyVecEnv:
         self._d_done = self.sim.malloc(4 * n)
         self._pending_actions = None
         self._seed = int(seed)
+        self._replayed_env_steps = 0.0
+        self._stream = None            # the simulation's own stream
 
     # ------------------------------------------------------------------
     def reset(self):
@@ -103,10 +105,7 @@ class RoboyVecEnv:
             raise ValueError("actions must be a contiguous float32 CUDA tensor of shape (%d, %d)" % (n, self.n_t))
         # run on torch's current stream so the policy's kernels and the env
         # step are ordered without a host sync
-        stream = torch.cuda.current_stream(actions.device).cuda_stream
-        if stream != getattr(self, "_stream", None):   # rb_set_stream drains the old stream: only on change
-            self.sim.set_stream(stream)
-            self._stream = stream
+        self.set_stream(torch.cuda.current_stream(actions.device).cuda_stream)
         obs = torch.empty((n, 3 * self.n_q), dtype=torch.float32, device=actions.device)
         rew = torch.empty((n,), dtype=torch.float32, device=actions.device)
         done = torch.empty((n,), dtype=torch.int32, device=actions.device)
@@ -141,12 +140,29 @@ class RoboyVecEnv:
     def render(self, mode="human"):
         pass        # RoboyEnv.render is a no-op too (roboy_env.py:89-90)
 
+    def set_stream(self, stream_ptr):
+        """Stream of every later launch of this env (``HipBatchSimulation.set_stream``: 0 = the
+        device's default stream).  A change drains the previous stream, so it is only forwarded
+        when the stream really changes."""
+        if stream_ptr != self._stream:
+            self.sim.set_stream(stream_ptr)
+            self._stream = stream_ptr
+
     def stats(self, reset: bool = False) -> dict:
         out = (ctypes.c_double * 8)()
         nat.check(self.sim._lib.rb_env_stats(self.sim.handle, out, int(reset)))
         keys = ("sum_return", "sum_return_sq", "n_episodes", "sum_length", "n_goal_reached",
                 "n_infeasible_steps", "n_env_steps", "sum_reward")
-        return dict(zip(keys, list(out)))
+        stats = dict(zip(keys, list(out)))
+        stats["n_env_steps"] += self._replayed_env_steps    # steps replayed from a captured graph
+        if reset:
+            self._replayed_env_steps = 0.0
+        return stats
+
+    def note_replayed_steps(self, n_steps: int):
+        """n_env_steps is counted where launches are issued; a caller that replays a
+        captured graph of `n_steps` env steps (ppo.py) reports them here."""
+        self._replayed_env_steps += float(n_steps) * self.num_envs
 
     def stats_dev(self, d_out8: int, reset: bool = False):
         nat.check(self.sim._lib.rb_env_stats_dev(self.sim.handle, ctypes.c_void_p(d_out8), int(reset)))

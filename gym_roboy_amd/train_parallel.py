@@ -22,6 +22,8 @@ def main(argv=None):
     ap.add_argument("--rounds", type=int, default=1, help="rounds of 100 000 timesteps (reference: unbounded)")
     ap.add_argument("--steps-per-round", type=int, default=TRAINING_STEPS_BETWEEN_BACKUPS)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-graphs", action="store_true",
+                    help="launch every kernel from Python instead of replaying HIP graphs (single-rank runs use graphs)")
     args = ap.parse_args(argv)
 
     import torch
@@ -45,7 +47,8 @@ def main(argv=None):
     env = RoboyVecEnv(MsjRobot(), args.num_envs, seed=args.seed, device=local_rank,
                       env_id_offset=rank * args.num_envs)
     more_exploration = 0.1                      # train_parallel.py:30
-    agent = PPO(env, ent_coef=more_exploration, device="cuda", dist=dist, seed=args.seed, reward_scale=0.01)
+    agent = PPO(env, ent_coef=more_exploration, device="cuda", dist=dist, seed=args.seed, reward_scale=0.01,
+                use_graphs=(world == 1 and not args.no_graphs))
     if os.path.exists(model_file):
         agent.load(model_file)                  # resume from the last backup
     for _ in range(args.rounds):

@@ -131,7 +131,13 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator,
 void rb_destroy(rb_sim *sim);
 int rb_info(const rb_sim *sim, rb_sim_info *info);
 int rb_select_kernel(rb_sim *sim, int kernel);
-int rb_set_stream(rb_sim *sim, void *hip_stream); /* NULL = the handle's own */
+/* The stream every launch, copy and synchronisation of this handle uses.  NULL = the
+ * handle's own (non-blocking) stream; RB_STREAM_DEVICE_DEFAULT = the device's default
+ * (null) stream, which is what a framework's "current stream" is unless the caller made
+ * another one current (its handle is 0 and cannot be told from NULL, hence the
+ * sentinel); anything else = that hipStream_t.  Drains the previous stream first. */
+#define RB_STREAM_DEVICE_DEFAULT ((void *)(intptr_t)-1)
+int rb_set_stream(rb_sim *sim, void *hip_stream);
 int rb_synchronize(rb_sim *sim);
 
 /* ---- host-buffer entry points (synchronous; plumbing, not the hot loop) ---- */

@@ -195,6 +195,35 @@ def test_fused_rollout_is_refused_for_tree_robots():
     sim.close()
 
 
+def test_stream_selection_own_default_and_given(msj_robot):
+    """set_stream(None) = the handle's own stream, 0 = the device's default (null) stream (what a
+    framework's current stream is by default; not the same thing as "own"), else a hipStream_t.
+    The three give the same results; graph capture is refused on the null stream, loudly."""
+    import torch
+    n = 4096
+    outs = []
+    for which in ("own", "default", "given"):
+        sim = _sim(msj_robot, n, seed=2)
+        side = torch.cuda.Stream()
+        sim.set_stream({"own": None, "default": 0, "given": side.cuda_stream}[which])
+        d_act = sim.malloc(4 * n * 8)
+        sim.fill_actions_dev(d_act, 0)
+        for _ in range(5):
+            sim.step_dev(d_act, 0.3)
+        if which == "default":
+            with pytest.raises(ValueError, match="non-default stream"):
+                sim.rollout_dev(d_act, 1, 16, 0.3, use_graph=True)
+            torch.cuda.synchronize()          # a torch-side sync of the default stream covers the launches
+        else:
+            sim.rollout_dev(d_act, 1, 16, 0.3, use_graph=True)
+            sim.rollout_dev(d_act, 1, 16, 0.3, use_graph=False)
+            sim.synchronize()
+        outs.append(sim.read_state())
+        sim.close()
+    assert np.array_equal(outs[0][0], outs[2][0]) and np.array_equal(outs[0][1], outs[2][1])
+    assert np.abs(outs[1][0]).max() > 0          # the default-stream steps ran
+
+
 def test_sharding_is_invisible(msj_robot):
     """Two handles of 512 envs with env_id_offset 0 / 512 reproduce one handle
     of 1024 (random streams are keyed by the global env id)."""

@@ -103,6 +103,64 @@ def test_ppo_runs_on_the_device_env_without_host_copies():
 
 
 @pytest.mark.gpu
+def test_graph_mode_rollout_is_a_valid_rollout():
+    """The captured rollout (policy, sampling, env kernel through the C ABI, GAE) produces what
+    the eager loop produces from the same policy: same env transitions for the same actions,
+    log-probs and values of the policy, GAE of the rewards."""
+    import torch
+    from gym_roboy_amd.envs.robots import MsjRobot
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    from gym_roboy_amd.ppo import gae
+    T, N = 16, 512
+    env = RoboyVecEnv(MsjRobot(), N, seed=3)
+    agent = PPO(env, n_steps=T, device="cuda", ent_coef=0.1, reward_scale=0.01, seed=4, use_graphs=True)
+    assert agent.use_graphs
+    roll = {k: v.clone() for k, v in agent.collect().items()}
+    assert all(bool(torch.isfinite(v).all()) for v in roll.values())
+    assert float(roll["act"].std()) > 0.5                       # sampled, not the mean
+    # replay the recorded actions through a second env with eager launches
+    env2 = RoboyVecEnv(MsjRobot(), N, seed=3)
+    obs = torch.as_tensor(env2.reset(), device="cuda")
+    assert torch.equal(obs, roll["obs"][0])
+    with torch.no_grad():
+        for t in range(T):
+            d = agent.policy.dist(roll["obs"][t])
+            assert torch.allclose(d.log_prob(roll["act"][t]).sum(-1), roll["logp"][t], rtol=1e-5, atol=1e-5)
+            assert torch.allclose(agent.policy.value(roll["obs"][t]), roll["val"][t], rtol=1e-5, atol=1e-6)
+            o, r, dn, _ = env2.step(roll["act"][t].clamp(-1, 1).contiguous())
+            assert torch.equal(r * 0.01, roll["rew"][t]) and torch.equal(dn.float(), roll["done"][t])
+            if t + 1 < T:
+                assert torch.equal(o, roll["obs"][t + 1])
+        adv, ret = gae(roll["rew"], roll["val"], roll["done"], agent.policy.value(o), 0.99, 0.95)
+    assert torch.allclose(adv, roll["adv"], rtol=1e-5, atol=1e-6) and torch.allclose(ret, roll["ret"], rtol=1e-5, atol=1e-6)
+    env.close(); env2.close()
+
+
+@pytest.mark.gpu
+def test_graph_mode_learns_counts_and_resumes(tmp_path):
+    import torch
+    from gym_roboy_amd.envs.robots import MsjRobot
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    env = RoboyVecEnv(MsjRobot(), 256, seed=0)
+    agent = PPO(env, n_steps=16, device="cuda", ent_coef=0.1, reward_scale=0.01, use_graphs=True)
+    logs = []
+    agent.learn(total_timesteps=256 * 16 * 4, log=logs.append)
+    assert len(logs) == 4 and all(np.isfinite(l["loss"]) for l in logs)
+    assert agent.num_timesteps == 256 * 16 * 4
+    assert env.stats()["n_env_steps"] == 256 * 16 * 4          # replayed steps are reported to the env
+    first = [l["mean_reward"] for l in logs]
+    assert len(set(first)) == 4                                 # every replay is a new rollout (RNG advances)
+    path = str(tmp_path / "model.pkl")
+    agent.save(path)
+    before = {k: v.clone() for k, v in agent.policy.state_dict().items()}
+    agent.load(path)                                            # resume from the checkpoint, rollout graph stays valid
+    agent.learn(total_timesteps=256 * 16, log=logs.append)
+    assert np.isfinite(logs[-1]["loss"])
+    assert any(not torch.equal(before[k], v) for k, v in agent.policy.state_dict().items())
+    env.close()
+
+
+@pytest.mark.gpu
 def test_train_then_play_back(tmp_path, capsys):
     """train_parallel.py -> model.pkl -> visualize_agent.py, the reference's two drivers."""
     from gym_roboy_amd import train_parallel, visualize_agent
