@@ -304,7 +304,17 @@ msj_env_step_kernel(const Const8 c, const EnvParams e, const GoalBox box,
         const float x = fminf(fmaxf(a[k], -1.0f), 1.0f);
         sp[k] = mul_then_add(e.slope, x - 1.0f, e.act_hi);
     }
-    const bool ok = rb::MsjModel<float, NT8>::template step<INTEG, UNROLL>(c, qq, vv, sp);
+    bool ok;
+    if (UNROLL >= NT8) {
+        ok = rb::MsjModel<float, NT8>::template step<INTEG, UNROLL>(c, qq, vv, sp);
+    } else {
+        // rolled tendon loop: the set-points are indexed at run time, keep them as an LDS column
+        // (as msj_step_env_per_lane does); each lane reads back only what it wrote
+        __shared__ float lds_sp[NT8][BLOCK];
+#pragma unroll
+        for (int k = 0; k < NT8; ++k) lds_sp[k][threadIdx.x] = sp[k];
+        ok = rb::MsjModel<float, NT8>::template step_sp<INTEG, UNROLL>(c, qq, vv, SpLds{&lds_sp[0][threadIdx.x], BLOCK});
+    }
     uint32_t sn = step_num[i] + 1u;
 
     // reward (roboy_env.py:92-112), fp32.  The normalisation (2v - hi - lo)/(hi - lo)

@@ -11,9 +11,9 @@ from oracle import philox_np as ph
 
 
 class HipStepper:
-    def __init__(self, robot, n, seed, env_id_offset=0):
+    def __init__(self, robot, n, seed, env_id_offset=0, integrator="euler"):
         from gym_roboy_amd.envs.simulations import HipBatchSimulation
-        self.sim = HipBatchSimulation(robot, n, seed=seed, env_id_offset=env_id_offset)
+        self.sim = HipBatchSimulation(robot, n, seed=seed, env_id_offset=env_id_offset, integrator=integrator)
         # the fused env kernel evaluates the env-per-lane arithmetic; use the same
         # form here so states can be compared bit for bit (the tendon-per-lane
         # form sums the 8 tendon torques in a different order)
