@@ -132,8 +132,8 @@ def test_tree_kernel_on_the_msj_robot_equals_the_closed_form(msj_robot, msj_orac
     _check(Msj4(), COracle(desc, "f64"), 65, "euler", 1, seed=8)
 
 
-@pytest.mark.parametrize("auto_reset", [True, False])
-def test_fused_env_layer_on_the_upper_body_matches_host_replay(upper_body, auto_reset):
+@pytest.mark.parametrize("auto_reset,integrator", [(True, "euler"), (False, "euler"), (True, "rk4")])
+def test_fused_env_layer_on_the_upper_body_matches_host_replay(upper_body, auto_reset, integrator):
     """RoboyVecEnv over the joint-tree kernel: same replay check as for MsjRobot
     (tests/test_env_layer_gpu.py): states and goals bit for bit against the plain
     tree kernel + numpy Philox, reward/done against reward.py in float64."""
@@ -142,8 +142,10 @@ def test_fused_env_layer_on_the_upper_body_matches_host_replay(upper_body, auto_
     from host_env_model import HipStepper, HostEnvModel
     from gym_roboy_amd.envs.vec_env import RoboyVecEnv
     n, seed, max_len = 130, 3, 9
-    vec = RoboyVecEnv(upper_body, n, seed=seed, auto_reset=auto_reset, max_episode_length=max_len, joint_vel_penalty=True)
-    host = HostEnvModel(upper_body, HipStepper(upper_body, n, seed), n, seed, max_len, True, True, auto_reset)
+    vec = RoboyVecEnv(upper_body, n, seed=seed, auto_reset=auto_reset, max_episode_length=max_len, joint_vel_penalty=True,
+                      integrator=integrator)
+    host = HostEnvModel(upper_body, HipStepper(upper_body, n, seed, integrator=integrator), n, seed, max_len, True, True,
+                        auto_reset)
     obs0 = vec.reset()
     host.goal = host.draw(np.ones(n, bool))
     assert obs0.shape == (n, 60) and not obs0[:, :40].any() and np.array_equal(obs0[:, 40:], host.goal)
