@@ -224,6 +224,53 @@ def test_stream_selection_own_default_and_given(msj_robot):
     assert np.abs(outs[1][0]).max() > 0          # the default-stream steps ran
 
 
+def test_device_pointer_accessors(msj_robot):
+    """rb_state_ptrs exposes the SoA planes q[j][N], qd[j][N], feasible[N] in place;
+    rb_sample_goals_dev draws the same goals as the host entry point; rb_env_stats_dev
+    delivers the same block as rb_env_stats."""
+    import ctypes
+    from gym_roboy_amd import _native as nat
+    from gym_roboy_amd.envs import RoboyVecEnv
+    n = 1000
+    a, b = _sim(msj_robot, n, seed=8), _sim(msj_robot, n, seed=8)
+    desc = msj_robot.get_description()
+    q, qd, sp = random_states(desc, n, 21)
+    a.set_state(q, qd)
+    a.forward_step_command(sp)
+    dq, dqd, dfeas = a.state_ptrs()
+    planes_q = a.download(dq, (3, n))               # [j][N]
+    planes_qd = a.download(dqd, (3, n))
+    feas = a.download(dfeas, (n,), np.uint32)
+    rq, rqd, rf = a.read_state()
+    assert np.array_equal(planes_q.T, rq) and np.array_equal(planes_qd.T, rqd) and np.array_equal(feas != 0, rf)
+    # goals: device planes [j][N] vs host rows [N][j], same draw index on two handles with the same seed
+    d_goal = a.malloc(4 * 3 * n)
+    a.sample_goals_dev(d_goal)
+    a.synchronize()
+    assert np.array_equal(a.download(d_goal, (3, n)).T, b.get_new_goal_joint_angles())
+    mask = (np.arange(n) % 3 == 0).astype(np.uint8)
+    d_mask = a.malloc(n)
+    a.upload(d_mask, mask)
+    before = a.download(d_goal, (3, n)).T.copy()
+    a.sample_goals_dev(d_goal, d_mask)
+    a.synchronize()
+    after = a.download(d_goal, (3, n)).T
+    expect = b.get_new_goal_joint_angles(mask)
+    assert np.array_equal(after[mask == 1], expect[mask == 1]) and np.array_equal(after[mask == 0], before[mask == 0])
+    a.close(); b.close()
+    env = RoboyVecEnv(msj_robot, 512, seed=1, max_episode_length=5)
+    env.reset()
+    for _ in range(12):
+        env.step(np.zeros((512, 8), np.float32))
+    d_out = env.sim.malloc(64)
+    env.stats_dev(d_out)
+    env.sim.synchronize()
+    host = env.stats()
+    dev = env.sim.download(d_out, (8,), np.float64)
+    assert np.array_equal(dev, np.array(list(host.values()))) and host["n_episodes"] >= 2 * 512
+    env.close()
+
+
 def test_sharding_is_invisible(msj_robot):
     """Two handles of 512 envs with env_id_offset 0 / 512 reproduce one handle
     of 1024 (random streams are keyed by the global env id)."""
