@@ -42,16 +42,20 @@ inline bool msj_class(const rb_robot_desc *d, std::string &why) {
 }
 
 template <typename T, int NT>
-int msj_build(const rb_robot_desc *d, double step_size, int nsub, MsjConst<T, NT> *out, std::string &err) {
+int msj_build(const rb_robot_desc *d, double step_size, int nsub, MsjConst<T, NT> *out, std::string &err,
+              bool exact = true) {
     if (!msj_class(d, err)) return RB_EUNSUPPORTED;
-    if (d->n_t != NT) { err = "tendon count does not match this kernel instance"; return RB_EUNSUPPORTED; }
+    // exact = true: the kernels with a compile-time tendon count; false: up to NT tendons, count in c.nt
+    if (exact ? d->n_t != NT : (d->n_t < 1 || d->n_t > NT)) {
+        err = "tendon count does not match this kernel instance"; return RB_EUNSUPPORTED;
+    }
     MsjConst<T, NT> &c = *out;
     auto seglen = [&](int va, int vb) {
         double s = 0.0;
         for (int a = 0; a < 3; ++a) { const double t = d->vp_pos[3 * vb + a] - d->vp_pos[3 * va + a]; s += t * t; }
         return std::sqrt(s);
     };
-    for (int k = 0; k < NT; ++k) {
+    for (int k = 0; k < d->n_t; ++k) {
         const int v0 = d->vp_offset[k], v1 = d->vp_offset[k + 1];
         int vb = v0;
         while (d->vp_link[vb] == -1) ++vb;   // first body via-point
@@ -71,6 +75,13 @@ int msj_build(const rb_robot_desc *d, double step_size, int nsub, MsjConst<T, NT
         t.inv_vl0 = T(1.0 / (d->v_max * l0));
         for (int a = 0; a < 4; ++a) t.pad[a] = T(0);
     }
+    for (int k = d->n_t; k < NT; ++k) {       // unused records: a well-formed tendon that never pulls
+        MsjTendon<T> &t = c.ten[k];
+        t.A[0] = T(1); t.A[1] = T(0); t.A[2] = T(0); t.B[0] = T(0); t.B[1] = T(0); t.B[2] = T(1);
+        t.ab2 = T(2); t.inv_l0 = T(1); t.e_lc = T(-1); t.sg_l0 = T(0); t.fmax = T(0); t.inv_vl0 = T(1);
+        for (int a = 0; a < 4; ++a) t.pad[a] = T(0);
+    }
+    c.nt = d->n_t;
     const double m = d->mass[2];
     const double *cm = d->com + 6, *ic = d->inertia + 12;
     const double c2 = cm[0] * cm[0] + cm[1] * cm[1] + cm[2] * cm[2];

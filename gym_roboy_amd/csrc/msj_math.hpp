@@ -123,6 +123,7 @@ struct MsjConst {
     T h;              // integrator substep
     int32_t nsub;
     int32_t simple;   // 1: principal-axis inertia, COM on body z, gravity along world z (fast path)
+    int32_t nt;       // tendons in use (<= NT); only the run-time-count kernels (UNROLL = 0) read it
 };
 
 // set-points held in a per-lane register array (compile-time indices only)
@@ -273,7 +274,9 @@ struct MsjModel {
 
     // Acceleration with all NT tendons evaluated by this lane.  UNROLL = unroll
     // factor of the tendon loop (NT: straight-line code, most ILP; 1: rolled,
-    // one scalar load of the tendon record per trip, fewest registers).
+    // one scalar load of the tendon record per trip, fewest registers; 0: rolled
+    // with the trip count c.nt <= NT read at run time, for robots of the class
+    // with another tendon count than the instantiated one).
     // SP: set-point source, sp(k) (register array or LDS column).
     template <int UNROLL, typename SP>
     struct AccelAllTendons {
@@ -282,8 +285,14 @@ struct MsjModel {
         RB_HD void operator()(const T q[3], const T qd[3], T qdd[3]) const {
             const Frame f = frame(q, qd);
             T tx = T(0), ty = T(0), tz = T(0);
-#pragma unroll UNROLL
-            for (int k = 0; k < NT; ++k) tendon(c, f, c.ten[k], sp(k), tx, ty, tz);
+            if (UNROLL == 0) {
+#pragma unroll 1
+                for (int k = 0; k < c.nt; ++k) tendon(c, f, c.ten[k], sp(k), tx, ty, tz);
+            } else {
+                constexpr int U = UNROLL > 0 ? UNROLL : 1;
+#pragma unroll U
+                for (int k = 0; k < NT; ++k) tendon(c, f, c.ten[k], sp(k), tx, ty, tz);
+            }
             rigid_body(c, f, qd, tx, ty, tz, qdd);
         }
     };

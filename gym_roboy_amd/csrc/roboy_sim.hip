@@ -53,6 +53,10 @@ using rbe::mul_then_add;
 
 constexpr int NT8 = 8;
 using Const8 = rb::MsjConst<float, NT8>;
+// ball-joint robots with another tendon count: kernels instantiated for up to NTX
+// tendons, the count itself (c.nt) read at run time (UNROLL = 0, rolled loop)
+constexpr int NTX = 16;
+using ConstX = rb::MsjConst<float, NTX>;
 
 // ------------------------------------------------------------------ kernels
 
@@ -98,6 +102,28 @@ msj_step_env_per_lane(const Const8 c, float *__restrict__ q, float *__restrict__
 }
 
 
+
+// Env-per-lane step for ball-joint robots with 1..NTX tendons (count in c.nt): the rolled
+// tendon loop of the large-batch form with a run-time trip count; actions are rows of
+// c.nt floats, staged (scaled) as the lane's LDS column.
+template <int INTEG, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+msj_step_env_per_lane_nt(const ConstX c, float *__restrict__ q, float *__restrict__ qd,
+                         uint32_t *__restrict__ feas, const float *__restrict__ act, float act_scale, long n) {
+    const long i = long(blockIdx.x) * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    __shared__ float lds_sp[NTX][BLOCK];
+    const int nt = c.nt;
+    const float *row = act + i * nt;
+    for (int k = 0; k < nt; ++k) lds_sp[k][threadIdx.x] = row[k] * act_scale;
+    float qq[3], vv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { qq[j] = q[j * n + i]; vv[j] = qd[j * n + i]; }
+    const bool ok = rb::MsjModel<float, NTX>::template step_sp<INTEG, 0>(c, qq, vv, SpLds{&lds_sp[0][threadIdx.x], BLOCK});
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { q[j * n + i] = qq[j]; qd[j * n + i] = vv[j]; }
+    feas[i] = ok ? 1u : 0u;
+}
 
 // ---------------------------------------------------------------------------
 // Tendon-per-lane form for small batches.  8 consecutive lanes share one env:
@@ -279,9 +305,10 @@ __device__ __forceinline__ void draw_goal3(const GoalBox &box, uint64_t seed, ui
     for (int j = 0; j < 3; ++j) g[j] = goal_value(box.lo[j], box.hi[j], r.v[j]);
 }
 
-template <int INTEG, int BLOCK, int UNROLL>
+// UNROLL = 0: run-time tendon count (ConstX, c.nt tendons, action rows of c.nt floats)
+template <int INTEG, int BLOCK, int UNROLL, typename CONST = Const8>
 __global__ void __launch_bounds__(BLOCK)
-msj_env_step_kernel(const Const8 c, const EnvParams e, const GoalBox box,
+msj_env_step_kernel(const CONST c, const EnvParams e, const GoalBox box,
                     float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
                     float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
                     uint32_t *__restrict__ goal_count, const float *__restrict__ act,
@@ -290,21 +317,27 @@ msj_env_step_kernel(const Const8 c, const EnvParams e, const GoalBox box,
                     long n, uint64_t seed, uint64_t env0) {
     const long i = long(blockIdx.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
-    float qq[3], vv[3], gg[3], sp[NT8];
+    float qq[3], vv[3], gg[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { qq[j] = q[j * n + i]; vv[j] = qd[j * n + i]; gg[j] = goal[j * n + i]; }
+    // the reference asserts the action lies in [-1,1] (roboy_env.py:52); a batched kernel
+    // cannot raise, so it clamps.  Then slope * (x - in_high) + out_high, each op rounded
+    // (roboy_env.py:157-158)
+    auto rescale = [&](float a) { return mul_then_add(e.slope, fminf(fmaxf(a, -1.0f), 1.0f) - 1.0f, e.act_hi); };
+    bool ok;
+    if constexpr (UNROLL == 0) {
+        __shared__ float lds_sp[NTX][BLOCK];
+        const int nt = c.nt;
+        const float *row = act + i * nt;
+        for (int k = 0; k < nt; ++k) lds_sp[k][threadIdx.x] = rescale(row[k]);
+        ok = rb::MsjModel<float, NTX>::template step_sp<INTEG, 0>(c, qq, vv, SpLds{&lds_sp[0][threadIdx.x], BLOCK});
+    } else {
+    float sp[NT8];
     const float4 a0 = reinterpret_cast<const float4 *>(act)[2 * i];
     const float4 a1 = reinterpret_cast<const float4 *>(act)[2 * i + 1];
     const float a[NT8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { qq[j] = q[j * n + i]; vv[j] = qd[j * n + i]; gg[j] = goal[j * n + i]; }
-#pragma unroll
-    for (int k = 0; k < NT8; ++k) {
-        // the reference asserts the action lies in [-1,1] (roboy_env.py:52); a
-        // batched kernel cannot raise, so it clamps.  Then
-        // slope * (x - in_high) + out_high, each op rounded (roboy_env.py:157-158)
-        const float x = fminf(fmaxf(a[k], -1.0f), 1.0f);
-        sp[k] = mul_then_add(e.slope, x - 1.0f, e.act_hi);
-    }
-    bool ok;
+    for (int k = 0; k < NT8; ++k) sp[k] = rescale(a[k]);
     if (UNROLL >= NT8) {
         ok = rb::MsjModel<float, NT8>::template step<INTEG, UNROLL>(c, qq, vv, sp);
     } else {
@@ -314,6 +347,7 @@ msj_env_step_kernel(const Const8 c, const EnvParams e, const GoalBox box,
 #pragma unroll
         for (int k = 0; k < NT8; ++k) lds_sp[k][threadIdx.x] = sp[k];
         ok = rb::MsjModel<float, NT8>::template step_sp<INTEG, UNROLL>(c, qq, vv, SpLds{&lds_sp[0][threadIdx.x], BLOCK});
+    }
     }
     uint32_t sn = step_num[i] + 1u;
 
@@ -434,6 +468,8 @@ struct rb_sim {
     uint64_t seed = 0;
     int64_t env0 = 0;
     Const8 c8;
+    ConstX cx;               // ball-joint robots with n_t != 8 (ntx = true)
+    bool ntx = false;
     rb::MsjTendon<float> *d_ten = nullptr;   // device copy of c8.ten for the tendon-per-lane form
     int kernel_choice = RB_KERNEL_AUTO;
     // generic joint-tree robots (tree_kernels.hpp): wave-per-env kernel
@@ -486,6 +522,13 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale) {
         else
             hipLaunchKernelGGL((rbt::tree_step_wave_per_env<1>), dim3(tree_blocks), dim3(64 * rbt::TREE_WAVES), lds, s->stream,
                                s->tree_host.dev, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
+    } else if (s->ntx) {
+#define RB_NT_LAUNCH(INTEG, B)                                                                          \
+    hipLaunchKernelGGL((msj_step_env_per_lane_nt<INTEG, B>), dim3(blocks_for(n, B)), dim3(B), 0,       \
+                       s->stream, s->cx, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n)
+        if (n <= RB_SMALL_BATCH) { if (s->integrator == RB_EULER) RB_NT_LAUNCH(0, 64); else RB_NT_LAUNCH(1, 64); }
+        else                     { if (s->integrator == RB_EULER) RB_NT_LAUNCH(0, 256); else RB_NT_LAUNCH(1, 256); }
+#undef RB_NT_LAUNCH
     } else if (s->kernel == RB_KERNEL_TENDON_PER_LANE) {
         const unsigned g = blocks_for(n * NT8, 64);
         if (s->integrator == RB_EULER)
@@ -554,6 +597,14 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
     if (!s) return fail(RB_ENOMEM, "out of host memory");
     std::string why;
     int rc = rb::msj_build<float, NT8>(robot, step_size, n_substeps, &s->c8, why);
+    if (rc == RB_EUNSUPPORTED && robot->n_t != NT8) {
+        // a ball-joint robot with another tendon count: same closed form, run-time count
+        std::string why_x;
+        if (rb::msj_build<float, NTX>(robot, step_size, n_substeps, &s->cx, why_x, /*exact=*/false) == RB_OK) {
+            s->ntx = true;
+            rc = RB_OK;
+        }
+    }
     if (rc == RB_EUNSUPPORTED) {
         // not a ball-joint robot: the generic joint-tree kernel (one env per wave)
         std::string why_tree;
@@ -670,6 +721,12 @@ int rb_select_kernel(rb_sim *s, int kernel) {
         return RB_OK;
     }
     if (kernel == RB_KERNEL_ENV_PER_WAVE) return fail(RB_EUNSUPPORTED, "ball-joint robots have no env-per-wave kernel");
+    if (s->ntx) {   // 8 lanes per env is the 8-tendon form
+        if (kernel == RB_KERNEL_TENDON_PER_LANE)
+            return fail(RB_EUNSUPPORTED, "the tendon-per-lane kernel is built for 8 tendons");
+        s->kernel = RB_KERNEL_ENV_PER_LANE;
+        return RB_OK;
+    }
     s->kernel = kernel != RB_KERNEL_AUTO ? kernel
                 : (s->n <= (s->integrator == RB_EULER ? RB_TENDON_LANE_BATCH_EULER : RB_TENDON_LANE_BATCH_RK4)
                        ? RB_KERNEL_TENDON_PER_LANE : RB_KERNEL_ENV_PER_LANE);
@@ -830,7 +887,7 @@ int rb_rollout_fused_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, 
     RB_HIP(hipSetDevice(s->device));
     if (ring < 1 || n_steps < 0) return fail(RB_EINVAL, "ring must be >= 1 and n_steps >= 0");
     if (reinterpret_cast<uintptr_t>(d_ring) % 16) return fail(RB_EINVAL, "action ring must be 16-byte aligned");
-    if (s->tree) return fail(RB_EUNSUPPORTED, "fused rollout is built for ball-joint robots");
+    if (s->tree || s->ntx) return fail(RB_EUNSUPPORTED, "fused rollout is built for 8-tendon ball-joint robots");
     if (n_steps == 0) return RB_OK;
     const long n = s->n;
 #define RB_FUSED_LAUNCH(INTEG, B, U)                                                                  \
@@ -865,7 +922,7 @@ int rb_sample_goals_dev(rb_sim *s, const uint8_t *d_mask, float *d_goal_q) {
 
 int rb_env_configure(rb_sim *s, const rb_env_config *cfg) {
     if (check(s) || !cfg) return fail(RB_EINVAL, "null argument");
-    if (!s->tree && (s->n_q != 3 || s->n_t != NT8)) return fail(RB_EUNSUPPORTED, "fused env layer: unsupported robot");
+    if (!s->tree && s->n_q != 3) return fail(RB_EUNSUPPORTED, "fused env layer: unsupported robot");
     if (cfg->max_episode_length < 1) return fail(RB_EINVAL, "max_episode_length must be >= 1");
     if (!(cfg->angle_hi > cfg->angle_lo) || !(cfg->vel_hi > cfg->vel_lo) || !(cfg->action_hi > cfg->action_lo))
         return fail(RB_EINVAL, "empty box in env config");
@@ -935,8 +992,18 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
                        s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done, s->d_ep_acc,       \
                        s->d_infeas_n, n,                                                                \
                        s->seed, uint64_t(s->env0))
+#define RB_ENV_LAUNCH_NT(INTEG, B)                                                                       \
+    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, 0, ConstX>), dim3(blocks_for(n, B)), dim3(B), 0,   \
+                       s->stream, s->cx, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal,          \
+                       s->d_step_num, s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done,      \
+                       s->d_ep_acc, s->d_infeas_n, n, s->seed, uint64_t(s->env0))
+    if (s->ntx) {
+        if (n <= RB_SMALL_BATCH) { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_NT(0, 64); else RB_ENV_LAUNCH_NT(1, 64); }
+        else                     { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_NT(0, 256); else RB_ENV_LAUNCH_NT(1, 256); }
+    } else
     if (n <= RB_SMALL_BATCH) { if (s->integrator == RB_EULER) RB_ENV_LAUNCH(0, 64, 8); else RB_ENV_LAUNCH(1, 64, 8); }
     else                     { if (s->integrator == RB_EULER) RB_ENV_LAUNCH(0, 256, 1); else RB_ENV_LAUNCH(1, 256, 1); }
+#undef RB_ENV_LAUNCH_NT
 #undef RB_ENV_LAUNCH
     RB_HIP(hipGetLastError());
     s->env_steps += double(n);

@@ -124,7 +124,11 @@ int rb_device_count(int *count);
 /* rb_create: build a batch of n_envs environments on `device`.
  * env_id_offset shards one logical batch over several handles/GPUs: all
  * counter-based random streams are keyed by (seed, env_id_offset + i), so
- * results do not depend on how the batch is split. */
+ * results do not depend on how the batch is split.
+ * The robot decides the kernels: one body on an x-y-z ball joint with 8 tendons
+ * (MsjRobot) gets the specialised closed-form kernels; the same class with 1..16
+ * tendons the closed form with a run-time tendon count (env-per-lane only); any
+ * other joint tree (up to 32 joints / 64 tendons) the generic one-env-per-wave kernel. */
 int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator,
               double step_size, int n_substeps, int device, uint64_t seed,
               int64_t env_id_offset, rb_sim **out);

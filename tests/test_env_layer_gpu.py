@@ -141,3 +141,32 @@ def test_vec_env_surface_of_stable_baselines(msj_robot):
         a.env_method("reset")
     assert a.render() is None
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("n_tendons,n,integrator", [(6, 500, "euler"), (12, 70001, "euler"), (4, 300, "rk4")])
+def test_fused_env_layer_for_other_tendon_counts(msj_robot, n_tendons, n, integrator):
+    """RoboyVecEnv over a ball-joint robot with another tendon count: the run-time-count form of the
+    fused kernel against the host replay (plain step kernel + numpy Philox + reward.py)."""
+    from test_physics_gpu import _ball_joint_robot
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    robot = _ball_joint_robot(msj_robot, n_tendons, 7)
+    seed, max_len = 2, 9
+    vec = RoboyVecEnv(robot, n, seed=seed, max_episode_length=max_len, integrator=integrator, joint_vel_penalty=True)
+    host = HostEnvModel(robot, HipStepper(robot, n, seed, integrator=integrator), n, seed, max_len, True, True, True)
+    obs0 = vec.reset()
+    host.goal = host.draw(np.ones(n, bool))
+    assert np.array_equal(obs0[:, 6:], host.goal)
+    rng = np.random.default_rng(4)
+    n_done = 0
+    for t in range(20):
+        a = rng.uniform(-1.2, 1.2, (n, n_tendons)).astype(np.float32)      # some outside the box: clamped
+        obs, rew, done, _ = vec.step(a)
+        h_obs, h_rew, h_done, margin = host.step(np.clip(a, -1, 1))
+        same = done == h_done
+        assert same.all() or (margin[~same] < 1e-5).all()
+        assert same.all()
+        assert np.array_equal(obs, h_obs.astype(np.float32))
+        np.testing.assert_allclose(rew, h_rew, rtol=2e-5, atol=2e-4)
+        n_done += int(done.sum())
+    assert n_done >= 2 * n and vec.stats()["n_episodes"] == n_done
+    vec.close(); host.stepper.close()

@@ -216,12 +216,13 @@ def test_kernel_arithmetic_general_inertia_branch_agrees_with_the_oracle(hostmat
     assert np.abs(q1 - want[0]).max() < 1e-13 and np.abs(qd1 - want[1]).max() < 1e-12
 
 
-def _random_ball_joint_robot(rng):
-    """A random robot of the ball-joint class: 8 tendons with 1-3 base via-points
+def _random_ball_joint_robot(rng, n_tendons=8):
+    """A random robot of the ball-joint class: `n_tendons` tendons with 1-3 base via-points
     and 1-3 body via-points each (constant segments on both sides), random
     inertia, COM, armature, damping, gravity direction and muscle constants."""
     from gym_roboy_amd.envs.robots import RobotDescription, msj_platform_spec
     spec = msj_platform_spec()
+    spec["tendons"] = [{"name": "motor%d" % k} for k in range(n_tendons)]
     for t in spec["tendons"]:
         base = [{"link": -1, "pos": (rng.uniform(-0.12, 0.12, 3) + [0, 0, -0.12]).tolist()} for _ in range(rng.integers(1, 4))]
         body = [{"link": 2, "pos": (rng.uniform(-0.08, 0.08, 3) + [0, 0, 0.12]).tolist()} for _ in range(rng.integers(1, 4))]
@@ -239,12 +240,15 @@ def _random_ball_joint_robot(rng):
     return RobotDescription(spec)
 
 
-@pytest.mark.parametrize("seed", range(6))
-def test_closed_form_equals_generic_tree_on_random_ball_joint_robots(hostmath_lib, seed):
+@pytest.mark.parametrize("seed,n_tendons", [(0, 8), (1, 8), (2, 8), (3, 8), (4, 8), (5, 8),
+                                            (6, 1), (7, 4), (8, 6), (9, 12), (10, 16)])
+def test_closed_form_equals_generic_tree_on_random_ball_joint_robots(hostmath_lib, seed, n_tendons):
     """msj_build.hpp's folding (moving segment, constant segments, |A|^2+|B|^2,
-    inertia about the joint centre, fast-path detection) on arbitrary geometry."""
+    inertia about the joint centre, fast-path detection) on arbitrary geometry, and for tendon
+    counts other than 8 the run-time-count form of the tendon loop (padding records inert)."""
     rng = np.random.default_rng(100 + seed)
-    desc = _random_ball_joint_robot(rng)
+    desc = _random_ball_joint_robot(rng, n_tendons)
+    assert desc.n_t == n_tendons
     oracle = TendonRobotOracle(desc)
     P = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))
     q, qd, sp = random_states(desc, 300, seed)

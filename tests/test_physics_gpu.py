@@ -30,7 +30,7 @@ def _check_step(robot, oracle, n, integrator, nsub, seed, kernel=0):
     sim = _sim(robot, n, integrator=integrator, n_substeps=nsub)
     sim.select_kernel(kernel)
     auto_limit = 8192 if integrator == "euler" else 16384
-    assert sim.info()["kernel"] == (kernel or (2 if n <= auto_limit else 1))
+    assert sim.info()["kernel"] == (kernel or (2 if n <= auto_limit and desc.n_t == 8 else 1))
     sim.set_state(q, qd)
     q1, qd1, f1 = sim.forward_step_command(sp)
     qo, qdo, fo = oracle.step(q.astype(np.float64), qd.astype(np.float64), sp.astype(np.float64),
@@ -269,6 +269,66 @@ def test_device_pointer_accessors(msj_robot):
     dev = env.sim.download(d_out, (8,), np.float64)
     assert np.array_equal(dev, np.array(list(host.values()))) and host["n_episodes"] >= 2 * 512
     env.close()
+
+
+def _ball_joint_robot(msj_robot, n_tendons, seed):
+    """A robot of the ball-joint class with another tendon count (random geometry, general inertia)."""
+    from test_oracle import _random_ball_joint_robot
+    desc = _random_ball_joint_robot(np.random.default_rng(seed), n_tendons)
+    box = type(msj_robot._ACTION_SPACE)(low=-0.3, high=0.3, shape=(n_tendons,), dtype="float32")
+
+    class Robot(type(msj_robot)):
+        _DIM_ACTION = n_tendons
+        _ACTION_SPACE = box
+
+        @classmethod
+        def get_description(cls):
+            return desc
+    return Robot()
+
+
+@pytest.mark.parametrize("n_tendons", [1, 4, 6, 12, 16])
+@pytest.mark.parametrize("integrator", ["euler", "rk4"])
+def test_ball_joint_robots_with_other_tendon_counts_keep_the_closed_form(msj_robot, n_tendons, integrator):
+    """Ball-joint robots with 1..16 tendons run the env-per-lane closed form with a run-time
+    tendon count (not the 100x slower joint-tree kernel); both launch configurations."""
+    from oracle.c_oracle import COracle
+    robot = _ball_joint_robot(msj_robot, n_tendons, 40 + n_tendons)
+    oracle = COracle(robot.get_description(), "f64")
+    for n in (1, 1000, 66000):
+        sim = _sim(robot, n, integrator=integrator)
+        info = sim.info()
+        assert info["kernel"] == KERNELS["env_per_lane"] and info["n_t"] == n_tendons
+        assert info["bytes_per_env_step"] == 4 * (12 + n_tendons + 1)
+        sim.close()
+        _check_step(robot, oracle, n, integrator, 2, seed=n_tendons, kernel=KERNELS["env_per_lane"])
+    sim = _sim(robot, 64)
+    with pytest.raises(Exception, match="8 tendons"):
+        sim.select_kernel(KERNELS["tendon_per_lane"])
+    d = sim.malloc(4 * 64 * n_tendons)
+    with pytest.raises(Exception, match="8-tendon"):
+        sim.rollout_fused_dev(d, 1, 4, 1.0)
+    sim.fill_actions_dev(d, 0)
+    sim.rollout_dev(d, 1, 20, 0.3, use_graph=True)          # the graph path works for them as well
+    sim.synchronize()
+    assert np.isfinite(sim.read_state()[0]).all()
+    sim.close()
+
+
+def test_seventeen_tendons_fall_back_to_the_tree_kernel(msj_robot):
+    from oracle.c_oracle import COracle
+    robot = _ball_joint_robot(msj_robot, 17, 3)
+    sim = _sim(robot, 10)
+    assert sim.info()["kernel"] == 3          # RB_KERNEL_ENV_PER_WAVE
+    sim.close()
+    desc = robot.get_description()
+    q, qd, sp = random_states(desc, 50, 2)
+    sim = _sim(robot, 50)
+    sim.set_state(q, qd)
+    q1, qd1, _ = sim.forward_step_command(sp)
+    qo, qdo, _ = COracle(desc, "f64").step(q.astype(np.float64), qd.astype(np.float64), sp.astype(np.float64), integrator=0)
+    assert np.abs(q1 - qo).max() < 2e-5 and np.abs(qd1 - qdo).max() < 2e-5
+    sim.close()
 
 
 def test_sharding_is_invisible(msj_robot):
