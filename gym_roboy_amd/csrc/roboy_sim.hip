@@ -3,9 +3,11 @@
 // Replaces the per-step ROS round-trip of the reference's RosSimulationClient
 // (gym_roboy/envs/simulations/ros_simulation_client.py:32-81) by kernels that
 // advance N independent environments in lock-step.  State is struct-of-arrays
-// in HBM, one env per lane (or one tendon per lane for small batches), robot
-// constants are wave-uniform and arrive through the kernarg (scalar loads ->
-// SGPRs), no LDS is needed in the env-per-lane form.  DESIGN.md §4-§5.
+// in HBM, one env per lane (or one tendon per lane for small batches, or one env
+// per wave for generic joint trees, tree_kernels.hpp), robot constants are
+// wave-uniform and arrive through the kernarg (scalar loads -> SGPRs); LDS holds
+// only what is indexed at run time (the set-points of the rolled tendon loop).
+// DESIGN.md §4-§5.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
