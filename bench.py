@@ -7,19 +7,32 @@ One "step" = one lock-step call of the batched ``forward_step_command`` = one
 kernel launch that advances every env of the rank's shard by one integrator
 step of dt = 0.1.  Actions are i.i.d. U[-1,1) from the Philox
 streams, pre-generated as a ring of 4 slabs resident in HBM and rescaled by
-0.3 in the kernel.  The default workload is BASELINE.json configs[1]
-("MsjRobot 4 096 envs, semi-implicit Euler fp32, 1 MI355X"); the other
-single-GPU configs are available through --workload and are also measured
-briefly and reported under "also" (they are not the headline).
+0.3 in the kernel.
+
+Default workload for every --gpus N: 262 144 envs per GPU, RK4 (BASELINE.json
+configs[2] at N = 1; at N = 8 the same shard size as configs[4], 2 097 152 envs
+in all).  The other single-GPU configs (4 096 envs, the Euler shard, a 2 097 152
+env batch, the upper body, the fused env layer) are measured briefly and
+reported under "also"; they are not the headline.
+
+Timing: W untimed warm-up steps, then the K-step region - bracketed by a
+barrier and a device synchronisation on both sides - is timed R times (R chosen
+so that the repeats cover >= 50 ms of device time, so a small K does not turn
+the number into a measurement of launch latency); ``ms_per_step`` is the median
+over the repeats of (max over ranks of the region's wall time) / K and ``value``
+the env steps of all ranks in one region divided by that time.
 
 N > 1: launched by torch.distributed.run, one rank per GPU; envs shard
 contiguously (weak scaling: the per-GPU batch is fixed), no data-path
-collective; every 100 steps the rank's episode statistics (8 doubles) are
-all-reduced over RCCL.  Prints ONE JSON line on rank 0.
+collective; every STATS_EVERY steps and at the end of every timed region the
+rank's episode statistics (8 doubles) are all-reduced over RCCL, and the line
+carries a ``collective`` object that audits it.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -31,33 +44,73 @@ import numpy as np  # noqa: E402
 
 WORKLOADS = {
     # name: (envs per GPU, integrator, substeps, default steps, default warmup, BASELINE.json config)
+    "msj-262144-rk4": (262144, "rk4", 1, 400, 40, "configs[2]: MsjRobot 262 144 envs per GPU, RK4 fp32 (x8 GPUs = configs[4]'s 2 097 152 envs)"),
+    "msj-262144-euler": (262144, "euler", 1, 800, 80, "configs[4] shard: MsjRobot 262 144 envs per GPU, semi-implicit Euler fp32"),
     "msj-4096-euler": (4096, "euler", 1, 4000, 200, "configs[1]: MsjRobot 4 096 envs, semi-implicit Euler fp32"),
-    "msj-262144-rk4": (262144, "rk4", 1, 400, 40, "configs[2]: MsjRobot 262 144 envs, RK4 fp32"),
-    "msj-262144-euler": (262144, "euler", 1, 1000, 100, "configs[4] shard: 262 144 envs per GPU, Euler fp32"),
-    "msj-2097152-euler": (2097152, "euler", 1, 300, 30, "large batch: 2 097 152 envs on one GPU, Euler fp32"),
+    "msj-2097152-euler": (2097152, "euler", 1, 300, 30, "large batch: MsjRobot 2 097 152 envs on one GPU, Euler fp32"),
     "upper-body-8192-euler": (8192, "euler", 1, 300, 30, "configs[3]: upper body (20 DOF / 38 tendons) 8 192 envs, Euler fp32"),
     "upper-body-8192-rk4": (8192, "rk4", 1, 100, 10, "configs[3]: upper body (20 DOF / 38 tendons) 8 192 envs, RK4 fp32"),
 }
+DEFAULT_WORKLOAD = "msj-262144-rk4"
 RING = 4
 # Steps between two all-reduces of the statistics block: one episode horizon
 # (RoboyEnv.max_episode_length = 400 env steps, roboy_env.py:23).
 STATS_EVERY = int(os.environ.get("ROBOY_BENCH_STATS_EVERY", "400"))
+MIN_TIMED_S = float(os.environ.get("ROBOY_BENCH_MIN_TIMED_S", "0.05"))   # device time the repeats must cover
+MAX_REPEATS = 256
 HBM_PEAK = 8.0e12          # B/s, spec (MI355X_MICROARCH.md "HBM3E peak BW")
 HBM_COPY = 6.29e12         # B/s, measured float4 copy (same table)
+VALU_PEAK = 157.3e12       # flop/s, fp32 vector peak (MI355X_MICROARCH.md "Peak FP32 (vector)")
+KERNEL_NAMES = {1: "msj_step_env_per_lane", 2: "msj_step_tendon_per_lane", 3: "tree_step_wave_per_env"}
+PROFILE_DIRS = ("r2_a", "r1_b")   # newest first: where the committed rocprofv3 PMC passes live
 
 
 def pmc_traffic(workload):
     """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC
-    passes (profiles/r1_b/hbm_traffic_pmc.json: separate --pmc FETCH_SIZE and
+    passes (profiles/<round>/hbm_traffic_pmc.json: separate --pmc FETCH_SIZE and
     --pmc WRITE_SIZE runs of this workload, FETCH_SIZE doubled as the gfx950
     guide prescribes).  PMC collection cannot run inside the timed bench, so the
     number is the profiled one, not a live one; None if the workload was not profiled."""
-    path = os.path.join(ROOT, "profiles", "r1_b", "hbm_traffic_pmc.json")
+    for d in PROFILE_DIRS:
+        try:
+            with open(os.path.join(ROOT, "profiles", d, "hbm_traffic_pmc.json")) as fh:
+                return json.load(fh)[workload]["hbm_bytes_per_launch"], "profiles/%s/hbm_traffic_pmc.json" % d
+        except Exception:
+            continue
+    return None, None
+
+
+def flops_per_env_step(robot_name, integrator, substeps):
+    """Floating-point operations of one env step, from the committed count of the
+    instrumented restatement (oracle/flop_count.cpp -> profiles/flops_per_env_step.json);
+    None for a robot that has not been counted."""
     try:
-        with open(path) as fh:
-            return json.load(fh)[workload]["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "flops_per_env_step.json")) as fh:
+            return json.load(fh)["%s/%s" % (robot_name, integrator)]["flops"] * substeps
     except Exception:
         return None
+
+
+def roofline(robot_name, integrator, substeps, n_envs, bytes_per_env_step, launch_s, workload=None):
+    """Both candidate roofs for one launch of the step kernel; ``bound`` names the one
+    the kernel sits closer to (the larger fraction)."""
+    nbytes = bytes_per_env_step * n_envs
+    gbps = nbytes / launch_s / 1e9
+    hbm = {"achieved": gbps, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": gbps * 1e9 / HBM_PEAK,
+           "frac_of_measured_copy_6.29TBps": gbps * 1e9 / HBM_COPY,
+           "bytes_per_env_step": bytes_per_env_step, "bytes_per_launch": nbytes}
+    flops = flops_per_env_step(robot_name, integrator, substeps)
+    valu = None
+    if flops is not None:
+        tf = flops * n_envs / launch_s / 1e12
+        valu = {"achieved": tf, "peak": VALU_PEAK / 1e12, "unit": "TFLOP/s", "frac": tf * 1e12 / VALU_PEAK,
+                "flops_per_env_step": flops, "flops_per_launch": flops * n_envs,
+                "source": "profiles/flops_per_env_step.json (instrumented restatement, oracle/flop_count.cpp)"}
+    top = valu if (valu is not None and valu["frac"] > hbm["frac"]) else hbm
+    traffic, src = pmc_traffic(workload) if workload else (None, None)
+    return {"bound": "valu" if top is valu else "hbm", "achieved": top["achieved"], "peak": top["peak"],
+            "unit": top["unit"], "frac": top["frac"], "traffic": traffic, "traffic_source": src,
+            "launch_us_events": launch_s * 1e6, "hbm": hbm, "valu": valu}
 
 
 def parse():
@@ -65,18 +118,20 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="msj-4096-euler", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=None, help="override envs per GPU")
     ap.add_argument("--substeps", type=int, default=None, help="override integrator substeps per env step")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 env-per-lane, 2 tendon-per-lane")
     ap.add_argument("--no-graph", action="store_true", help="eager per-step launches instead of hipGraph replay")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=16.0)
+    ap.add_argument("--repeats", type=int, default=None, help="fix the number of timed repeats (default: cover 50 ms)")
     return ap.parse_args()
 
 
-def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world, dist, substeps=None, kernel=0):
+def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world, dist, substeps=None, kernel=0,
+                 repeats=None):
     """Returns dict(ms_per_step, value, kernel_us, ...) for this workload."""
     from gym_roboy_amd.envs.simulations import HipBatchSimulation
     n_envs, integrator, nsub, d_steps, d_warm, label = WORKLOADS[name]
@@ -98,10 +153,10 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
     # c10d op runs on the current stream).  Measured on one MI355X (profiles/r1_b/
     # rccl_one_rank_rehearsal.log): letting the collective run concurrently on a second
     # stream (async_op=True, or an own side stream) slows the graph-replayed step kernels
-    # from 2.2 to 3.7 us per step for the whole rollout, independent of how often it runs;
-    # in line it costs its own ~20 us per call and nothing else.
+    # for the whole rollout, independent of how often it runs; in line it costs its own
+    # ~20 us per call and nothing else.
     stats_ring = [torch.zeros(8, dtype=torch.float64, device="cuda") for _ in range(2)]
-    state = {"chunk": 0, "last": stats_ring[0]}
+    state = {"chunk": 0, "last": stats_ring[0], "steps_issued": 0, "calls": 0}
     act_scale = float(robot.get_action_space().high[0])
 
     def reduce_stats():
@@ -117,56 +172,101 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
             dist.all_reduce(host)
             buf.copy_(host)
         state["last"] = buf
+        state["calls"] += 1
 
-    def rollout(k):
+    def rollout(k, final_reduce=False):
+        """k per-step launches; the statistics block is all-reduced after every full
+        STATS_EVERY-step chunk and - when asked - after the last (partial) chunk too."""
         done = 0
+        reduced = True
         while done < k:
             chunk = min(STATS_EVERY, k - done)
             sim.rollout_dev(ring.data_ptr(), RING, chunk, act_scale, use_graph=use_graph)
             done += chunk
+            state["steps_issued"] += chunk
+            reduced = False
             if dist is not None and chunk == STATS_EVERY:
                 reduce_stats()
+                reduced = True
+        if dist is not None and final_reduce and not reduced:
+            reduce_stats()
+
+    def timed_region():
+        """One K-step region between barrier + synchronize pairs.  Returns (wall seconds
+        = max over ranks, device seconds between two events on the launch stream that
+        bracket the K launches and nothing else)."""
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        done = 0
+        while done < steps:                      # rollout() with the closing event before the final reduce
+            chunk = min(STATS_EVERY, steps - done)
+            sim.rollout_dev(ring.data_ptr(), RING, chunk, act_scale, use_graph=use_graph)
+            done += chunk
+            state["steps_issued"] += chunk
+            if done == steps:
+                ev1.record(stream)
+            if dist is not None:
+                if chunk == STATS_EVERY or done == steps:
+                    reduce_stats()               # at least one per region, whatever K is
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0          # this rank: start of the region -> its work is complete
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if dist is not None:
+            t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        return wall, ev0.elapsed_time(ev1) * 1e-3
 
     # 16 untimed steps from the reset state decorrelate the envs (SURVEY §8d), then warm-up
     rollout(16)
     rollout(warmup)
-    # untimed rehearsal of the chunk sizes the timed region will use, so that no
-    # hipGraph is captured / instantiated inside it (graphs are cached per chunk size)
-    rollout(min(steps, STATS_EVERY))
-    if steps > STATS_EVERY and steps % STATS_EVERY:
-        rollout(steps % STATS_EVERY)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    rollout(steps)
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    # untimed rehearsal of the timed region, so that no hipGraph is captured / instantiated
+    # inside it (graphs are cached per chunk size) and RCCL's first call is behind us
+    first_wall, first_dev = timed_region()
+    if repeats is None:
+        # cover >= MIN_TIMED_S of device time; same R on every rank (first_wall is the max over ranks)
+        repeats = max(3, min(MAX_REPEATS, int(np.ceil(MIN_TIMED_S / max(first_wall, 1e-6)))))
+    walls, devs = [], []
+    for _ in range(repeats):
+        w, d = timed_region()
+        walls.append(w)
+        devs.append(d)
+    wall = statistics.median(walls)
+    launch_s = statistics.median(devs) / steps   # HIP events on the launch stream, per launch
     q, qd, feas = sim.read_state()
     info = sim.info()
+    # audit of the collective: the all-reduced block's slot 6 is the sum over ranks of the
+    # env steps each rank has issued since its simulation was created
+    collective = None
+    if dist is not None:
+        last = [float(x) for x in state["last"].cpu()]
+        expected = float(world) * n_envs * state["steps_issued"]
+        collective = {"backend": "rccl (torch.distributed 'nccl')" if dist.get_backend() == "nccl" else dist.get_backend(),
+                      "world_size": dist.get_world_size(), "allreduce_calls": state["calls"],
+                      "payload_bytes": 64, "every_steps": STATS_EVERY,
+                      "n_env_steps_allreduced": last[6], "expected": expected,
+                      "ok": last[6] == expected and dist.get_world_size() == world}
+    stats = [float(x) for x in state["last"].cpu()]
     sim.close()
-    bytes_per_launch = info["bytes_per_env_step"] * n_envs
-    launch_s = dev_ms * 1e-3 / steps            # HIP events on the launch stream, per launch
+    robot_name = type(robot).__name__
     return {
         "workload": name, "label": label, "envs_per_gpu": n_envs, "integrator": integrator,
-        "substeps": nsub, "steps": steps, "warmup": warmup,
+        "substeps": nsub, "steps": steps, "warmup": warmup, "repeats": repeats,
         "value": world * n_envs * steps / wall, "ms_per_step": wall * 1e3 / steps,
-        "launch_us_events": launch_s * 1e6, "bytes_per_launch": bytes_per_launch,
-        "achieved_GBps": bytes_per_launch / launch_s / 1e9,
-        "kernel": {1: "msj_step_env_per_lane", 2: "msj_step_tendon_per_lane", 3: "tree_step_wave_per_env"}[info["kernel"]],
-        "stats": [float(x) for x in state["last"].cpu()],
+        "ms_per_step_min": min(walls) * 1e3 / steps, "ms_per_step_max": max(walls) * 1e3 / steps,
+        "timed_device_ms": sum(devs) * 1e3,
+        "launch_us_events": launch_s * 1e6,
+        "roofline": roofline(robot_name, integrator, nsub, n_envs, info["bytes_per_env_step"], launch_s,
+                             name if envs is None and substeps is None else None),
+        "kernel": KERNEL_NAMES[info["kernel"]],
+        "stats": stats, "collective": collective,
         "finite": bool(np.isfinite(q).all() and np.isfinite(qd).all()),
         "feasible_frac": float(feas.mean()),
     }
@@ -196,11 +296,14 @@ def run_fused_env(torch, robot, n_envs, steps=300, warmup=30):
     wall = time.perf_counter() - t0
     us = e0.elapsed_time(e1) * 1e3 / steps
     bytes_per = 4 * (4 * env.n_q + env.n_t + 1) + 4 * (3 * env.n_q + env.n_q + 6)   # + obs, goal, counter x2, return x2, reward, done
+    finite = bool(torch.isfinite(obs).all().item() and torch.isfinite(rew).all().item())
+    q, qd, feas = env.sim.read_state()
     env.close()
-    return {"workload": "fused-env-%d" % n_envs, "label": "fused env layer (RoboyVecEnv.step), %d envs, Euler fp32" % n_envs,
-            "value": n_envs * steps / wall, "ms_per_step": wall * 1e3 / steps, "launch_us_events": us,
-            "achieved_GBps": n_envs * bytes_per / us / 1e3, "steps": steps, "bytes_per_env_step": bytes_per,
-            "frac_of_hbm_peak": n_envs * bytes_per / us / 1e3 * 1e9 / HBM_PEAK}
+    name = "fused-env-%d" % n_envs
+    return {"workload": name, "label": "fused env layer (RoboyVecEnv.step), %d envs, Euler fp32" % n_envs,
+            "value": n_envs * steps / wall, "ms_per_step": wall * 1e3 / steps, "launch_us_events": us, "steps": steps,
+            "roofline": roofline(type(robot).__name__, "euler", 1, n_envs, bytes_per, us * 1e-6, name),
+            "finite": finite and bool(np.isfinite(q).all() and np.isfinite(qd).all()), "feasible_frac": float(feas.mean())}
 
 
 def run_fused_rollout(torch, robot, n_envs, steps_per_launch=100, launches=20):
@@ -225,20 +328,67 @@ def run_fused_rollout(torch, robot, n_envs, steps_per_launch=100, launches=20):
     wall = time.perf_counter() - t0
     steps = steps_per_launch * launches
     us = e0.elapsed_time(e1) * 1e3 / steps
-    q, _, _ = sim.read_state()
+    q, qd, feas = sim.read_state()
     sim.close()
     return {"workload": "fused-rollout-%d" % n_envs,
             "label": "open-loop rollout, %d steps fused per launch, %d envs, Euler fp32 (not the per-step contract)"
                      % (steps_per_launch, n_envs),
             "value": n_envs * steps / wall, "ms_per_step": wall * 1e3 / steps, "us_per_step_events": us,
-            "steps": steps, "bytes_per_env_step": 4 * sim.n_t, "finite": bool(np.isfinite(q).all())}
+            "steps": steps, "bytes_per_env_step": 4 * sim.n_t,
+            "finite": bool(np.isfinite(q).all() and np.isfinite(qd).all()), "feasible_frac": float(feas.mean())}
+
+
+_PY_ENV_WORKER = r"""
+import contextlib, io, sys, time
+sys.path.insert(0, %(root)r)
+import numpy as np
+from gym_roboy_amd.envs import RoboyEnv
+from gym_roboy_amd.envs.robots import MsjRobot
+from oracle.cpu_simulation_client import CpuSimulationClient
+from oracle import philox_np as ph
+rank = int(sys.argv[1]); seconds = float(sys.argv[2])
+robot = MsjRobot()
+acts = [a for a in ph.actions(0, np.arange(256, dtype=np.uint64) + 256 * rank, 0, 8)]
+with contextlib.redirect_stdout(io.StringIO()):
+    env = RoboyEnv(simulation_client=CpuSimulationClient(robot), seed=rank)
+    env.reset()
+    t0 = time.perf_counter(); k = 0
+    while time.perf_counter() - t0 < seconds:
+        if env.step(acts[k %% 256])[2]:
+            env.reset()
+        k += 1
+    dt = time.perf_counter() - t0
+sys.stdout.write("%%d %%.6f\n" %% (k, dt))
+"""
+
+
+def cpu_python_env_loop(num_cpu, seconds):
+    """The reference's own architecture (train_parallel.py:19-29): num_cpu OS processes,
+    one Python RoboyEnv each, stepping its own simulator - here the oracle-backed
+    CpuSimulationClient in place of the absent ROS/CARDSflow instance.  Children are
+    plain `python -c` processes started before this process has touched the GPU."""
+    code = _PY_ENV_WORKER % {"root": ROOT}
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r + 1), str(seconds)], stdout=subprocess.PIPE,
+                              stderr=subprocess.DEVNULL, text=True, env=env) for r in range(num_cpu)]
+    total, per = 0.0, []
+    for p in procs:
+        out, _ = p.communicate(timeout=seconds * 10 + 120)
+        if p.returncode == 0 and out.strip():
+            k, dt = out.split()
+            per.append(int(k) / float(dt))
+            total += int(k) / float(dt)
+    return {"value": total, "processes": len(per), "per_process": (total / len(per)) if per else None,
+            "seconds_each": seconds}
 
 
 def cpu_baseline(robot, seconds, name):
-    """The C restatement of the same step (oracle/roboy_oracle.c, fp32 build)
-    timed on this box's host cores on a bounded sample of the workload: first
-    one thread (the scalar port), then OpenMP over envs on up to 64 cores with
-    a sample large enough (>= 256 envs per thread) for the threads to pay off."""
+    """The C restatement of the same step (oracle/roboy_oracle.c, fp32 build) timed on this
+    box's host cores on a bounded sample of the workload: one thread (the
+    scalar port), 64 threads and every core the process may run on (OpenMP over envs; the
+    sample is large enough - >= 256 envs per thread - for the threads to pay off); the best of
+    them is `value`.  Then the reference's architecture: one Python RoboyEnv per process x num_cpu
+    processes.  Runs before the GPU is touched."""
     from oracle.c_oracle import COracle
     from oracle import philox_np as ph
     n_envs, integrator, nsub, *_ = WORKLOADS[name]
@@ -247,9 +397,11 @@ def cpu_baseline(robot, seconds, name):
     integ = 0 if integrator == "euler" else 1
     small = desc.n_q <= 3
     cores_avail = len(os.sched_getaffinity(0))
+    thread_counts = sorted({1, min(cores_avail, 64), cores_avail})
+    budget = seconds * 0.6 / len(thread_counts)
     out = {}
-    for threads in sorted({1, min(cores_avail, 64)}):
-        n = min(n_envs, 4096 if small else 512) if threads == 1 else min(max(n_envs, 256 * threads), 65536 if small else 16384)
+    for threads in thread_counts:
+        n = min(n_envs, 4096 if small else 512) if threads == 1 else min(max(n_envs, 256 * threads), 262144 if small else 16384)
         ids = np.arange(n, dtype=np.uint64)
         slabs = [np.ascontiguousarray(ph.actions(0, ids, r, desc.n_t) * np.float32(0.3)) for r in range(RING)]
         q = np.zeros((n, desc.n_q), np.float32)
@@ -257,7 +409,6 @@ def cpu_baseline(robot, seconds, name):
         feas = np.zeros(n, np.uint8)
         for t in range(4):
             orc.step_inplace(q, qd, slabs[t % RING], feas, integrator=integ, n_substeps=nsub, threads=threads)
-        budget = seconds / 2
         t0 = time.perf_counter()
         k = 0
         while time.perf_counter() - t0 < budget:
@@ -265,33 +416,28 @@ def cpu_baseline(robot, seconds, name):
             k += 1
         out[threads] = (n * k / (time.perf_counter() - t0), k, n)
     best = max(out, key=lambda th: out[th][0])
-    # the reference's architecture: one Python RoboyEnv per env (train_parallel.py:19-29), one core
     py_loop = None
     if small:
-        from gym_roboy_amd.envs import RoboyEnv
-        from oracle.cpu_simulation_client import CpuSimulationClient
-        import contextlib
-        import io
-        acts = [a for a in ph.actions(0, np.arange(256, dtype=np.uint64), 0, desc.n_t)]
-        # RoboyEnv prints a banner whenever a goal is reached (also while it
-        # derives its reward range): keep stdout to the one JSON line
-        with contextlib.redirect_stdout(io.StringIO()):
-            env = RoboyEnv(simulation_client=CpuSimulationClient(robot))
-            env.reset()
-            t0 = time.perf_counter()
-            k = 0
-            while time.perf_counter() - t0 < 2.0:
-                if env.step(acts[k % 256])[2]:
-                    env.reset()
-                k += 1
-        py_loop = k / (time.perf_counter() - t0)
+        num_cpu = min(cores_avail, 32)
+        py_loop = cpu_python_env_loop(num_cpu, max(2.0, seconds * 0.25))
+        py_loop["cores"] = num_cpu
+        py_loop["what"] = ("RoboyEnv.step (Python, one env per process x %d processes, Euler) over the oracle-backed "
+                           "CpuSimulationClient: the reference's architecture, train_parallel.py:19-29" % num_cpu)
     return {
         "value": out[best][0], "unit": "env-steps/s", "cores": best, "kind": "port",
         "sample": "%d envs x %d steps of %s, C fp32 restatement (oracle/roboy_oracle.c), %s"
                   % (out[best][2], out[best][1], name, "OpenMP over envs" if best > 1 else "one thread"),
+        "by_threads": {str(th): {"value": out[th][0], "envs": out[th][2], "steps": out[th][1]} for th in thread_counts},
         "value_1_core": out[1][0], "host_cores_available": cores_avail,
-        "python_env_loop_1_core": py_loop,   # RoboyEnv.step over the oracle-backed client, per process
+        "python_env_processes": py_loop,
     }
+
+
+def brief(r):
+    """An `also` entry: the workload's own numbers with both roofline fractions and the sanity fields."""
+    keep = ("workload", "label", "value", "ms_per_step", "launch_us_events", "steps", "repeats", "kernel",
+            "roofline", "finite", "feasible_frac", "us_per_step_events", "bytes_per_env_step")
+    return {k: r[k] for k in keep if k in r}
 
 
 def main():
@@ -310,6 +456,14 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
                          "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    from gym_roboy_amd.envs.robots import MsjRobot, UpperBodyRobot
+    robot = UpperBodyRobot() if args.workload.startswith("upper-body") else MsjRobot()
+    # CPU baseline first: its Python env workers are separate processes, started while this
+    # process has not initialised the GPU yet (rank 0 at N = 1 only)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(robot, args.cpu_seconds, args.workload)
+
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the physics step)")
@@ -329,65 +483,61 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    from gym_roboy_amd.envs.robots import MsjRobot, UpperBodyRobot
-    robot = UpperBodyRobot() if args.workload.startswith("upper-body") else MsjRobot()
     use_graph = not args.no_graph
     also = []
     # stream capture is not allowed on the legacy default stream: run on a side stream
     with torch.cuda.stream(torch.cuda.Stream()):
         head = run_workload(torch, robot, args.workload, args.steps, args.warmup, args.envs, use_graph,
-                            rank, world, dist, args.substeps, args.kernel)
+                            rank, world, dist, args.substeps, args.kernel, args.repeats)
         if world == 1 and not args.no_also:
-            for name in ("msj-262144-rk4", "msj-2097152-euler", "upper-body-8192-euler"):
+            for name in ("msj-4096-euler", "msj-262144-euler", "msj-262144-rk4", "msj-2097152-euler",
+                         "upper-body-8192-euler", "upper-body-8192-rk4"):
                 if name != args.workload:
                     rob = UpperBodyRobot() if name.startswith("upper-body") else MsjRobot()
-                    r = run_workload(torch, rob, name, None, None, None, use_graph, rank, world, dist)
-                    also.append({k: r[k] for k in ("workload", "label", "value", "ms_per_step", "launch_us_events",
-                                                   "achieved_GBps", "steps")} |
-                                {"frac_of_hbm_peak": r["achieved_GBps"] * 1e9 / HBM_PEAK})
-            also.append(run_fused_env(torch, MsjRobot(), 2097152))
+                    also.append(brief(run_workload(torch, rob, name, None, None, None, use_graph, rank, world, dist)))
+            also.append(brief(run_fused_env(torch, MsjRobot(), 2097152)))
             for n_fused in (4096, 2097152):
-                also.append(run_fused_rollout(torch, MsjRobot(), n_fused))
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(robot, args.cpu_seconds, args.workload)
+                also.append(brief(run_fused_rollout(torch, MsjRobot(), n_fused)))
 
+    rc = 0
     if rank == 0:
         line = {
             "metric": "env-steps/sec, MsjRobot (3-DOF/8-tendon) batched rollout" if type(robot).__name__ == "MsjRobot"
                       else "env-steps/sec, %s batched rollout" % type(robot).__name__,
             "value": head["value"], "unit": "env-steps/s",
-            "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"],
+            "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"], "repeats": head["repeats"],
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": head["label"], "robot": type(robot).__name__, "envs_per_gpu": head["envs_per_gpu"],
                        "total_envs": head["envs_per_gpu"] * world, "integrator": head["integrator"],
                        "substeps": head["substeps"], "step_size": 0.1,
                        "launch": "hipGraph replay of per-step kernels" if use_graph else "eager per-step launches",
-                       "parallelism": "env shards x%d, RCCL all-reduce of episode statistics every %d steps"
-                                      % (world, STATS_EVERY) if world > 1 else "single GPU"},
-            "roofline": {
-                "bound": "hbm", "achieved": head["achieved_GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": head["achieved_GBps"] * 1e9 / HBM_PEAK,
-                "traffic": pmc_traffic(args.workload) if args.envs is None and args.substeps is None else None,
-                "traffic_source": "rocprofv3 --pmc passes committed in profiles/r1_b/hbm_traffic_pmc.json (bytes per launch)",
-                "kernel": head["kernel"], "bytes_per_env_step": head["bytes_per_launch"] // head["envs_per_gpu"],
-                "bytes_per_launch": head["bytes_per_launch"], "launch_us_events": head["launch_us_events"],
-                "note": "events bracket the whole timed region on the launch stream, so the per-launch "
-                        "time includes the kernel boundary; rocprofv3 kernel-only time is in profiles/",
-                "launch_floor_us": {"empty_kernel_graph_node": 1.61, "load_store_only_graph_node": 2.16,
-                                    "source": "profiles/r1_b/graph_floor.log (tools/graph_floor.hip), 4 096-env grid"}
-                                   if head["envs_per_gpu"] == 4096 else None,
-            },
+                       "parallelism": ("env shards x%d, RCCL all-reduce of episode statistics every %d steps and at the "
+                                       "end of every timed region" % (world, STATS_EVERY)) if world > 1 else "single GPU",
+                       "timing": "median of %d repeats of the %d-step region (barrier + synchronize on both sides, "
+                                 "max over ranks); %.1f ms of device time in all"
+                                 % (head["repeats"], head["steps"], head["timed_device_ms"])},
+            "ms_per_step_spread": [head["ms_per_step_min"], head["ms_per_step_max"]],
+            "roofline": dict(head["roofline"], kernel=head["kernel"],
+                             note="launch_us_events = HIP events on the launch stream around the K per-step launches "
+                                  "of a region, median over the repeats, / K: kernel + kernel boundary; "
+                                  "rocprofv3 kernel-only averages are in profiles/"),
             "cpu_baseline": cpu,
+            "collective": head["collective"],
             "also": also,
             "sanity": {"finite": head["finite"], "feasible_frac": head["feasible_frac"],
                        "allreduced_stats": head["stats"]},
         }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
+        if head["collective"] is not None and not head["collective"]["ok"]:
+            sys.stderr.write("bench.py: the all-reduced env-step count %r does not match world x envs x steps = %r\n"
+                             % (head["collective"]["n_env_steps_allreduced"], head["collective"]["expected"]))
+            rc = 3
     if dist is not None:
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -76,6 +76,7 @@ SIGNATURES = {
     "rb_sample_goals_dev": (ctypes.c_int, [_sim, _vp, _vp]),
     "rb_env_configure": (ctypes.c_int, [_sim, ctypes.POINTER(EnvConfig)]),
     "rb_env_reset_dev": (ctypes.c_int, [_sim, _vp]),
+    "rb_env_set_goal": (ctypes.c_int, [_sim, _fp, _u32p]),
     "rb_env_step_dev": (ctypes.c_int, [_sim, _vp, _vp, _vp, _vp]),
     "rb_env_stats": (ctypes.c_int, [_sim, ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
     "rb_env_stats_dev": (ctypes.c_int, [_sim, _vp, ctypes.c_int]),

@@ -315,7 +315,7 @@ msj_env_step_kernel(const CONST c, const EnvParams e, const GoalBox box,
                     float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
                     uint32_t *__restrict__ goal_count, const float *__restrict__ act,
                     float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
-                    float *__restrict__ ep_acc, uint32_t *__restrict__ infeas_n,
+                    double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt, uint32_t *__restrict__ infeas_n,
                     long n, uint64_t seed, uint64_t env0) {
     const long i = long(blockIdx.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -374,10 +374,11 @@ msj_env_step_kernel(const CONST c, const EnvParams e, const GoalBox box,
     if (!ok) infeas_n[i] += 1u;
     if (dn) {
         // per-env episode accumulators, touched only when an episode ends;
-        // rb_env_stats reduces them (no atomics in the step kernel)
-        float *acc = ep_acc + i;
-        acc[0 * n] += ret; acc[1 * n] += ret * ret; acc[2 * n] += 1.0f;
-        acc[3 * n] += float(sn - 1u); acc[4 * n] += reached ? 1.0f : 0.0f;
+        // rb_env_stats reduces them (no atomics in the step kernel).  Sums of returns
+        // in fp64 (a return carries the +1000 bonus, its square overflows fp32's 24 bits
+        // after a few episodes), counts as integers (fp32 counters stop at 2^24)
+        ep_sum[i] += double(ret); ep_sum[n + i] += double(ret) * double(ret);
+        ep_cnt[i] += 1u; ep_cnt[n + i] += sn - 1u; ep_cnt[2 * n + i] += reached ? 1u : 0u;
         const uint64_t gid = env0 + uint64_t(i);
         uint32_t draw = goal_count[i];
         draw_goal3(box, seed, gid, draw++, gg);          // RoboyEnv.step: _set_new_goal (:67-68)
@@ -408,14 +409,15 @@ msj_env_step_kernel(const CONST c, const EnvParams e, const GoalBox box,
 // rb_env_stats: block-reduce the per-env accumulators in fp64, one atomic per
 // block and statistic (runs once per reporting interval, not per step)
 __global__ void __launch_bounds__(256)
-stats_reduce_kernel(const float *ep_acc, const float *ep_ret, const uint32_t *infeas_n,
+stats_reduce_kernel(const double *ep_sum, const uint32_t *ep_cnt, const float *ep_ret, const uint32_t *infeas_n,
                     const uint32_t *feas, double *out, double env_steps, long n) {
     __shared__ double sh[4][7];
     double v[7] = {0, 0, 0, 0, 0, 0, 0};
     for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n; i += long(gridDim.x) * 256) {
-        if (ep_acc) {
+        if (ep_sum) {
+            v[0] += ep_sum[i]; v[1] += ep_sum[n + i];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) v[k] += double(ep_acc[k * n + i]);
+            for (int k = 0; k < 3; ++k) v[2 + k] += double(ep_cnt[k * n + i]);
             v[6] += double(ep_ret[i]);
             v[5] += double(infeas_n[i]);     // env layer: infeasible env-steps since the reset
         } else {
@@ -486,7 +488,9 @@ struct rb_sim {
     // fused env layer (rb_env_*)
     bool env_ready = false;
     EnvParams env;
-    float *d_goal = nullptr, *d_ep_ret = nullptr, *d_ep_acc = nullptr;   // ep_acc: [5][n]
+    float *d_goal = nullptr, *d_ep_ret = nullptr;
+    double *d_ep_sum = nullptr;      // [2][n]: sum of episode returns, sum of squared returns
+    uint32_t *d_ep_cnt = nullptr;    // [3][n]: episodes, summed episode length, goals reached
     uint32_t *d_step_num = nullptr, *d_infeas_n = nullptr;
     double *d_stats = nullptr;   // [8] scratch of the reduction
     double env_steps = 0.0;      // env steps issued since the statistics were reset
@@ -696,7 +700,7 @@ void rb_destroy(rb_sim *s) {
     (void)hipFree(s->d_goal_count); (void)hipFree(s->d_rows); (void)hipFree(s->d_u8); (void)hipFree(s->d_ten);
     (void)hipFree(s->d_tree_ints);   // d_tree_floats points into the same allocation
     (void)hipFree(s->d_state_rows); (void)hipHostFree(s->h_state_rows);
-    (void)hipFree(s->d_goal); (void)hipFree(s->d_ep_ret); (void)hipFree(s->d_ep_acc);
+    (void)hipFree(s->d_goal); (void)hipFree(s->d_ep_ret); (void)hipFree(s->d_ep_sum); (void)hipFree(s->d_ep_cnt);
     (void)hipFree(s->d_step_num); (void)hipFree(s->d_infeas_n); (void)hipFree(s->d_stats);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     delete s;
@@ -732,7 +736,8 @@ int rb_select_kernel(rb_sim *s, int kernel) {
     s->kernel = kernel != RB_KERNEL_AUTO ? kernel
                 : (s->n <= (s->integrator == RB_EULER ? RB_TENDON_LANE_BATCH_EULER : RB_TENDON_LANE_BATCH_RK4)
                        ? RB_KERNEL_TENDON_PER_LANE : RB_KERNEL_ENV_PER_LANE);
-    // graphs captured with the other variant must not be replayed
+    // graphs captured with the other variant must not be replayed (and none may be in flight when destroyed)
+    if (!s->graphs.empty()) { RB_HIP(hipSetDevice(s->device)); RB_HIP(hipStreamSynchronize(s->stream)); }
     for (auto &kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     s->graphs.clear();
     return RB_OK;
@@ -869,6 +874,7 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
             (void)hipGraphDestroy(graph);
             if (e != hipSuccess) return fail(RB_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
             if (s->graphs.size() >= 16) {   // bound the cache: callers that keep changing slabs get re-captures, not a leak
+                RB_HIP(hipStreamSynchronize(s->stream));   // a cached exec may still be in flight (launched by an earlier chunk)
                 for (auto &kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
                 s->graphs.clear();
             }
@@ -944,9 +950,11 @@ int rb_env_configure(rb_sim *s, const rb_env_config *cfg) {
         RB_HIP(hipMalloc(&s->d_goal, plane * s->n_q));
         RB_HIP(hipMalloc(&s->d_ep_ret, plane));
         RB_HIP(hipMalloc(&s->d_step_num, sizeof(uint32_t) * size_t(s->n)));
-        RB_HIP(hipMalloc(&s->d_ep_acc, plane * 5));
+        RB_HIP(hipMalloc(&s->d_ep_sum, sizeof(double) * size_t(s->n) * 2));
+        RB_HIP(hipMalloc(&s->d_ep_cnt, sizeof(uint32_t) * size_t(s->n) * 3));
     }
-    RB_HIP(hipMemsetAsync(s->d_ep_acc, 0, sizeof(float) * size_t(s->n) * 5, s->stream));
+    RB_HIP(hipMemsetAsync(s->d_ep_sum, 0, sizeof(double) * size_t(s->n) * 2, s->stream));
+    RB_HIP(hipMemsetAsync(s->d_ep_cnt, 0, sizeof(uint32_t) * size_t(s->n) * 3, s->stream));
     RB_HIP(hipMemsetAsync(s->d_infeas_n, 0, sizeof(uint32_t) * size_t(s->n), s->stream));
     s->env_steps = 0.0;
     s->env_ready = true;
@@ -969,6 +977,20 @@ int rb_env_reset_dev(rb_sim *s, float *d_obs) {
     return RB_OK;
 }
 
+int rb_env_set_goal(rb_sim *s, const float *goal_q, const uint32_t *step_num) {
+    if (check(s) || !goal_q) return fail(RB_EINVAL, "null argument");
+    RB_HIP(hipSetDevice(s->device));
+    if (!s->env_ready) return fail(RB_EINVAL, "rb_env_configure has not been called");
+    const long n = s->n;
+    RB_HIP(hipMemcpyAsync(s->d_rows, goal_q, sizeof(float) * n * s->n_q, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s->stream, s->d_rows, s->d_goal, s->n_q, n);
+    RB_HIP(hipGetLastError());
+    if (step_num)
+        RB_HIP(hipMemcpyAsync(s->d_step_num, step_num, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s->stream));
+    RB_HIP(hipStreamSynchronize(s->stream));
+    return RB_OK;
+}
+
 int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward, uint32_t *d_done) {
     if (check(s) || !d_act || !d_obs || !d_reward || !d_done) return fail(RB_EINVAL, "null argument");
     RB_HIP(hipSetDevice(s->device));
@@ -980,7 +1002,7 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
 #define RB_TREE_ENV_LAUNCH(INTEG)                                                                          \
     hipLaunchKernelGGL((rbt::tree_env_step_wave_per_env<INTEG>), dim3(unsigned((n + rbt::TREE_WAVES - 1) / rbt::TREE_WAVES)), dim3(64 * rbt::TREE_WAVES), lds, s->stream, \
                        s->tree_host.dev, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, \
-                       s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done, s->d_ep_acc, s->d_infeas_n, \
+                       s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done, s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, \
                        n, s->seed, uint64_t(s->env0))
         if (s->integrator == RB_EULER) RB_TREE_ENV_LAUNCH(0); else RB_TREE_ENV_LAUNCH(1);
 #undef RB_TREE_ENV_LAUNCH
@@ -991,14 +1013,14 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
 #define RB_ENV_LAUNCH(INTEG, B, U)                                                                       \
     hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, U>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream, \
                        s->c8, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num,      \
-                       s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done, s->d_ep_acc,       \
-                       s->d_infeas_n, n,                                                                \
+                       s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done, s->d_ep_sum,       \
+                       s->d_ep_cnt, s->d_infeas_n, n,                                                   \
                        s->seed, uint64_t(s->env0))
 #define RB_ENV_LAUNCH_NT(INTEG, B)                                                                       \
     hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, 0, ConstX>), dim3(blocks_for(n, B)), dim3(B), 0,   \
                        s->stream, s->cx, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal,          \
                        s->d_step_num, s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done,      \
-                       s->d_ep_acc, s->d_infeas_n, n, s->seed, uint64_t(s->env0))
+                       s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, n, s->seed, uint64_t(s->env0))
     if (s->ntx) {
         if (n <= RB_SMALL_BATCH) { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_NT(0, 64); else RB_ENV_LAUNCH_NT(1, 64); }
         else                     { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_NT(0, 256); else RB_ENV_LAUNCH_NT(1, 256); }
@@ -1017,14 +1039,17 @@ static int stats_launch(rb_sim *s, int reset) {
     unsigned g = blocks_for(s->n, 256);
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL(stats_reduce_kernel, dim3(g), dim3(256), 0, s->stream,
-                       s->env_ready ? s->d_ep_acc : nullptr, s->d_ep_ret, s->d_infeas_n, s->d_feas, s->d_stats,
+                       s->env_ready ? s->d_ep_sum : nullptr, s->d_ep_cnt, s->d_ep_ret, s->d_infeas_n, s->d_feas, s->d_stats,
                        s->env_steps, s->n);
     RB_HIP(hipGetLastError());
     (void)reset;
     return RB_OK;
 }
 static int stats_reset(rb_sim *s) {
-    if (s->env_ready) RB_HIP(hipMemsetAsync(s->d_ep_acc, 0, sizeof(float) * size_t(s->n) * 5, s->stream));
+    if (s->env_ready) {
+        RB_HIP(hipMemsetAsync(s->d_ep_sum, 0, sizeof(double) * size_t(s->n) * 2, s->stream));
+        RB_HIP(hipMemsetAsync(s->d_ep_cnt, 0, sizeof(uint32_t) * size_t(s->n) * 3, s->stream));
+    }
     RB_HIP(hipMemsetAsync(s->d_infeas_n, 0, sizeof(uint32_t) * size_t(s->n), s->stream));
     s->env_steps = 0.0;
     return RB_OK;
@@ -1057,17 +1082,20 @@ int rb_malloc(rb_sim *s, int64_t bytes, void **d_ptr) {
 }
 int rb_free(rb_sim *s, void *d_ptr) {
     if (check(s)) return RB_EINVAL;
+    RB_HIP(hipSetDevice(s->device));
     RB_HIP(hipFree(d_ptr));
     return RB_OK;
 }
 int rb_memcpy_h2d(rb_sim *s, void *d_dst, const void *h_src, int64_t bytes) {
     if (check(s) || !d_dst || !h_src) return fail(RB_EINVAL, "null argument");
+    RB_HIP(hipSetDevice(s->device));
     RB_HIP(hipMemcpyAsync(d_dst, h_src, size_t(bytes), hipMemcpyHostToDevice, s->stream));
     RB_HIP(hipStreamSynchronize(s->stream));
     return RB_OK;
 }
 int rb_memcpy_d2h(rb_sim *s, void *h_dst, const void *d_src, int64_t bytes) {
     if (check(s) || !h_dst || !d_src) return fail(RB_EINVAL, "null argument");
+    RB_HIP(hipSetDevice(s->device));
     RB_HIP(hipMemcpyAsync(h_dst, d_src, size_t(bytes), hipMemcpyDeviceToHost, s->stream));
     RB_HIP(hipStreamSynchronize(s->stream));
     return RB_OK;

@@ -575,7 +575,7 @@ tree_env_step_wave_per_env(const TreeDev tg, const rbe::EnvParams ep, const rbe:
                            float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
                            uint32_t *__restrict__ goal_count, const float *__restrict__ act,
                            float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
-                           float *__restrict__ ep_acc, uint32_t *__restrict__ infeas_n,
+                           double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt, uint32_t *__restrict__ infeas_n,
                            long n, uint64_t seed, uint64_t env0) {
     extern __shared__ float4 lds_raw4[];
     float *lds_raw = reinterpret_cast<float *>(lds_raw4);
@@ -613,8 +613,8 @@ tree_env_step_wave_per_env(const TreeDev tg, const rbe::EnvParams ep, const rbe:
         };
         gj = draw_goal(draw++);                       // RoboyEnv.step: _set_new_goal (:67-68)
         if (lane == 0) {
-            ep_acc[0 * n + e] += ret; ep_acc[1 * n + e] += ret * ret; ep_acc[2 * n + e] += 1.0f;
-            ep_acc[3 * n + e] += float(sn - 1u); ep_acc[4 * n + e] += reached ? 1.0f : 0.0f;
+            ep_sum[e] += double(ret); ep_sum[n + e] += double(ret) * double(ret);
+            ep_cnt[e] += 1u; ep_cnt[n + e] += sn - 1u; ep_cnt[2 * n + e] += reached ? 1u : 0u;
         }
         if (ep.auto_reset) {                          // VecEnv worker: env.reset() (:82-87)
             gj = draw_goal(draw++);

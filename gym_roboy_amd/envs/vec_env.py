@@ -80,6 +80,19 @@ class RoboyVecEnv:
         self.sim.synchronize()
         return self.sim.download(self._d_obs, (self.num_envs, 3 * self.n_q))
 
+    def set_goal(self, goal_q, step_num=None):
+        """Overwrite every env's goal ``[N, n_q]`` (and episode step counter ``[N]``): the
+        batched form of assigning ``RoboyEnv._goal_state`` / ``.step_num`` as the reference's
+        tests do (``gym_roboy/envs/tests/test_roboy_env.py:62-66,172-176``)."""
+        g = nat.as_f32(goal_q, (self.num_envs, self.n_q), "goal_q")
+        sn = None
+        if step_num is not None:
+            sn = np.ascontiguousarray(step_num, dtype=np.uint32)
+            if sn.shape != (self.num_envs,):
+                raise ValueError("step_num must have shape (%d,)" % self.num_envs)
+        nat.check(self.sim._lib.rb_env_set_goal(
+            self.sim.handle, nat.fptr(g), None if sn is None else sn.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
+
     def step(self, actions):
         if _is_cuda_tensor(actions):
             return self._step_torch(actions)

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define RB_ABI_VERSION 1
+#define RB_ABI_VERSION 2
 
 enum rb_status {
     RB_OK = 0,
@@ -181,6 +181,12 @@ int rb_sample_goals_dev(rb_sim *sim, const uint8_t *d_mask, float *d_goal_q /* [
 /* ---- fused env layer (next row of the scope table) ---- */
 int rb_env_configure(rb_sim *sim, const rb_env_config *cfg);
 int rb_env_reset_dev(rb_sim *sim, float *d_obs /* [n_envs][3 n_q] */);
+/* Host-buffer entry (synchronous): overwrite every env's goal ([n_envs][n_q]) and,
+ * if step_num is not NULL, its episode step counter - what assigning
+ * RoboyEnv._goal_state / .step_num does in the reference's own tests
+ * (gym_roboy/envs/tests/test_roboy_env.py:62-66,172-176); lets a caller replay recorded
+ * (state, goal, counter) triples through rb_env_step_dev. */
+int rb_env_set_goal(rb_sim *sim, const float *goal_q, const uint32_t *step_num /* [n_envs] or NULL */);
 int rb_env_step_dev(rb_sim *sim, const float *d_act /* [n_envs][n_t] in [-1,1] */,
                     float *d_obs, float *d_reward, uint32_t *d_done);
 /* episode statistics summed over this handle's envs since the last reset of

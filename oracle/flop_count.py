@@ -1,0 +1,74 @@
+"""TEST / MEASUREMENT INFRASTRUCTURE - flops per env step from the instrumented
+restatement (oracle/flop_count.cpp; SURVEY.md §8(d) "emit the exact count from an
+instrumented oracle").
+
+    python -m oracle.flop_count            # prints the table and rewrites profiles/flops_per_env_step.json
+
+bench.py reads the committed JSON (it must not execute anything under oracle/ in
+its timed or reporting legs other than cpu_baseline); tests/test_flop_count.py
+checks that the JSON is what this module produces and that the instrumented run
+reproduces the C oracle's step.
+"""
+import ctypes
+import json
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+JSON_PATH = os.path.join(os.path.dirname(_HERE), "profiles", "flops_per_env_step.json")
+FIELDS = ("add", "mul", "div", "minmax", "trans")
+
+
+def _lib():
+    path = os.path.join(_HERE, "libflopcount.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", _HERE, "libflopcount.so"], stdout=subprocess.DEVNULL)
+    return ctypes.CDLL(path)
+
+
+def count_msj_step(desc, integrator, q, qd, sp, step_size=0.1, n_substeps=1):
+    """One instrumented env step of the ball-joint closed form.  Returns
+    (counts dict, q', qd', feasible)."""
+    lib = _lib()
+    q = np.array(q, dtype=np.float64)
+    qd = np.array(qd, dtype=np.float64)
+    sp = np.ascontiguousarray(sp, dtype=np.float64)
+    out = np.zeros(5, np.uint64)
+    feas = ctypes.c_ubyte(0)
+    rc = lib.fc_msj_step(ctypes.byref(desc.as_c_struct()), ctypes.c_double(step_size), int(n_substeps),
+                         int(integrator), q.ctypes.data_as(ctypes.c_void_p), qd.ctypes.data_as(ctypes.c_void_p),
+                         sp.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(feas))
+    if rc:
+        raise RuntimeError("fc_msj_step failed: %d" % rc)
+    counts = {k: int(v) for k, v in zip(FIELDS, out)}
+    counts["flops"] = sum(counts[k] for k in FIELDS)
+    # fewest VALU instructions that can carry these operations: every add fused with a multiply where
+    # both exist (v_fma), one instruction per selection and per transcendental
+    counts["valu_instr_lower_bound"] = max(counts["add"], counts["mul"]) + counts["div"] + counts["minmax"] + counts["trans"]
+    return counts, q, qd, bool(feas.value)
+
+
+def table():
+    from gym_roboy_amd.envs.robots import MsjRobot
+    desc = MsjRobot().get_description()
+    rng = np.random.default_rng(0)
+    q = rng.uniform(0.5 * desc.q_lo, 0.5 * desc.q_hi)
+    qd = rng.uniform(-0.5 * desc.qd_max, 0.5 * desc.qd_max)
+    sp = rng.uniform(-0.3, 0.3, desc.n_t)
+    out = {"_about": "floating-point operations per env step, counted by oracle/flop_count.cpp (the kernels' closed "
+                     "form instantiated with a tallying scalar); flops = add + mul + div + minmax + trans; "
+                     "regenerate with `python -m oracle.flop_count`"}
+    for name, integ in (("euler", 0), ("rk4", 1)):
+        c, *_ = count_msj_step(desc, integ, q, qd, sp)
+        out["MsjRobot/%s" % name] = c
+    return out
+
+
+if __name__ == "__main__":
+    t = table()
+    with open(JSON_PATH, "w") as fh:
+        json.dump(t, fh, indent=1, sort_keys=True)
+        fh.write("\n")
+    print(json.dumps(t, indent=1, sort_keys=True))

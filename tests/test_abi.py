@@ -102,9 +102,12 @@ def test_bench_never_prints_outside_its_json_line():
     """bench.py's stdout is one JSON line; anything that can print (the RoboyEnv
     goal banner in the python-loop baseline) must run under redirect_stdout."""
     src = open(os.path.join(ROOT, "bench.py")).read()
-    body = src[src.index("def cpu_baseline"):src.index("def main")]
+    # the Python env workers are child processes whose stdout is a pipe; inside them the env runs
+    # under redirect_stdout and only the "<steps> <seconds>" result line is written
+    body = src[src.index("_PY_ENV_WORKER"):src.index("def cpu_python_env_loop")]
     guarded = body[body.index("with contextlib.redirect_stdout"):]
     assert "RoboyEnv(simulation_client" in guarded and "RoboyEnv(simulation_client" not in body[:body.index("with contextlib.redirect_stdout")]
+    assert "stdout=subprocess.PIPE" in src[src.index("def cpu_python_env_loop"):src.index("def cpu_baseline")]
     # the only writer to the real stdout is the os.write of the JSON line on the saved descriptor;
     # fd 1 itself points at stderr for the whole run (RCCL prints a banner on stdout)
     assert src.count("print(") == 0

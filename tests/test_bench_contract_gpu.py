@@ -11,50 +11,88 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_prints_one_json_line_with_the_contract_keys():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "300", "--warmup", "20",
-                          "--no-also", "--cpu-seconds", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
+def _run(args, env=None, timeout=900):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                         timeout=timeout, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def _check_roofline(r, envs):
+    assert r["bound"] in ("hbm", "valu") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    h, v = r["hbm"], r["valu"]
+    assert h["peak"] == 8000.0 and h["bytes_per_launch"] == 84 * envs
+    assert abs(h["achieved"] - h["bytes_per_launch"] / r["launch_us_events"] / 1e3) / h["achieved"] < 1e-6
+    assert v["peak"] == 157.3 and abs(v["achieved"] - v["flops_per_launch"] / r["launch_us_events"] / 1e6) / v["achieved"] < 1e-6
+    assert r["frac"] == max(h["frac"], v["frac"])
+    assert r["traffic"] is None or r["traffic"] >= 0.9 * h["bytes_per_launch"]
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    """The driver's invocation shape (a small --steps): the headline is the 262 144-env workload and the
+    per-step time does not degrade into launch latency."""
+    d = _run(["--steps", "20", "--warmup", "5", "--no-also", "--cpu-seconds", "3"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "repeats"):
         assert key in d, key
-    assert d["unit"] == "env-steps/s" and d["n_gpus"] == 1 and d["steps"] == 300 and d["warmup"] == 20
+    assert d["unit"] == "env-steps/s" and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic"
-    assert "workload" in d["config"] and "model" not in d["config"] and "4 096" in d["config"]["workload"]
+    assert "workload" in d["config"] and "model" not in d["config"] and "262 144" in d["config"]["workload"]
+    assert d["config"]["envs_per_gpu"] == 262144 and d["config"]["integrator"] == "rk4"
+    assert d["repeats"] >= 3 and d["repeats"] * 20 * d["ms_per_step"] >= 40.0      # >= ~50 ms timed in all
     # value = envs * steps / time
     assert abs(d["value"] - d["config"]["total_envs"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-6
-    r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert r["bytes_per_launch"] == 84 * d["config"]["envs_per_gpu"]
-    assert abs(r["achieved"] - r["bytes_per_launch"] / r["launch_us_events"] / 1e3) / r["achieved"] < 1e-6
-    assert r["traffic"] is None or r["traffic"] >= 0.9 * r["bytes_per_launch"]
+    _check_roofline(d["roofline"], 262144)
+    assert d["roofline"]["bound"] == "valu"       # four acceleration evaluations per env step
+    # wall time per step (barrier + sync around 20 launches) within 12 % of the device-event time per launch
+    assert d["ms_per_step"] * 1e3 < 1.12 * d["roofline"]["launch_us_events"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "env-steps/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["python_env_processes"]["processes"] >= 1 and c["python_env_processes"]["value"] > 0
     assert d["value"] > 1e7          # BASELINE.json's target for one MI355X
-    assert d["sanity"]["finite"]
+    assert d["sanity"]["finite"] and d["collective"] is None
+
+
+def test_bench_default_run_carries_every_config_with_sanity_fields():
+    d = _run(["--no-cpu-baseline"])
+    assert d["steps"] == 400 and "262 144" in d["config"]["workload"]
+    names = [a["workload"] for a in d["also"]]
+    for w in ("msj-4096-euler", "msj-262144-euler", "msj-2097152-euler", "upper-body-8192-euler",
+              "upper-body-8192-rk4", "fused-env-2097152"):
+        assert w in names, names
+    for a in d["also"]:
+        assert a["finite"] is True and 0.0 <= a["feasible_frac"] <= 1.0, a["workload"]
+        if "roofline" in a:
+            assert a["roofline"]["hbm"]["frac"] > 0
 
 
 def test_bench_collective_path_with_one_rccl_rank():
-    """The multi-rank code path (process group over RCCL, in-line statistics all-reduce
-    every STATS_EVERY steps, barrier, max-reduce) rehearsed with world size 1: still one
-    JSON line on stdout (RCCL's banner must not reach it), the all-reduced statistics
-    count every env step up to the last reduce, and the collective costs no throughput."""
+    """The multi-rank code path (process group over RCCL, in-line statistics all-reduce at the end of
+    every timed region and every STATS_EVERY steps, barrier, max-reduce) rehearsed with world size 1
+    at the driver's --steps 20: one JSON line on stdout (RCCL's banner must not reach it), the
+    collective object audits the all-reduce, and the collective costs little throughput."""
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT="29633", ROBOY_BENCH_DIST_AT_1="1", ROBOY_BENCH_STATS_EVERY="400")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1600",
-                          "--warmup", "100", "--no-also", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = out.stdout.splitlines()
-    assert len(lines) == 1, lines
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["steps"] == 1600
-    stats = d["sanity"]["allreduced_stats"]
-    # n_env_steps at the last reduce: 16 decorrelation + 100 warm-up + 400 rehearsal + 1600 timed steps
-    assert stats[6] == 4096.0 * (16 + 100 + 400 + 1600)
-    assert d["ms_per_step"] < 0.0035      # 2.2-2.3 us per step without a process group; 3.7 with a concurrent collective
+               MASTER_PORT="29633", ROBOY_BENCH_DIST_AT_1="1")
+    d = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-also", "--no-cpu-baseline"], env=env)
+    assert d["n_gpus"] == 1 and d["steps"] == 20
+    c = d["collective"]
+    assert c["ok"] and c["world_size"] == 1 and c["backend"].startswith("rccl")
+    assert c["allreduce_calls"] == d["repeats"] + 1            # one per timed region (+ the rehearsal region)
+    assert c["n_env_steps_allreduced"] == c["expected"] == 262144.0 * (16 + 5 + 20 * (d["repeats"] + 1))
+    assert d["sanity"]["allreduced_stats"][6] == c["expected"]
+    assert d["ms_per_step"] * 1e3 < 1.25 * d["roofline"]["launch_us_events"]
+
+
+def test_bench_collective_with_full_chunks():
+    """--steps above STATS_EVERY: an all-reduce after every full chunk and one after the partial tail."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29634", ROBOY_BENCH_DIST_AT_1="1", ROBOY_BENCH_STATS_EVERY="100")
+    d = _run(["--gpus", "1", "--steps", "250", "--warmup", "10", "--no-also", "--no-cpu-baseline",
+              "--workload", "msj-4096-euler", "--repeats", "3"], env=env)
+    c = d["collective"]
+    assert c["ok"] and c["allreduce_calls"] == 3 * 4 and c["every_steps"] == 100
+    assert c["expected"] == 4096.0 * (16 + 10 + 250 * 4)

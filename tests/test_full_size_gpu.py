@@ -85,3 +85,72 @@ def test_full_batch_rest_equilibrium_and_boundary(msj_robot):
     assert np.all(np.abs(q) <= np.float32(0.6) + 1e-6)
     assert np.array_equal(q[0], q[-1]) and np.array_equal(q[0], q[n // 2])   # identical inputs, identical outputs
     sim.close()
+
+
+# ----------------------------------------------------------------------------
+# BASELINE.json configs[3]: the upper body (20 DOF / 38 tendons) at its stated 8 192 envs
+@pytest.fixture(scope="module")
+def upper_body():
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    return UpperBodyRobot()
+
+
+@pytest.mark.parametrize("integrator", ["euler", "rk4"])
+def test_upper_body_full_batch_sample_determinism_permutation(upper_body, integrator):
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    from oracle.c_oracle import COracle
+    desc = upper_body.get_description()
+    n = 8192
+    q, qd, sp = _states(desc, n, 7)
+    sim = HipBatchSimulation(upper_body, n, integrator=integrator)
+    assert sim.info()["kernel"] == 3
+    sim.set_state(q, qd)
+    q1, qd1, f1 = sim.forward_step_command(sp)
+    assert np.isfinite(q1).all() and np.isfinite(qd1).all()
+    # (a) every 13th env (630 envs: every wave slot of a workgroup, both dispatch generations) vs the fp64 oracle
+    idx = np.arange(0, n, 13)
+    qo, qdo, fo = COracle(desc, "f64").step(q[idx], qd[idx], sp[idx], integrator=0 if integrator == "euler" else 1,
+                                            threads=8)
+    assert np.abs(q1[idx] - qo).max() < 2e-5, np.abs(q1[idx] - qo).max()
+    assert np.abs(qd1[idx] - qdo).max() < 2e-5, np.abs(qd1[idx] - qdo).max()
+    near = np.minimum(np.abs(qo - desc.q_lo), np.abs(qo - desc.q_hi)).min(axis=1) < 1e-5
+    assert not np.any((f1[idx] != fo) & ~near)
+    # (b) determinism
+    sim.set_state(q, qd)
+    q2, qd2, f2 = sim.forward_step_command(sp)
+    assert np.array_equal(q1, q2) and np.array_equal(qd1, qd2) and np.array_equal(f1, f2)
+    # (c) permutation equivariance, bit for bit
+    perm = np.random.default_rng(8).permutation(n)
+    sim.set_state(q[perm], qd[perm])
+    q3, qd3, f3 = sim.forward_step_command(sp[perm])
+    assert np.array_equal(q3, q1[perm]) and np.array_equal(qd3, qd1[perm]) and np.array_equal(f3, f1[perm])
+    sim.close()
+
+
+def test_upper_body_full_batch_shards_and_rest_equilibrium(upper_body):
+    """8 192 envs = 2 shards of 4 096 (env_id_offset), driven by the device action stream; then the rest pose."""
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    n_shard, seed = 4096, 6
+    whole = HipBatchSimulation(upper_body, 2 * n_shard, seed=seed)
+    parts = [HipBatchSimulation(upper_body, n_shard, seed=seed, env_id_offset=r * n_shard) for r in (0, 1)]
+
+    def run(sim):
+        d = sim.malloc(4 * sim.n_envs * sim.n_t)
+        for t in range(6):
+            sim.fill_actions_dev(d, t)
+            sim.step_dev(d, 0.3)
+        sim.synchronize()
+        return sim.read_state()
+    qw, qdw, fw = run(whole)
+    for r, p in enumerate(parts):
+        qp, qdp, fp = run(p)
+        sl = slice(r * n_shard, (r + 1) * n_shard)
+        assert np.array_equal(qw[sl], qp) and np.array_equal(qdw[sl], qdp) and np.array_equal(fw[sl], fp)
+        p.close()
+    assert np.abs(qw).max() > 0.01 and np.isfinite(qw).all()
+    whole.forward_reset_command()
+    q, qd, f = whole.forward_step_command(np.zeros((2 * n_shard, whole.n_t), np.float32))
+    # fp32 gravity terms cancel to ~1e-8 rad (tests/test_tree_robot_gpu.py), every env alike
+    assert np.abs(q).max() < 1e-6 and np.abs(qd).max() < 1e-5 and f.all()
+    assert np.array_equal(q[0], q[-1]) and np.array_equal(q[0], q[4097])
+    whole.close()
