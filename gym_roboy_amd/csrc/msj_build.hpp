@@ -50,6 +50,8 @@ int msj_build(const rb_robot_desc *d, double step_size, int nsub, MsjConst<T, NT
         err = "tendon count does not match this kernel instance"; return RB_EUNSUPPORTED;
     }
     MsjConst<T, NT> &c = *out;
+    const double log2e = 1.4426950408889634;
+    const double sc = std::sqrt(log2e) / d->fl_width;     // strain scale: f_L = exp2(-(sc e)^2)
     auto seglen = [&](int va, int vb) {
         double s = 0.0;
         for (int a = 0; a < 3; ++a) { const double t = d->vp_pos[3 * vb + a] - d->vp_pos[3 * va + a]; s += t * t; }
@@ -70,16 +72,18 @@ int msj_build(const rb_robot_desc *d, double step_size, int nsub, MsjConst<T, NT
         for (int a = 0; a < 3; ++a) { t.A[a] = T(d->vp_pos[3 * va + a]); t.B[a] = T(d->vp_pos[3 * vb + a]); }
         double ab2 = 0.0;
         for (int a = 0; a < 3; ++a) ab2 += d->vp_pos[3 * va + a] * d->vp_pos[3 * va + a] + d->vp_pos[3 * vb + a] * d->vp_pos[3 * vb + a];
-        t.ab2 = T(ab2); t.inv_l0 = T(1.0 / l0); t.e_lc = T(lc / l0 - 1.0); t.sg_l0 = T(d->setpoint_scale / l0);
+        for (int a = 0; a < 3; ++a) t.B2[a] = T(-2.0 * d->vp_pos[3 * vb + a]);
+        t.ab2 = T(ab2); t.il0s = T(sc / l0); t.elcs = T(sc * (lc / l0 - 1.0)); t.ksg = T(d->kp * d->setpoint_scale / l0);
         t.fmax = T(d->f_max[k]);
         t.inv_vl0 = T(1.0 / (d->v_max * l0));
-        for (int a = 0; a < 4; ++a) t.pad[a] = T(0);
+        t.pad = T(0);
     }
     for (int k = d->n_t; k < NT; ++k) {       // unused records: a well-formed tendon that never pulls
         MsjTendon<T> &t = c.ten[k];
         t.A[0] = T(1); t.A[1] = T(0); t.A[2] = T(0); t.B[0] = T(0); t.B[1] = T(0); t.B[2] = T(1);
-        t.ab2 = T(2); t.inv_l0 = T(1); t.e_lc = T(-1); t.sg_l0 = T(0); t.fmax = T(0); t.inv_vl0 = T(1);
-        for (int a = 0; a < 4; ++a) t.pad[a] = T(0);
+        t.B2[0] = T(0); t.B2[1] = T(0); t.B2[2] = T(-2);
+        t.ab2 = T(2); t.il0s = T(sc); t.elcs = T(-sc); t.ksg = T(0); t.fmax = T(0); t.inv_vl0 = T(1);
+        t.pad = T(0);
     }
     c.nt = d->n_t;
     const double m = d->mass[2];
@@ -97,14 +101,13 @@ int msj_build(const rb_robot_desc *d, double step_size, int nsub, MsjConst<T, NT
         c.arm[a] = T(d->armature[a]); c.damp[a] = T(d->damping[a]);
         c.qlo[a] = T(d->q_lo[a]); c.qhi[a] = T(d->q_hi[a]); c.qdmax[a] = T(d->qd_max[a]);
     }
-    const double log2e = 1.4426950408889634;
-    c.kp = T(d->kp);
-    c.fl_k2 = T(-log2e / (d->fl_width * d->fl_width));
-    c.pe_k2 = T(log2e * d->kpe / d->e0);
+    c.kps = T(d->kp / sc);
+    c.pe_k2s = T(log2e * d->kpe / (d->e0 * sc));
     c.inv_pe_den = T(1.0 / (std::exp(d->kpe) - 1.0));
     const double slope0 = 1.0 + 1.0 / d->fv_a;
     const double c2l = slope0 / (d->fv_n - 1.0);
     c.fv_c2s = T(-1.0 / d->fv_a);
+    c.fv_k = T(1.0 + 1.0 / d->fv_a);
     c.fv_c1l = T(d->fv_n * c2l); c.fv_c2l = T(c2l);
     c.h = T(step_size / nsub); c.nsub = nsub;
     c.simple = (ic[3] == 0.0 && ic[4] == 0.0 && ic[5] == 0.0 && cm[0] == 0.0 && cm[1] == 0.0 &&

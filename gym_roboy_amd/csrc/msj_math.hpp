@@ -29,6 +29,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -87,24 +88,45 @@ template <> struct Fast<float> {
     }
 };
 
-template <typename T> RB_HD T tmin(T a, T b) { return a < b ? a : b; }
-template <typename T> RB_HD T tmax(T a, T b) { return a > b ? a : b; }
-template <typename T> RB_HD T tclamp(T x, T lo, T hi) { return tmin(tmax(x, lo), hi); }
+// min / max / clamp: on the device, for float, one VALU instruction each (v_min_f32 /
+// v_max_f32 / v_med3_f32) instead of a compare-select pair
+template <typename T> RB_HD T tmin(T a, T b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (std::is_same<T, float>::value) return __builtin_fminf(a, b);
+#endif
+    return a < b ? a : b;
+}
+template <typename T> RB_HD T tmax(T a, T b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (std::is_same<T, float>::value) return __builtin_fmaxf(a, b);
+#endif
+    return a > b ? a : b;
+}
+template <typename T> RB_HD T tclamp(T x, T lo, T hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (std::is_same<T, float>::value) return __builtin_amdgcn_fmed3f(x, lo, hi);
+#endif
+    return tmin(tmax(x, lo), hi);
+}
 
 // ---- per-robot constants (wave-uniform: fetched by scalar loads into SGPRs) ----
 // One 16-scalar record per tendon, so a rolled tendon loop needs a single
 // s_load_dwordx16 per trip and only ~16 SGPRs of tendon constants are live.
+// Lengths enter the muscle model through the scaled strain  es = s (l/l0 - 1)  with
+// s = sqrt(log2 e)/fl_width, so that f_L = exp2(-es^2) needs no further multiply; the other
+// users of the strain carry 1/s in their own constants (kps, pe_k2s).
 template <typename T>
 struct alignas(64) MsjTendon {
     T A[3];        // last base via-point, world = base frame
     T B[3];        // first body via-point, body frame
+    T B2[3];       // -2 B  (|B - a|^2 = ab2 + a . B2)
     T ab2;         // |A|^2 + |B|^2
-    T inv_l0;      // 1 / rest length
-    T e_lc;        // lc / l0 - 1  (lc = summed length of the segments that do not move)
-    T sg_l0;       // setpoint_scale / rest length
+    T il0s;        // s / rest length
+    T elcs;        // s (lc / l0 - 1)  (lc = summed length of the segments that do not move)
+    T ksg;         // kp * setpoint_scale / rest length: set-point -> activation offset u = ksg * setpoint
     T fmax;        // maximum isometric force
     T inv_vl0;     // 1 / (v_max * rest length)
-    T pad[4];
+    T pad;
 };
 
 template <typename T, int NT>
@@ -114,12 +136,12 @@ struct MsjConst {
     T mc[3];          // mass * centre of mass (body frame)
     T g[3];           // gravity, world
     T arm[3], damp[3], qlo[3], qhi[3], qdmax[3];
-    T kp;             // activation per unit of normalised length error
-    T fl_k2;          // -log2(e) / fl_width^2           (f_L  = exp2(fl_k2 * e^2))
-    T pe_k2;          // log2(e) * kpe / e0              (f_PE = (exp2(pe_k2 * e) - 1) * inv_pe_den)
+    T kps;            // kp / s: activation per unit of scaled strain
+    T pe_k2s;         // log2(e) * kpe / (e0 s)          (f_PE = (exp2(pe_k2s * es) - 1) * inv_pe_den)
     T inv_pe_den;     // 1 / (exp(kpe) - 1)
     T fv_c1l, fv_c2l; // lengthening branch of f_V; the shortening branch is (1 + v)/(1 + fv_c2s v)
     T fv_c2s;
+    T fv_k;           // 1 - fv_c2s
     T h;              // integrator substep
     int32_t nsub;
     int32_t simple;   // 1: principal-axis inertia, COM on body z, gravity along world z (fast path)
@@ -161,36 +183,41 @@ struct MsjModel {
     }
 
     // one tendon: routing, Hill-type force, torque about the joint centre (body
-    // frame) subtracted from (tx,ty,tz)
-    static RB_HD void tendon(const C &c, const Frame &f, const MsjTendon<T> &t, T spk, T &tx, T &ty, T &tz) {
+    // frame) subtracted from (tx,ty,tz).  `u` is the tendon's activation offset
+    // ksg * set-point (prescale()).
+    static RB_HD void tendon(const C &c, const Frame &f, const MsjTendon<T> &t, T u, T &tx, T &ty, T &tz) {
         // a = R^T A (body frame).  With |a| = |A|:  |B - a|^2 = (|A|^2 + |B|^2) - 2 a.B,
         // and the torque arm w = B x (B - a)/|d| = (a x B)/|d|, so neither the
         // difference vector nor the unit vector is formed.
         const T ax = f.r00 * t.A[0] + f.r10 * t.A[1] + f.r20 * t.A[2];
         const T ay = f.r01 * t.A[0] + f.r11 * t.A[1] + f.r21 * t.A[2];
         const T az = f.r02 * t.A[0] + f.r12 * t.A[1] + f.r22 * t.A[2];
-        const T d2 = t.ab2 - T(2) * (ax * t.B[0] + ay * t.B[1] + az * t.B[2]);
+        const T d2 = ax * t.B2[0] + (ay * t.B2[1] + (az * t.B2[2] + t.ab2));
         const T inv = Fast<T>::rsqrt(d2);
         // cr = a x B;  w = cr * inv
         const T mx = ay * t.B[2] - az * t.B[1];
         const T my = az * t.B[0] - ax * t.B[2];
         const T mz = ax * t.B[1] - ay * t.B[0];
         const T ldot = (f.wx * mx + f.wy * my + f.wz * mz) * inv;
-        // Hill-type muscle: e = l/l0 - 1 = |d|/l0 + (lc/l0 - 1), err = e - (sigma/l0) s
-        const T e = (d2 * inv) * t.inv_l0 + t.e_lc;
-        const T act = tclamp(c.kp * (e - t.sg_l0 * spk), T(0), T(1));
-        const T fl = Fast<T>::exp2(c.fl_k2 * (e * e));
-        // f_V = (1 + c1 v)/(1 + c2 v) per branch, written branch-free with
-        // v+ = max(v,0) and v- = clamp(v,-1,0) (one of them is zero)
+        // Hill-type muscle on the scaled strain es = s (l/l0 - 1) = s |d|/l0 + s (lc/l0 - 1):
+        // activation = clamp(kp (e - (sigma/l0) setpoint), 0, 1) = clamp((kp/s) es - u, 0, 1)
+        const T es = (d2 * inv) * t.il0s + t.elcs;
+        const T act = tclamp(c.kps * es - u, T(0), T(1));
+        const T fl = Fast<T>::exp2(-(es * es));
+        // f_V = (1 + c1 v)/(1 + c2 v) per branch, written branch-free with v+ = max(v,0) and
+        // p = 1 + clamp(v,-1,0) = clamp(1 + v, 0, 1)  (v+ = 0 or p = 1)
         const T v = ldot * t.inv_vl0;
-        const T vp = tmax(v, T(0)), vm = tclamp(v, T(-1), T(0));
-        const T num = c.fv_c1l * vp + (T(1) + vm);
-        const T den = c.fv_c2l * vp + (c.fv_c2s * vm + T(1));
-        const T fv = num * Fast<T>::rcp(den);          // >= 0: num >= 0, den >= 1
-        const T fpe = tmax((Fast<T>::exp2(c.pe_k2 * e) - T(1)) * c.inv_pe_den, T(0));
-        const T Fs = t.fmax * (act * fl * fv + fpe) * inv;     // tension / |d|
+        const T vp = tmax(v, T(0)), p = tclamp(v + T(1), T(0), T(1));
+        const T num = c.fv_c1l * vp + p;
+        const T den = c.fv_c2l * vp + (c.fv_c2s * p + c.fv_k);
+        const T rden = Fast<T>::rcp(den);              // den >= 1
+        const T fpe = tmax(Fast<T>::exp2(c.pe_k2s * es) * c.inv_pe_den - c.inv_pe_den, T(0));
+        const T Fs = (t.fmax * inv) * ((act * fl) * num * rden + fpe);     // tension / |d|
         tx -= Fs * mx; ty -= Fs * my; tz -= Fs * mz;
     }
+
+    // set-point (tendon length offset, the action box +-0.3 of msj_robot.py:15-16) -> activation offset
+    static RB_HD T prescale(const C &c, int k, T setpoint) { return c.ten[k].ksg * setpoint; }
 
     // rigid body about the joint centre: qdd from the summed tendon torque.
     // c.simple (wave-uniform) marks the common case - principal-axis inertia,
@@ -361,14 +388,19 @@ struct MsjModel {
         return feasible;
     }
 
+    // sp(k): activation offset of tendon k (prescale() of its set-point)
     template <int INTEG, int UNROLL, typename SP>
     static RB_HD bool step_sp(const C &c, T q[3], T qd[3], const SP &sp) {
         return integrate<INTEG>(c, q, qd, AccelAllTendons<UNROLL, SP>{c, sp});
     }
 
+    // sp: raw set-points; step_sp's SP source yields activation offsets (prescale())
     template <int INTEG, int UNROLL = NT>
     static RB_HD bool step(const C &c, T q[3], T qd[3], const T sp[NT]) {
-        const SpArray<T, NT> src{sp};
+        T u[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) u[k] = prescale(c, k, sp[k]);
+        const SpArray<T, NT> src{u};
         return step_sp<INTEG, UNROLL>(c, q, qd, src);
     }
 };

@@ -4,7 +4,7 @@
 // (gym_roboy/envs/simulations/ros_simulation_client.py:32-81) by kernels that
 // advance N independent environments in lock-step.  State is struct-of-arrays
 // in HBM, one env per lane (or one tendon per lane for small batches, or one env
-// per wave for generic joint trees, tree_kernels.hpp), robot constants are
+// per wave for generic joint trees, tree_aba.hpp), robot constants are
 // wave-uniform and arrive through the kernarg (scalar loads -> SGPRs); LDS holds
 // only what is indexed at run time (the set-points of the rolled tendon loop).
 // DESIGN.md §4-§5.
@@ -21,7 +21,7 @@
 #include "msj_math.hpp"
 #include "philox.hpp"
 #include "env_common.hpp"
-#include "tree_kernels.hpp"
+#include "tree_aba.hpp"
 
 namespace {
 
@@ -47,6 +47,20 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #endif
 #ifndef RB_TENDON_LANE_BATCH_RK4
 #define RB_TENDON_LANE_BATCH_RK4 16384
+#endif
+// launch configuration of the env-per-lane form above RB_SMALL_BATCH envs: workgroup size and
+// unroll factor of the tendon loop, per integrator (A/B: profiles/r2_a/kernel_ab_experiments.log)
+#ifndef RB_BIG_BLOCK_EULER
+#define RB_BIG_BLOCK_EULER 256
+#endif
+#ifndef RB_BIG_UNROLL_EULER
+#define RB_BIG_UNROLL_EULER 1
+#endif
+#ifndef RB_BIG_BLOCK_RK4
+#define RB_BIG_BLOCK_RK4 256
+#endif
+#ifndef RB_BIG_UNROLL_RK4
+#define RB_BIG_UNROLL_RK4 1
 #endif
 using rbe::EnvParams;
 using rbe::GoalBox;
@@ -86,11 +100,13 @@ msj_step_env_per_lane(const Const8 c, float *__restrict__ q, float *__restrict__
     const float4 a1 = reinterpret_cast<const float4 *>(act)[2 * i + 1];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { qq[j] = q[j * n + i]; vv[j] = qd[j * n + i]; }
-    sp[0] = a0.x * act_scale; sp[1] = a0.y * act_scale; sp[2] = a0.z * act_scale; sp[3] = a0.w * act_scale;
-    sp[4] = a1.x * act_scale; sp[5] = a1.y * act_scale; sp[6] = a1.z * act_scale; sp[7] = a1.w * act_scale;
+    // activation offsets u_k = ksg_k * (act_scale * action_k): what the model's tendon loop consumes
+    const float a[NT8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+    for (int k = 0; k < NT8; ++k) sp[k] = a[k] * (act_scale * c.ten[k].ksg);
     bool ok;
     if (UNROLL >= NT8) {
-        ok = rb::MsjModel<float, NT8>::template step<INTEG, UNROLL>(c, qq, vv, sp);
+        ok = rb::MsjModel<float, NT8>::template step_sp<INTEG, UNROLL>(c, qq, vv, rb::SpArray<float, NT8>{sp});
     } else {
         __shared__ float lds_sp[NT8][BLOCK];
 #pragma unroll
@@ -117,7 +133,7 @@ msj_step_env_per_lane_nt(const ConstX c, float *__restrict__ q, float *__restric
     __shared__ float lds_sp[NTX][BLOCK];
     const int nt = c.nt;
     const float *row = act + i * nt;
-    for (int k = 0; k < nt; ++k) lds_sp[k][threadIdx.x] = row[k] * act_scale;
+    for (int k = 0; k < nt; ++k) lds_sp[k][threadIdx.x] = row[k] * (act_scale * c.ten[k].ksg);
     float qq[3], vv[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { qq[j] = q[j * n + i]; vv[j] = qd[j * n + i]; }
@@ -183,7 +199,7 @@ msj_step_tendon_per_lane(const Const8 c, const rb::MsjTendon<float> *__restrict_
     const bool live = e < n;          // whole 8-lane groups are live or not; dead groups
     if (!live) e = n - 1;             // shadow the last env so every DPP partner is active
     const rb::MsjTendon<float> rec = ten[k];
-    const float spk = act[e * NT8 + k] * act_scale;
+    const float spk = act[e * NT8 + k] * (act_scale * rec.ksg);   // activation offset of the own tendon
     float qq[3], vv[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { qq[j] = q[j * n + e]; vv[j] = qd[j * n + e]; }
@@ -218,15 +234,17 @@ msj_rollout_fused(const Const8 c, float *__restrict__ q, float *__restrict__ qd,
     __shared__ float lds_sp[UNROLL >= NT8 ? 1 : NT8][BLOCK];
     int slab = 0;
     for (int t = 0; t < n_steps; ++t) {
-        const float sp[NT8] = {a0.x * act_scale, a0.y * act_scale, a0.z * act_scale, a0.w * act_scale,
-                               a1.x * act_scale, a1.y * act_scale, a1.z * act_scale, a1.w * act_scale};
+        const float a[NT8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        float sp[NT8];
+#pragma unroll
+        for (int k = 0; k < NT8; ++k) sp[k] = a[k] * (act_scale * c.ten[k].ksg);
         if (t + 1 < n_steps) {   // next step's action: in flight under this step's arithmetic
             slab = slab + 1 == ring ? 0 : slab + 1;
             const float4 *nx = rec + long(slab) * 2 * n;
             a0 = nx[0]; a1 = nx[1];
         }
         if (UNROLL >= NT8) {
-            ok = rb::MsjModel<float, NT8>::template step<INTEG, UNROLL>(c, qq, vv, sp);
+            ok = rb::MsjModel<float, NT8>::template step_sp<INTEG, UNROLL>(c, qq, vv, rb::SpArray<float, NT8>{sp});
         } else {
 #pragma unroll
             for (int k = 0; k < NT8; ++k) lds_sp[k][threadIdx.x] = sp[k];   // lane-private column: no barrier
@@ -331,7 +349,7 @@ msj_env_step_kernel(const CONST c, const EnvParams e, const GoalBox box,
         __shared__ float lds_sp[NTX][BLOCK];
         const int nt = c.nt;
         const float *row = act + i * nt;
-        for (int k = 0; k < nt; ++k) lds_sp[k][threadIdx.x] = rescale(row[k]);
+        for (int k = 0; k < nt; ++k) lds_sp[k][threadIdx.x] = rescale(row[k]) * c.ten[k].ksg;
         ok = rb::MsjModel<float, NTX>::template step_sp<INTEG, 0>(c, qq, vv, SpLds{&lds_sp[0][threadIdx.x], BLOCK});
     } else {
     float sp[NT8];
@@ -339,9 +357,9 @@ msj_env_step_kernel(const CONST c, const EnvParams e, const GoalBox box,
     const float4 a1 = reinterpret_cast<const float4 *>(act)[2 * i + 1];
     const float a[NT8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-    for (int k = 0; k < NT8; ++k) sp[k] = rescale(a[k]);
+    for (int k = 0; k < NT8; ++k) sp[k] = rescale(a[k]) * c.ten[k].ksg;   // set-point -> activation offset
     if (UNROLL >= NT8) {
-        ok = rb::MsjModel<float, NT8>::template step<INTEG, UNROLL>(c, qq, vv, sp);
+        ok = rb::MsjModel<float, NT8>::template step_sp<INTEG, UNROLL>(c, qq, vv, rb::SpArray<float, NT8>{sp});
     } else {
         // rolled tendon loop: the set-points are indexed at run time, keep them as an LDS column
         // (as msj_step_env_per_lane does); each lane reads back only what it wrote
@@ -476,11 +494,11 @@ struct rb_sim {
     bool ntx = false;
     rb::MsjTendon<float> *d_ten = nullptr;   // device copy of c8.ten for the tendon-per-lane form
     int kernel_choice = RB_KERNEL_AUTO;
-    // generic joint-tree robots (tree_kernels.hpp): wave-per-env kernel
+    // generic joint-tree robots (tree_aba.hpp): a few envs per wave, articulated-body algorithm
     bool tree = false;
     rbt::TreeHost tree_host;
-    int *d_tree_ints = nullptr;
-    float *d_tree_floats = nullptr;
+    uint32_t *d_tree_words = nullptr;   // the robot tables, staged into LDS by every workgroup
+    int tree_waves = 1;                 // waves per workgroup
     GoalBox box;
     hipStream_t own_stream = nullptr, stream = nullptr;
     float *d_q = nullptr, *d_qd = nullptr;
@@ -520,13 +538,15 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale) {
     hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U>), dim3(blocks_for(n, B)), dim3(B), 0,      \
                        s->stream, s->c8, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n)
     if (s->tree) {
-        const size_t lds = s->tree_host.lds_floats * sizeof(float);
-        const unsigned tree_blocks = unsigned((n + rbt::TREE_WAVES - 1) / rbt::TREE_WAVES);
+        const int wv = s->tree_waves;
+        const size_t lds = rbt::tree_lds_bytes(s->tree_host, wv);
+        const long per_block = long(wv) * rbt::TREE_E;
+        const unsigned tree_blocks = unsigned((n + per_block - 1) / per_block);
         if (s->integrator == RB_EULER)
-            hipLaunchKernelGGL((rbt::tree_step_wave_per_env<0>), dim3(tree_blocks), dim3(64 * rbt::TREE_WAVES), lds, s->stream,
+            hipLaunchKernelGGL((rbt::tree_step_aba<0, rbt::TREE_E>), dim3(tree_blocks), dim3(64 * wv), lds, s->stream,
                                s->tree_host.dev, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
         else
-            hipLaunchKernelGGL((rbt::tree_step_wave_per_env<1>), dim3(tree_blocks), dim3(64 * rbt::TREE_WAVES), lds, s->stream,
+            hipLaunchKernelGGL((rbt::tree_step_aba<1, rbt::TREE_E>), dim3(tree_blocks), dim3(64 * wv), lds, s->stream,
                                s->tree_host.dev, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
     } else if (s->ntx) {
 #define RB_NT_LAUNCH(INTEG, B)                                                                          \
@@ -546,7 +566,8 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale) {
     } else if (n <= RB_SMALL_BATCH) {
         if (s->integrator == RB_EULER) RB_STEP_LAUNCH(0, 64, 8); else RB_STEP_LAUNCH(1, 64, 8);
     } else {
-        if (s->integrator == RB_EULER) RB_STEP_LAUNCH(0, 256, 1); else RB_STEP_LAUNCH(1, 256, 1);
+        if (s->integrator == RB_EULER) RB_STEP_LAUNCH(0, RB_BIG_BLOCK_EULER, RB_BIG_UNROLL_EULER);
+        else RB_STEP_LAUNCH(1, RB_BIG_BLOCK_RK4, RB_BIG_UNROLL_RK4);
     }
 #undef RB_STEP_LAUNCH
     RB_HIP(hipGetLastError());
@@ -666,18 +687,20 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
         RB_TRY(hipMemcpyAsync(s->d_ten, s->c8.ten, sizeof(s->c8.ten), hipMemcpyHostToDevice, s->stream));
     } else {
         rbt::TreeHost &th = s->tree_host;
-        // one allocation: [ints | floats | pad to 16 B]; d_tree_floats points into it
-        const size_t words = rbt::tree_table_words(th);
-        RB_TRY(hipMalloc(&s->d_tree_ints, sizeof(int) * words));
-        RB_TRY(hipMemset(s->d_tree_ints, 0, sizeof(int) * words));
-        s->d_tree_floats = reinterpret_cast<float *>(s->d_tree_ints) + th.ints.size();
-        RB_TRY(hipMemcpy(s->d_tree_ints, th.ints.data(), sizeof(int) * th.ints.size(), hipMemcpyHostToDevice));
-        RB_TRY(hipMemcpy(s->d_tree_floats, th.floats.data(), sizeof(float) * th.floats.size(), hipMemcpyHostToDevice));
-        rbt::tree_patch_pointers(th, s->d_tree_ints, s->d_tree_floats);
-        if (th.lds_floats * sizeof(float) > 160 * 1024) {
+        RB_TRY(hipMalloc(&s->d_tree_words, sizeof(uint32_t) * th.words.size()));
+        RB_TRY(hipMemcpy(s->d_tree_words, th.words.data(), sizeof(uint32_t) * th.words.size(), hipMemcpyHostToDevice));
+        th.dev.g_words = reinterpret_cast<const float4 *>(s->d_tree_words);
+        if (rbt::tree_lds_bytes(th, 1) > 160 * 1024) {
             rb_destroy(s);
             return fail(RB_EUNSUPPORTED, "robot working set exceeds the 160 KiB LDS of a CU");
         }
+        s->tree_waves = rbt::tree_pick_waves(th);
+        // more than 64 KiB of dynamic LDS per workgroup has to be granted per kernel
+        const int lds_max = 160 * 1024;
+        RB_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rbt::tree_step_aba<0, rbt::TREE_E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        RB_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rbt::tree_step_aba<1, rbt::TREE_E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        RB_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rbt::tree_env_step_aba<0, rbt::TREE_E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        RB_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rbt::tree_env_step_aba<1, rbt::TREE_E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     }
     RB_TRY(hipMemsetAsync(s->d_goal_count, 0, sizeof(uint32_t) * size_t(n_envs), s->stream));
     RB_TRY(hipMalloc(&s->d_infeas_n, sizeof(uint32_t) * size_t(n_envs)));
@@ -698,7 +721,7 @@ void rb_destroy(rb_sim *s) {
     for (auto &kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     (void)hipFree(s->d_q); (void)hipFree(s->d_qd); (void)hipFree(s->d_feas);
     (void)hipFree(s->d_goal_count); (void)hipFree(s->d_rows); (void)hipFree(s->d_u8); (void)hipFree(s->d_ten);
-    (void)hipFree(s->d_tree_ints);   // d_tree_floats points into the same allocation
+    (void)hipFree(s->d_tree_words);
     (void)hipFree(s->d_state_rows); (void)hipHostFree(s->h_state_rows);
     (void)hipFree(s->d_goal); (void)hipFree(s->d_ep_ret); (void)hipFree(s->d_ep_sum); (void)hipFree(s->d_ep_cnt);
     (void)hipFree(s->d_step_num); (void)hipFree(s->d_infeas_n); (void)hipFree(s->d_stats);
@@ -903,7 +926,7 @@ int rb_rollout_fused_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, 
                        s->c8, s->d_q, s->d_qd, s->d_feas, d_ring, ring, n_steps, act_scale, n)
     const bool euler = s->integrator == RB_EULER;
     if (n <= RB_SMALL_BATCH) { if (euler) RB_FUSED_LAUNCH(0, 64, 8); else RB_FUSED_LAUNCH(1, 64, 8); }
-    else                     { if (euler) RB_FUSED_LAUNCH(0, 256, 1); else RB_FUSED_LAUNCH(1, 256, 1); }
+    else                     { if (euler) RB_FUSED_LAUNCH(0, RB_BIG_BLOCK_EULER, RB_BIG_UNROLL_EULER); else RB_FUSED_LAUNCH(1, RB_BIG_BLOCK_RK4, RB_BIG_UNROLL_RK4); }
 #undef RB_FUSED_LAUNCH
     RB_HIP(hipGetLastError());
     s->env_steps += double(n) * n_steps;
@@ -998,9 +1021,11 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
     if (!s->tree && reinterpret_cast<uintptr_t>(d_act) % 16) return fail(RB_EINVAL, "action slab must be 16-byte aligned");
     const long n = s->n;
     if (s->tree) {
-        const size_t lds = s->tree_host.lds_floats * sizeof(float);
+        const int wv = s->tree_waves;
+        const size_t lds = rbt::tree_lds_bytes(s->tree_host, wv);
+        const long per_block = long(wv) * rbt::TREE_E;
 #define RB_TREE_ENV_LAUNCH(INTEG)                                                                          \
-    hipLaunchKernelGGL((rbt::tree_env_step_wave_per_env<INTEG>), dim3(unsigned((n + rbt::TREE_WAVES - 1) / rbt::TREE_WAVES)), dim3(64 * rbt::TREE_WAVES), lds, s->stream, \
+    hipLaunchKernelGGL((rbt::tree_env_step_aba<INTEG, rbt::TREE_E>), dim3(unsigned((n + per_block - 1) / per_block)), dim3(64 * wv), lds, s->stream, \
                        s->tree_host.dev, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, \
                        s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done, s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, \
                        n, s->seed, uint64_t(s->env0))
@@ -1026,7 +1051,7 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
         else                     { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_NT(0, 256); else RB_ENV_LAUNCH_NT(1, 256); }
     } else
     if (n <= RB_SMALL_BATCH) { if (s->integrator == RB_EULER) RB_ENV_LAUNCH(0, 64, 8); else RB_ENV_LAUNCH(1, 64, 8); }
-    else                     { if (s->integrator == RB_EULER) RB_ENV_LAUNCH(0, 256, 1); else RB_ENV_LAUNCH(1, 256, 1); }
+    else                     { if (s->integrator == RB_EULER) RB_ENV_LAUNCH(0, RB_BIG_BLOCK_EULER, RB_BIG_UNROLL_EULER); else RB_ENV_LAUNCH(1, RB_BIG_BLOCK_RK4, RB_BIG_UNROLL_RK4); }
 #undef RB_ENV_LAUNCH_NT
 #undef RB_ENV_LAUNCH
     RB_HIP(hipGetLastError());

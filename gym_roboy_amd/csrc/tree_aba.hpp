@@ -1,0 +1,912 @@
+// tree_aba.hpp - generic joint-tree robots (roboy-tendon-robot/1): E envs per WAVE,
+// articulated-body algorithm in world coordinates.
+//
+// For robots outside the ball-joint class (msj_math.hpp) - e.g. the 20-DOF / 38-tendon upper
+// body of BASELINE.json configs[3] - one lane cannot hold an env.  Round 1 gave each env a whole
+// wavefront and built the joint-space mass matrix (CRBA + in-LDS Cholesky); its tree passes ran
+// at 1-3 active lanes and the kernel was bound by wave-instruction issue (109 us at 8 192 envs,
+// profiles/r1_b).  This file replaces it:
+//
+//   * E (template, 4) envs share a wave; every phase maps lanes to (env, item) pairs, so the
+//     per-level passes of the tree run E times wider and each wave-instruction serves E envs;
+//   * forward dynamics by the articulated-body algorithm (Featherstone), O(n_q), with every
+//     spatial quantity expressed in WORLD coordinates about the WORLD ORIGIN.  Then the
+//     accumulation of articulated inertias / bias forces into the parent is a plain sum (no
+//     coordinate transforms), and there is no mass matrix, no factorisation, no substitution;
+//   * a tendon acts on the links only where it crosses from one link to another: segments
+//     between via-points of the same link have constant length and their forces cancel, so
+//     tree_build() folds them into a constant and keeps the "crossings" (1 per tendon on the
+//     upper body), each of which exerts +-W = +-F (x_a x u ; u) on its two links.
+//
+// Phases of one acceleration evaluation, lanes = (env, item):
+//   P1  links, level by level from the root:  R, p, joint axis s = (z ; p x z), spatial velocity
+//       v = (w ; vO), velocity-product acceleration c
+//   P2  tendons:  crossing geometry, length, length rate, Hill force, wrench W per crossing
+//   P3  links:  spatial inertia about the origin -> I^A (21 floats), bias force p^A = v x* I v
+//   P4  (link, component):  p^A -= sum of the tendon wrenches on the link (owner gathers: no atomics)
+//   P5  links, level by level from the leaves:  gather children, U = I^A s, D, u, I^a, p^a
+//   P6  links, level by level from the root:  a, qdd
+// Every accumulation is a gather by its owner lane in table order: results are bit-reproducible
+// and independent of which wave / slot an env occupies.  The phases of a wave are ordered by
+// wave_sync() alone (LDS instructions of one wave execute in issue order); a workgroup is a few
+// waves sharing one LDS copy of the robot tables (staged behind the only barrier).
+//
+// The model is DESIGN.md §2; oracle/physics_np.py (Jacobian-sum M, RNE bias, dense solve) is what
+// this is checked against; tools/proto/aba_world.py is the fp64 prototype of this formulation
+// (agrees with the oracle to 3e-15).  Algorithmic HBM bytes per env step: 4 (4 n_q + n_t + 1).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/roboy_sim.h"
+#include "env_common.hpp"
+#include "philox.hpp"
+
+namespace rbt {
+
+constexpr int MAXQ = 32;    // joints per robot
+constexpr int MAXT = 64;    // tendons per robot
+constexpr int MAXVP = 1024; // via-points
+#ifndef RB_TREE_E
+#define RB_TREE_E 2
+#endif
+#ifndef RB_TREE_SKIP
+#define RB_TREE_SKIP 0      // timing-only builds: bit k set = phase P(k+1) left out (results wrong by construction)
+#endif
+constexpr int TREE_E = RB_TREE_E;   // envs per wave
+constexpr int LS = 48;      // floats per link in an env's working set (layout below)
+constexpr int LINK_REC = 24, TENDON_REC = 8, CROSS_REC = 8;
+
+// Link block (LS floats), by phase:
+//   [ 0..11]  R (9, row-major), p (3)          P1 -> P3     then  I^A[0..17] spans [0..17]   P3 -> P5
+//   [12..17]  w (3), vO (3)                     P1 -> P3     (after P5:  a (6) at [0..5])
+//   [18..23]  z (3), sl = p x z (3)             P1 -> P6
+//   [24..29]  c (6)                             P1 -> P6
+//   [30..32]  I^A[18..20]                       P3 -> P5
+//   [33..38]  p^A (6)                           P3 -> P5
+//   [39..44]  U (6)                             P5 -> P6
+//   [45..47]  1/D, u, qdd                       P5 -> P7
+// I^A as 21 floats: AA (xx,yy,zz,xy,xz,yz), AL (3x3 row-major: rows angular, columns linear), LL (xx,yy,zz,xy,xz,yz).
+constexpr int O_RP = 0, O_V = 12, O_S = 18, O_C = 24, O_IA2 = 30, O_PA = 33, O_U = 39, O_D = 45, O_A = 0;
+
+struct TreeDev {
+    int n_q, n_t, n_cr, n_levels, nsub, n_act;   // n_act: links some tendon ends on
+    int lw_shift, q_shift;           // log2 of the lane slots per env in the level passes / joint passes
+    int ES, o_W, o_SQD, o_SPU, zoff;        // env stride (floats, multiple of 4) and offsets inside an env's block (SQ aliases W)
+    int o_parent, o_order, o_level_start, o_child_start, o_child_list, o_lc_start, o_lc_list, o_act_link, o_t_cr_start,
+        o_link, o_tendon, o_cross;   // word offsets into the table buffer
+    float h, g[3], kps, pe_k2s, inv_pe_den, fv_c1l, fv_c2l, fv_c2s, fv_k;
+    const float4 *g_words;           // all tables as one device buffer of 32-bit words, staged to LDS per workgroup
+    int n_vec4;
+};
+
+struct TreeHost {
+    std::vector<uint32_t> words;
+    TreeDev dev;
+    size_t ws_floats_per_wave = 0;   // E * ES
+    size_t table_floats = 0;         // padded to 16 bytes
+};
+
+inline uint32_t f2w(double v) { const float f = float(v); uint32_t w; std::memcpy(&w, &f, 4); return w; }
+
+// Flatten the description; rest lengths and every derived constant in fp64.
+inline int tree_build(const rb_robot_desc *d, double step_size, int nsub, TreeHost &out, std::string &err) {
+    const int nq = d->n_q, nt = d->n_t, nvp = d->n_vp;
+    if (nq < 1 || nq > MAXQ) { err = "generic-tree kernel supports 1..32 joints"; return RB_EUNSUPPORTED; }
+    if (nt < 1 || nt > MAXT) { err = "generic-tree kernel supports 1..64 tendons"; return RB_EUNSUPPORTED; }
+    if (nvp > MAXVP) { err = "too many via-points"; return RB_EUNSUPPORTED; }
+    std::vector<int> level(nq), parent(d->parent, d->parent + nq);
+    int nlev = 0;
+    for (int i = 0; i < nq; ++i) {
+        if (parent[i] < -1 || parent[i] >= i) { err = "parent must be -1 or an earlier joint"; return RB_EINVAL; }
+        level[i] = parent[i] < 0 ? 0 : level[parent[i]] + 1;
+        nlev = level[i] + 1 > nlev ? level[i] + 1 : nlev;
+    }
+    std::vector<int> order, level_start(nlev + 1, 0), child_start(nq + 1, 0), child_list;
+    int max_width = 1;
+    for (int L = 0; L < nlev; ++L) {
+        level_start[L] = int(order.size());
+        for (int i = 0; i < nq; ++i) if (level[i] == L) order.push_back(i);
+        const int wdt = int(order.size()) - level_start[L];
+        max_width = wdt > max_width ? wdt : max_width;
+    }
+    level_start[nlev] = nq;
+    for (int i = 0; i < nq; ++i) {
+        child_start[i] = int(child_list.size());
+        for (int c = 0; c < nq; ++c) if (parent[c] == i) child_list.push_back(c);
+    }
+    child_start[nq] = int(child_list.size());
+    if (child_list.empty()) child_list.push_back(0);
+    // zero pose => every link frame is a pure translation: rest lengths, constant segments
+    std::vector<double> org(3 * nq);
+    for (int i = 0; i < nq; ++i)
+        for (int a = 0; a < 3; ++a) org[3 * i + a] = (parent[i] < 0 ? 0.0 : org[3 * parent[i] + a]) + d->origin[3 * i + a];
+    const double log2e = 1.4426950408889634;
+    const double sc = std::sqrt(log2e) / d->fl_width;     // strain scale: f_L = exp2(-(sc e)^2), as in msj_build.hpp
+    struct Cross { int la, lb; double ra[3], rb[3]; };
+    std::vector<Cross> cross;
+    std::vector<int> t_cr_start(nt + 1, 0);
+    std::vector<double> t_rec(size_t(nt) * TENDON_REC, 0.0);
+    for (int k = 0; k < nt; ++k) {
+        const int v0 = d->vp_offset[k], v1 = d->vp_offset[k + 1];
+        if (v1 - v0 < 2) { err = "tendon with fewer than two via-points"; return RB_EINVAL; }
+        double l0 = 0.0, lconst = 0.0;
+        t_cr_start[k] = int(cross.size());
+        for (int v = v0; v + 1 < v1; ++v) {
+            const int la = d->vp_link[v], lb = d->vp_link[v + 1];
+            if (la < -1 || la >= nq || lb < -1 || lb >= nq) { err = "via-point on an unknown link"; return RB_EINVAL; }
+            double s = 0.0, sl = 0.0;
+            for (int a = 0; a < 3; ++a) {
+                const double xa = (la < 0 ? 0.0 : org[3 * la + a]) + d->vp_pos[3 * v + a];
+                const double xb = (lb < 0 ? 0.0 : org[3 * lb + a]) + d->vp_pos[3 * (v + 1) + a];
+                s += (xb - xa) * (xb - xa);
+                const double dl = d->vp_pos[3 * (v + 1) + a] - d->vp_pos[3 * v + a];
+                sl += dl * dl;
+            }
+            if (s < 1e-12) { err = "degenerate tendon segment"; return RB_EINVAL; }
+            l0 += std::sqrt(s);
+            if (la == lb) {
+                lconst += std::sqrt(sl);        // both ends move with the same link: constant length, no net wrench
+            } else {
+                Cross c;
+                c.la = la; c.lb = lb;
+                for (int a = 0; a < 3; ++a) { c.ra[a] = d->vp_pos[3 * v + a]; c.rb[a] = d->vp_pos[3 * (v + 1) + a]; }
+                cross.push_back(c);
+            }
+        }
+        double *r = &t_rec[size_t(k) * TENDON_REC];
+        r[0] = sc / l0;                              // il0s
+        r[1] = sc * (lconst / l0 - 1.0);             // elcs
+        r[2] = d->kp * d->setpoint_scale / l0;       // ksg
+        r[3] = d->f_max[k];
+        r[4] = 1.0 / (d->v_max * l0);                // inv_vl0
+    }
+    t_cr_start[nt] = int(cross.size());
+    const int ncr = int(cross.size());
+    // P4's lists: for every link that a tendon ends on, the crossings incident to it with the sign
+    // of their wrench in p^A (fext_la += W, fext_lb -= W, p^A -= fext): entry = W offset (6 * crossing)
+    // << 1 | (1 if the link is lb, i.e. +W).  Links sorted by falling list length (lanes of one pass
+    // then loop about equally long), every list padded to a multiple of 4 with entries that point at
+    // the env block's zero slot (6 * n_cr), so the gather loop runs 4 independent loads per trip.
+    const int ncr_ = int(cross.size());
+    const int zoff = 6 * ncr_ > nq ? 6 * ncr_ : nq;      // zero slot: behind W and behind SQ, which aliases W's start
+    std::vector<std::vector<int>> inc(nq);
+    for (int c = 0; c < ncr_; ++c) {
+        if (cross[c].la >= 0) inc[cross[c].la].push_back((6 * c) << 1);
+        if (cross[c].lb >= 0) inc[cross[c].lb].push_back(((6 * c) << 1) | 1);
+    }
+    std::vector<int> act_link;
+    for (int i = 0; i < nq; ++i) if (!inc[i].empty()) act_link.push_back(i);
+    std::stable_sort(act_link.begin(), act_link.end(), [&](int a, int b) { return inc[a].size() > inc[b].size(); });
+    std::vector<int> lc_start, lc_list;     // lc_start: [n_act + 1], then act_link ids follow in their own table
+    for (int i : act_link) {
+        lc_start.push_back(int(lc_list.size()));
+        for (int en : inc[i]) lc_list.push_back(en);
+        while (lc_list.size() % 4) lc_list.push_back(zoff << 1);
+    }
+    lc_start.push_back(int(lc_list.size()));
+    const int n_act = int(act_link.size());
+    if (act_link.empty()) act_link.push_back(0);
+    if (lc_list.empty()) lc_list.assign(4, zoff << 1);
+
+    std::vector<uint32_t> &w = out.words;
+    w.clear();
+    auto pad4 = [&]() { while (w.size() % 4) w.push_back(0u); };
+    auto push_i = [&](const std::vector<int> &v) { pad4(); const int off = int(w.size()); for (int x : v) w.push_back(uint32_t(x)); return off; };
+    TreeDev &t = out.dev;
+    t.o_parent = push_i(parent); t.o_order = push_i(order); t.o_level_start = push_i(level_start);
+    t.o_child_start = push_i(child_start); t.o_child_list = push_i(child_list);
+    t.o_lc_start = push_i(lc_start); t.o_lc_list = push_i(lc_list); t.o_act_link = push_i(act_link);
+    t.o_t_cr_start = push_i(t_cr_start);
+    t.n_act = n_act;
+    pad4(); t.o_link = int(w.size());
+    for (int i = 0; i < nq; ++i) {
+        // axis 3, origin 3, com 3, inertia 6, mass, armature, damping, qlo, qhi, qdmax, pad 3
+        for (int a = 0; a < 3; ++a) w.push_back(f2w(d->axis[3 * i + a]));
+        for (int a = 0; a < 3; ++a) w.push_back(f2w(d->origin[3 * i + a]));
+        for (int a = 0; a < 3; ++a) w.push_back(f2w(d->com[3 * i + a]));
+        for (int a = 0; a < 6; ++a) w.push_back(f2w(d->inertia[6 * i + a]));
+        w.push_back(f2w(d->mass[i])); w.push_back(f2w(d->armature[i])); w.push_back(f2w(d->damping[i]));
+        w.push_back(f2w(d->q_lo[i])); w.push_back(f2w(d->q_hi[i])); w.push_back(f2w(d->qd_max[i]));
+        for (int a = 0; a < 3; ++a) w.push_back(0u);
+    }
+    pad4(); t.o_tendon = int(w.size());
+    for (double x : t_rec) w.push_back(f2w(x));
+    pad4(); t.o_cross = int(w.size());
+    for (const Cross &c : cross) {
+        w.push_back(uint32_t(c.la)); w.push_back(uint32_t(c.lb));
+        for (int a = 0; a < 3; ++a) w.push_back(f2w(c.ra[a]));
+        for (int a = 0; a < 3; ++a) w.push_back(f2w(c.rb[a]));
+    }
+    pad4();
+    out.table_floats = w.size();
+
+    t.n_q = nq; t.n_t = nt; t.n_cr = ncr; t.n_levels = nlev; t.nsub = nsub; t.h = float(step_size / nsub);
+    int lw = 1; t.lw_shift = 0;
+    while (lw < max_width) { lw <<= 1; ++t.lw_shift; }
+    int qw = 1; t.q_shift = 0;
+    while (qw < nq) { qw <<= 1; ++t.q_shift; }
+    // env block: links | W (6 per crossing, then a zero slot of 6; SQ aliases the start during P1) | SQD | SPU
+    const int wsz = zoff + 6;
+    t.zoff = zoff;
+    t.o_W = nq * LS;
+    t.o_SQD = t.o_W + wsz;
+    t.o_SPU = t.o_SQD + nq;
+    t.ES = (t.o_SPU + nt + 3) / 4 * 4;
+    if ((t.ES / 4) % 2 == 0) t.ES += 4;             // odd multiple of 16 bytes: envs start in different banks
+    for (int a = 0; a < 3; ++a) t.g[a] = float(d->gravity[a]);
+    t.kps = float(d->kp / sc);
+    t.pe_k2s = float(log2e * d->kpe / (d->e0 * sc));
+    t.inv_pe_den = float(1.0 / (std::exp(d->kpe) - 1.0));
+    const double c2l = (1.0 + 1.0 / d->fv_a) / (d->fv_n - 1.0);
+    t.fv_c2s = float(-1.0 / d->fv_a); t.fv_k = float(1.0 + 1.0 / d->fv_a);
+    t.fv_c1l = float(d->fv_n * c2l); t.fv_c2l = float(c2l);
+    t.g_words = nullptr; t.n_vec4 = int(w.size() / 4);
+    out.ws_floats_per_wave = size_t(TREE_E) * t.ES;
+    return RB_OK;
+}
+
+// dynamic LDS of a workgroup of `waves` waves
+inline size_t tree_lds_bytes(const TreeHost &h, int waves) { return 4 * (h.table_floats + size_t(waves) * h.ws_floats_per_wave); }
+
+// waves per workgroup (1..8) that keeps the most waves resident on a CU (160 KiB of LDS, one table copy per workgroup)
+inline int tree_pick_waves(const TreeHost &h) {
+    int best = 1, best_res = 0;
+    for (int wv = 1; wv <= 8; ++wv) {
+        const size_t bytes = tree_lds_bytes(h, wv);
+        if (bytes > 160 * 1024) break;
+        int wgs = int((160 * 1024) / bytes);
+        int res = wgs * wv;
+        if (res > 32) res = 32;
+        if (res > best_res || (res == best_res && wv < best)) { best_res = res; best = wv; }
+    }
+    return best;
+}
+
+// ------------------------------------------------------------------ device
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ V3 ld3(const float *p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(float *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+struct M3 { float m[9]; };   // row-major
+__device__ __forceinline__ V3 mul(const M3 &a, V3 v) {
+    return {a.m[0] * v.x + a.m[1] * v.y + a.m[2] * v.z, a.m[3] * v.x + a.m[4] * v.y + a.m[5] * v.z,
+            a.m[6] * v.x + a.m[7] * v.y + a.m[8] * v.z};
+}
+__device__ __forceinline__ V3 mulT(const M3 &a, V3 v) {   // a^T v
+    return {a.m[0] * v.x + a.m[3] * v.y + a.m[6] * v.z, a.m[1] * v.x + a.m[4] * v.y + a.m[7] * v.z,
+            a.m[2] * v.x + a.m[5] * v.y + a.m[8] * v.z};
+}
+__device__ __forceinline__ M3 mul(const M3 &a, const M3 &b) {
+    M3 o;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o.m[3 * r + c] = a.m[3 * r] * b.m[c] + a.m[3 * r + 1] * b.m[3 + c] + a.m[3 * r + 2] * b.m[6 + c];
+    return o;
+}
+// symmetric 3x3 as xx,yy,zz,xy,xz,yz
+__device__ __forceinline__ V3 symmul(const float *s, V3 v) {
+    return {s[0] * v.x + s[3] * v.y + s[4] * v.z, s[3] * v.x + s[1] * v.y + s[5] * v.z, s[4] * v.x + s[5] * v.y + s[2] * v.z};
+}
+
+// Phases of a wave exchange data through the wave's own LDS working set only.  LDS
+// instructions of one wave execute in issue order, so a later ds_read sees an earlier
+// ds_write of another lane of the same wave; all that is needed between phases is that
+// the compiler keeps that order.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// item `it` of a phase with C items per env -> (env slot, item); E is small: a compare chain beats a division
+template <int E>
+__device__ __forceinline__ void split(int it, int C, int &e, int &x) {
+    e = 0;
+#pragma unroll
+    for (int k = 1; k < E; ++k) e += (it >= k * C) ? 1 : 0;
+    x = it - e * C;
+}
+
+// one wave's view of the staged tables and of its envs' working sets
+struct Ctx {
+    const TreeDev &t;
+    const float *tab;     // LDS copy of the tables
+    float *ws;            // LDS working sets of this wave: E blocks of t.ES floats
+    int lane;
+    __device__ __forceinline__ int ti(int off) const { return __float_as_int(tab[off]); }
+    __device__ __forceinline__ float tf(int off) const { return tab[off]; }
+    __device__ __forceinline__ float *env(int e) const { return ws + e * t.ES; }
+    __device__ __forceinline__ float *link(int e, int i) const { return ws + e * t.ES + i * LS; }
+};
+
+// Copy the robot tables to LDS: 16-byte loads, issued in batches before their stores.
+__device__ __forceinline__ void stage_tables(const TreeDev &g, float *lds_tab, int tid, int nthreads) {
+    float4 *dst = reinterpret_cast<float4 *>(lds_tab);
+    for (int base = 0; base < g.n_vec4; base += 4 * nthreads) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = base + u * nthreads + tid;
+            v[u] = k < g.n_vec4 ? g.g_words[k] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = base + u * nthreads + tid;
+            if (k < g.n_vec4) dst[k] = v[u];
+        }
+    }
+    __syncthreads();
+}
+
+// ---- P1: one link: frame, joint axis, spatial velocity, velocity-product acceleration ----
+__device__ __forceinline__ void p1_link(const Ctx &c, int e, int i) {
+    const int par = c.ti(c.t.o_parent + i);
+    const float *rec = c.tab + c.t.o_link + i * LINK_REC;
+    float *me = c.link(e, i);
+    const float *sq = c.env(e) + c.t.o_W, *sqd = c.env(e) + c.t.o_SQD;
+    M3 Rp = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+    V3 pp = {0, 0, 0}, wp = {0, 0, 0}, vop = {0, 0, 0};
+    if (par >= 0) {
+        const float *pa = c.link(e, par);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rp.m[k] = pa[O_RP + k];
+        pp = ld3(pa + O_RP + 9); wp = ld3(pa + O_V); vop = ld3(pa + O_V + 3);
+    }
+    const V3 ax = ld3(rec), org = ld3(rec + 3);
+    const float qi = sq[i], qdi = sqd[i];
+    float sn, cs;
+    __sincosf(qi, &sn, &cs);
+    // Rodrigues: I + sin K + (1 - cos) K^2
+    const float oc = 1.0f - cs;
+    const M3 rot = {{1.0f - oc * (ax.y * ax.y + ax.z * ax.z), -sn * ax.z + oc * ax.x * ax.y, sn * ax.y + oc * ax.x * ax.z,
+                     sn * ax.z + oc * ax.x * ax.y, 1.0f - oc * (ax.x * ax.x + ax.z * ax.z), -sn * ax.x + oc * ax.y * ax.z,
+                     -sn * ax.y + oc * ax.x * ax.z, sn * ax.x + oc * ax.y * ax.z, 1.0f - oc * (ax.x * ax.x + ax.y * ax.y)}};
+    const M3 Ri = mul(Rp, rot);
+    const V3 pi = pp + mul(Rp, org);
+    const V3 zi = mul(Rp, ax);
+    const V3 sl = cross(pi, zi);
+    const V3 wi = wp + zi * qdi;
+    const V3 voi = vop + sl * qdi;
+    const V3 ca = cross(wp, zi) * qdi;                           // w_i x z_i = w_p x z_i
+    const V3 cl = (cross(wi, sl) + cross(voi, zi)) * qdi;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) me[O_RP + k] = Ri.m[k];
+    st3(me + O_RP + 9, pi); st3(me + O_V, wi); st3(me + O_V + 3, voi);
+    st3(me + O_S, zi); st3(me + O_S + 3, sl); st3(me + O_C, ca); st3(me + O_C + 3, cl);
+}
+
+// world position and velocity of a point fixed to `link` (local coordinates r); link < 0: the base
+__device__ __forceinline__ void point_on_link(const Ctx &c, int e, int link, V3 r, V3 &x, V3 &xd) {
+    if (link < 0) { x = r; xd = {0.0f, 0.0f, 0.0f}; return; }
+    const float *lk = c.link(e, link);
+    M3 R;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R.m[k] = lk[O_RP + k];
+    x = ld3(lk + O_RP + 9) + mul(R, r);
+    xd = ld3(lk + O_V + 3) + cross(ld3(lk + O_V), x);           // vO + w x x  (velocity about the world origin)
+}
+
+// ---- P2: one tendon: crossing geometry, Hill force, wrench of every crossing ----
+__device__ __forceinline__ void p2_tendon(const Ctx &c, int e, int k) {
+    const TreeDev &t = c.t;
+    const int c0 = c.ti(t.o_t_cr_start + k), c1 = c.ti(t.o_t_cr_start + k + 1);
+    float *W = c.env(e) + t.o_W;
+    float len = 0.0f, ldot = 0.0f;
+    for (int cr = c0; cr < c1; ++cr) {
+        const float *rec = c.tab + t.o_cross + cr * CROSS_REC;
+        const int la = __float_as_int(rec[0]), lb = __float_as_int(rec[1]);
+        V3 xa, va, xb, vb;
+        point_on_link(c, e, la, ld3(rec + 2), xa, va);
+        point_on_link(c, e, lb, ld3(rec + 5), xb, vb);
+        const V3 d = xb - xa;
+        const float d2 = dot(d, d), inv = __builtin_amdgcn_rsqf(d2);
+        const V3 u = d * inv;
+        len += d2 * inv;
+        ldot += dot(u, vb - va);
+        st3(W + 6 * cr, cross(xa, u)); st3(W + 6 * cr + 3, u);      // unit wrench; scaled by the tension below
+    }
+    const float *tr = c.tab + t.o_tendon + k * TENDON_REC;
+    const float es = len * tr[0] + tr[1];                             // scaled strain s (l/l0 - 1)
+    const float act = __builtin_amdgcn_fmed3f(t.kps * es - (c.env(e) + t.o_SPU)[k], 0.0f, 1.0f);
+    const float fl = __builtin_amdgcn_exp2f(-(es * es));
+    const float v = ldot * tr[4];
+    const float vp = fmaxf(v, 0.0f), p = __builtin_amdgcn_fmed3f(v + 1.0f, 0.0f, 1.0f);
+    const float num = t.fv_c1l * vp + p, den = t.fv_c2l * vp + (t.fv_c2s * p + t.fv_k);
+    const float fpe = fmaxf(__builtin_amdgcn_exp2f(t.pe_k2s * es) * t.inv_pe_den - t.inv_pe_den, 0.0f);
+    const float F = tr[3] * ((act * fl) * num * __builtin_amdgcn_rcpf(den) + fpe);
+    for (int cr = c0; cr < c1; ++cr) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) W[6 * cr + a] *= F;
+    }
+}
+
+// ---- P3: one link: spatial inertia about the world origin, bias force ----
+__device__ __forceinline__ void p3_link(const Ctx &c, int e, int i) {
+    const float *rec = c.tab + c.t.o_link + i * LINK_REC;
+    float *me = c.link(e, i);
+    const float m = rec[15];
+    const float *I6 = rec + 9;
+    float IA[21], pA[6];
+    if (m != 0.0f || I6[0] != 0.0f || I6[1] != 0.0f || I6[2] != 0.0f) {
+        M3 R;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R.m[k] = me[O_RP + k];
+        const V3 p = ld3(me + O_RP + 9), w = ld3(me + O_V), vo = ld3(me + O_V + 3);
+        const V3 cw = p + mul(R, ld3(rec + 6));
+        // Iw = R I R^T (symmetric)
+        M3 RI;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const V3 row = {R.m[3 * r], R.m[3 * r + 1], R.m[3 * r + 2]};
+            const V3 ri = symmul(I6, row);     // (R I)_row = I row (I symmetric)
+            RI.m[3 * r] = ri.x; RI.m[3 * r + 1] = ri.y; RI.m[3 * r + 2] = ri.z;
+        }
+        auto rowdot = [&](int r1, int r2) {
+            return RI.m[3 * r1] * R.m[3 * r2] + RI.m[3 * r1 + 1] * R.m[3 * r2 + 1] + RI.m[3 * r1 + 2] * R.m[3 * r2 + 2];
+        };
+        const float c2 = dot(cw, cw);
+        IA[0] = rowdot(0, 0) + m * (c2 - cw.x * cw.x); IA[1] = rowdot(1, 1) + m * (c2 - cw.y * cw.y);
+        IA[2] = rowdot(2, 2) + m * (c2 - cw.z * cw.z);
+        IA[3] = rowdot(0, 1) - m * cw.x * cw.y; IA[4] = rowdot(0, 2) - m * cw.x * cw.z; IA[5] = rowdot(1, 2) - m * cw.y * cw.z;
+        const V3 h = cw * m;
+        // AL = [h]x  (rows angular, columns linear)
+        IA[6] = 0.0f; IA[7] = -h.z; IA[8] = h.y; IA[9] = h.z; IA[10] = 0.0f; IA[11] = -h.x; IA[12] = -h.y; IA[13] = h.x; IA[14] = 0.0f;
+        IA[15] = m; IA[16] = m; IA[17] = m; IA[18] = 0.0f; IA[19] = 0.0f; IA[20] = 0.0f;
+        const V3 Iva = symmul(IA, w) + cross(h, vo), Ivl = vo * m - cross(h, w);
+        const V3 pa = cross(w, Iva) + cross(vo, Ivl), pl = cross(w, Ivl);
+        pA[0] = pa.x; pA[1] = pa.y; pA[2] = pa.z; pA[3] = pl.x; pA[4] = pl.y; pA[5] = pl.z;
+    } else {
+        // massless virtual link (the x / y joints of a ball joint)
+#pragma unroll
+        for (int k = 0; k < 21; ++k) IA[k] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pA[k] = 0.0f;
+    }
+    // all inputs are in registers: I^A[0..17] overwrites R, p, w, vO
+#pragma unroll
+    for (int k = 0; k < 18; ++k) me[k] = IA[k];
+#pragma unroll
+    for (int k = 18; k < 21; ++k) me[O_IA2 + k - 18] = IA[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) me[O_PA + k] = pA[k];
+}
+
+// ---- P5: one link of the backward pass ----
+__device__ __forceinline__ void p5_link(const Ctx &c, int e, int i) {
+    const TreeDev &t = c.t;
+    float *me = c.link(e, i);
+    float IA[21], pA[6];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) IA[k] = me[k];
+#pragma unroll
+    for (int k = 18; k < 21; ++k) IA[k] = me[O_IA2 + k - 18];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pA[k] = me[O_PA + k];
+    for (int idx = c.ti(t.o_child_start + i); idx < c.ti(t.o_child_start + i + 1); ++idx) {
+        const float *ch = c.link(e, c.ti(t.o_child_list + idx));
+#pragma unroll
+        for (int k = 0; k < 18; ++k) IA[k] += ch[k];
+#pragma unroll
+        for (int k = 18; k < 21; ++k) IA[k] += ch[O_IA2 + k - 18];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pA[k] += ch[O_PA + k];
+    }
+    const float *rec = c.tab + t.o_link + i * LINK_REC;
+    const V3 z = ld3(me + O_S), sl = ld3(me + O_S + 3);
+    const float *AA = IA, *AL = IA + 6, *LL = IA + 15;
+    M3 al;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) al.m[k] = AL[k];
+    const V3 Ua = symmul(AA, z) + mul(al, sl);
+    const V3 Ul = mulT(al, z) + symmul(LL, sl);
+    const float D = dot(z, Ua) + dot(sl, Ul) + rec[16];
+    const float invD = __builtin_amdgcn_rcpf(D);
+    const float qdi = (c.env(e) + t.o_SQD)[i];
+    const V3 pa = {pA[0], pA[1], pA[2]}, pl = {pA[3], pA[4], pA[5]};
+    const float u = -rec[17] * qdi - (dot(z, pa) + dot(sl, pl));
+    st3(me + O_U, Ua); st3(me + O_U + 3, Ul);
+    me[O_D] = invD; me[O_D + 1] = u;
+    if (c.ti(t.o_parent + i) >= 0) {
+        // I^a = I^A - U U^T / D ;  p^a = p^A + I^a c + U u / D  (left in place for the parent to gather)
+        const V3 Ka = Ua * invD, Kl = Ul * invD;
+        float Ia[21];
+        Ia[0] = AA[0] - Ka.x * Ua.x; Ia[1] = AA[1] - Ka.y * Ua.y; Ia[2] = AA[2] - Ka.z * Ua.z;
+        Ia[3] = AA[3] - Ka.x * Ua.y; Ia[4] = AA[4] - Ka.x * Ua.z; Ia[5] = AA[5] - Ka.y * Ua.z;
+        Ia[6] = AL[0] - Ka.x * Ul.x; Ia[7] = AL[1] - Ka.x * Ul.y; Ia[8] = AL[2] - Ka.x * Ul.z;
+        Ia[9] = AL[3] - Ka.y * Ul.x; Ia[10] = AL[4] - Ka.y * Ul.y; Ia[11] = AL[5] - Ka.y * Ul.z;
+        Ia[12] = AL[6] - Ka.z * Ul.x; Ia[13] = AL[7] - Ka.z * Ul.y; Ia[14] = AL[8] - Ka.z * Ul.z;
+        Ia[15] = LL[0] - Kl.x * Ul.x; Ia[16] = LL[1] - Kl.y * Ul.y; Ia[17] = LL[2] - Kl.z * Ul.z;
+        Ia[18] = LL[3] - Kl.x * Ul.y; Ia[19] = LL[4] - Kl.x * Ul.z; Ia[20] = LL[5] - Kl.y * Ul.z;
+        const V3 ca = ld3(me + O_C), cl = ld3(me + O_C + 3);
+        M3 ial;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) ial.m[k] = Ia[6 + k];
+        const float ud = u * invD;
+        const V3 na = pa + symmul(Ia, ca) + mul(ial, cl) + Ua * ud;
+        const V3 nl = pl + mulT(ial, ca) + symmul(Ia + 15, cl) + Ul * ud;
+#pragma unroll
+        for (int k = 0; k < 18; ++k) me[k] = Ia[k];
+#pragma unroll
+        for (int k = 18; k < 21; ++k) me[O_IA2 + k - 18] = Ia[k];
+        st3(me + O_PA, na); st3(me + O_PA + 3, nl);
+    }
+}
+
+// ---- P6: one link of the forward pass: spatial acceleration and qdd ----
+__device__ __forceinline__ void p6_link(const Ctx &c, int e, int i) {
+    const TreeDev &t = c.t;
+    float *me = c.link(e, i);
+    const int par = c.ti(t.o_parent + i);
+    V3 aa = {0.0f, 0.0f, 0.0f}, al = {-t.g[0], -t.g[1], -t.g[2]};       // base: fictitious acceleration -g
+    if (par >= 0) { const float *pa = c.link(e, par); aa = ld3(pa + O_A); al = ld3(pa + O_A + 3); }
+    aa = aa + ld3(me + O_C); al = al + ld3(me + O_C + 3);
+    const V3 Ua = ld3(me + O_U), Ul = ld3(me + O_U + 3);
+    const float qdd = (me[O_D + 1] - (dot(Ua, aa) + dot(Ul, al))) * me[O_D];
+    st3(me + O_A, aa + ld3(me + O_S) * qdd); st3(me + O_A + 3, al + ld3(me + O_S + 3) * qdd);
+    me[O_D + 2] = qdd;
+}
+
+template <int E> struct Passes { static constexpr int N = (E * MAXQ + 63) / 64; };
+
+// joint slot of pass p: (env slot, joint); false for padding slots
+template <int E>
+__device__ __forceinline__ bool joint_slot(const TreeDev &t, int lane, int p, int &e, int &j) {
+    const int slot = lane + 64 * p;
+    e = slot >> t.q_shift;
+    j = slot & ((1 << t.q_shift) - 1);
+    return e < E && j < t.n_q;
+}
+
+// qdd of the joints this lane owns (Passes<E>::N slots), from their q / qd
+template <int E>
+__device__ __forceinline__ void tree_accel(const Ctx &c, const float *qj, const float *vj, float *qdd) {
+    constexpr int NP = Passes<E>::N;
+    const TreeDev &t = c.t;
+    const int lane = c.lane;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        int e, j;
+        if (joint_slot<E>(t, lane, p, e, j)) { (c.env(e) + t.o_W)[j] = qj[p]; (c.env(e) + t.o_SQD)[j] = vj[p]; }
+    }
+    wave_sync();
+    const int lw = 1 << t.lw_shift;
+    // ---- P1: forward kinematics, one tree level at a time ----
+    for (int L = 0; L < ((RB_TREE_SKIP & 1) ? 0 : t.n_levels); ++L) {
+        const int a = c.ti(t.o_level_start + L), cnt = c.ti(t.o_level_start + L + 1) - a;
+        for (int slot = lane; slot < (E << t.lw_shift); slot += 64) {
+            const int e = slot >> t.lw_shift, x = slot & (lw - 1);
+            if (x < cnt) p1_link(c, e, c.ti(t.o_order + a + x));
+        }
+        wave_sync();
+    }
+    // ---- P2: tendons (SQ is dead: W overwrites it) ----
+    for (int it = lane; it < ((RB_TREE_SKIP & 2) ? 0 : E * t.n_t); it += 64) {
+        int e, k;
+        split<E>(it, t.n_t, e, k);
+        p2_tendon(c, e, k);
+    }
+    wave_sync();
+    // ---- P3: link inertias and bias forces ----
+    for (int it = lane; it < ((RB_TREE_SKIP & 4) ? 0 : E * t.n_q); it += 64) {
+        int e, i;
+        split<E>(it, t.n_q, e, i);
+        p3_link(c, e, i);
+    }
+    wave_sync();
+    // ---- P4: p^A -= tendon wrenches on the link; lanes = (link with tendons, env, component), link-major,
+    //      lists sorted by falling length and padded to 4: every trip is 4 independent loads, added in list order ----
+    for (int it = lane; it < ((RB_TREE_SKIP & 8) ? 0 : t.n_act * E * 6); it += 64) {
+        const int t2 = it / 6, comp = it - 6 * t2;
+        const int a = t2 / E, e = t2 - a * E;
+        const int i = c.ti(t.o_act_link + a);
+        const float *W = c.env(e) + t.o_W + comp;
+        float acc = 0.0f;
+        const int s0 = c.ti(t.o_lc_start + a), s1 = c.ti(t.o_lc_start + a + 1);
+        for (int idx = s0; idx < s1; idx += 4) {
+            const int4 en = *reinterpret_cast<const int4 *>(c.tab + t.o_lc_list + idx);
+            const float w0 = W[en.x >> 1], w1 = W[en.y >> 1], w2 = W[en.z >> 1], w3 = W[en.w >> 1];
+            acc += (en.x & 1) ? w0 : -w0;
+            acc += (en.y & 1) ? w1 : -w1;
+            acc += (en.z & 1) ? w2 : -w2;
+            acc += (en.w & 1) ? w3 : -w3;
+        }
+        c.link(e, i)[O_PA + comp] += acc;
+    }
+    wave_sync();
+    // ---- P5: articulated inertias, leaves to root ----
+    for (int L = ((RB_TREE_SKIP & 16) ? 0 : t.n_levels) - 1; L >= 0; --L) {
+        const int a = c.ti(t.o_level_start + L), cnt = c.ti(t.o_level_start + L + 1) - a;
+        for (int slot = lane; slot < (E << t.lw_shift); slot += 64) {
+            const int e = slot >> t.lw_shift, x = slot & (lw - 1);
+            if (x < cnt) p5_link(c, e, c.ti(t.o_order + a + x));
+        }
+        wave_sync();
+    }
+    // ---- P6: accelerations, root to leaves ----
+    for (int L = 0; L < ((RB_TREE_SKIP & 32) ? 0 : t.n_levels); ++L) {
+        const int a = c.ti(t.o_level_start + L), cnt = c.ti(t.o_level_start + L + 1) - a;
+        for (int slot = lane; slot < (E << t.lw_shift); slot += 64) {
+            const int e = slot >> t.lw_shift, x = slot & (lw - 1);
+            if (x < cnt) p6_link(c, e, c.ti(t.o_order + a + x));
+        }
+        wave_sync();
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        int e, j;
+        qdd[p] = joint_slot<E>(t, lane, p, e, j) ? c.link(e, j)[O_D + 2] : 0.0f;
+    }
+    wave_sync();
+}
+
+// one env step of the joints this lane owns: n_substeps integrator substeps with the
+// set-points held, velocity saturation and joint limits; ok[p] = false where a joint hit a limit
+template <int INTEG, int E>
+__device__ __forceinline__ void tree_integrate(const Ctx &c, float *qj, float *vj, bool *ok) {
+    constexpr int NP = Passes<E>::N;
+    const TreeDev &t = c.t;
+    float vmax[NP], lo[NP], hi[NP];
+    bool joint[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        int e, j;
+        joint[p] = joint_slot<E>(t, c.lane, p, e, j);
+        const float *rec = c.tab + t.o_link + (joint[p] ? j : 0) * LINK_REC;
+        vmax[p] = joint[p] ? rec[20] : 0.0f; lo[p] = joint[p] ? rec[18] : 0.0f; hi[p] = joint[p] ? rec[19] : 0.0f;
+        ok[p] = true;
+    }
+    // the zero slot behind W that pads P4's lists
+    if (c.lane < 6 * E) (c.env(c.lane / 6) + t.o_W + t.zoff)[c.lane % 6] = 0.0f;
+    const float h = t.h;
+    auto sat = [&](float v, int p) { return __builtin_amdgcn_fmed3f(v, -vmax[p], vmax[p]); };
+    for (int sub = 0; sub < t.nsub; ++sub) {
+        if (INTEG == 0) {
+            float a[NP];
+            tree_accel<E>(c, qj, vj, a);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { vj[p] = sat(vj[p] + h * a[p], p); qj[p] = qj[p] + h * vj[p]; }
+        } else {
+            const float hh = 0.5f * h, h6 = h * (1.0f / 6.0f);
+            float k1q[NP], k1v[NP], k2q[NP], k2v[NP], k3q[NP], k3v[NP], k4q[NP], k4v[NP], qs[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) k1q[p] = sat(vj[p], p);
+            tree_accel<E>(c, qj, k1q, k1v);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { k2q[p] = sat(vj[p] + hh * k1v[p], p); qs[p] = qj[p] + hh * k1q[p]; }
+            tree_accel<E>(c, qs, k2q, k2v);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { k3q[p] = sat(vj[p] + hh * k2v[p], p); qs[p] = qj[p] + hh * k2q[p]; }
+            tree_accel<E>(c, qs, k3q, k3v);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { k4q[p] = sat(vj[p] + h * k3v[p], p); qs[p] = qj[p] + h * k3q[p]; }
+            tree_accel<E>(c, qs, k4q, k4v);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                qj[p] = qj[p] + h6 * (k1q[p] + 2.0f * k2q[p] + 2.0f * k3q[p] + k4q[p]);
+                vj[p] = vj[p] + h6 * (k1v[p] + 2.0f * k2v[p] + 2.0f * k3v[p] + k4v[p]);
+            }
+        }
+        // velocity saturation + joint limits
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float v = sat(vj[p], p);
+            const bool over = qj[p] > hi[p], under = qj[p] < lo[p];
+            if (over) { qj[p] = hi[p]; v = fminf(v, 0.0f); }
+            if (under) { qj[p] = lo[p]; v = fmaxf(v, 0.0f); }
+            vj[p] = v;
+            ok[p] = ok[p] && !(joint[p] && (over || under));
+        }
+    }
+}
+
+// per-env AND of the joints' flags: lanes publish into LDS, one lane per env combines.
+// scratch: E * MAXQ floats at the start of env 0's W region (dead outside tree_accel) - any env block works
+template <int E>
+__device__ __forceinline__ bool env_all_ok(const Ctx &c, const bool *ok, int e_query) {
+    constexpr int NP = Passes<E>::N;
+    const TreeDev &t = c.t;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        int e, j;
+        if (joint_slot<E>(t, c.lane, p, e, j)) (c.env(e) + t.o_W)[j] = ok[p] ? 1.0f : 0.0f;
+    }
+    wave_sync();
+    bool all = true;
+    if (e_query >= 0) {
+        const float *f = c.env(e_query) + t.o_W;
+        for (int j = 0; j < t.n_q; ++j) all = all && (f[j] != 0.0f);
+    }
+    wave_sync();
+    return all;
+}
+
+template <int INTEG, int E>
+__global__ void __launch_bounds__(512)
+tree_step_aba(const TreeDev tg, float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
+              const float *__restrict__ act, float act_scale, long n) {
+    constexpr int NP = Passes<E>::N;
+    extern __shared__ float4 lds_raw4[];
+    float *lds = reinterpret_cast<float *>(lds_raw4);
+    stage_tables(tg, lds, threadIdx.x, blockDim.x);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const long env0 = (long(blockIdx.x) * nw + wave) * E;      // first env of this wave
+    if (env0 >= n) return;                                      // whole wave idle (no barrier follows)
+    const Ctx c{tg, lds, lds + 4 * tg.n_vec4 + wave * (E * tg.ES), lane};
+    // a slot past the end of the batch shadows the last env and stores nothing
+    float qj[NP], vj[NP];
+    bool ok[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        int e, j;
+        const bool js = joint_slot<E>(tg, lane, p, e, j);
+        const long env = env0 + e < n ? env0 + e : n - 1;
+        qj[p] = js ? q[long(j) * n + env] : 0.0f;
+        vj[p] = js ? qd[long(j) * n + env] : 0.0f;
+    }
+    // activation offsets u = ksg * set-point (what the tendon phase consumes), once per env step
+    for (int it = lane; it < E * tg.n_t; it += 64) {
+        int e, k;
+        split<E>(it, tg.n_t, e, k);
+        const long env = env0 + e < n ? env0 + e : n - 1;
+        (c.env(e) + tg.o_SPU)[k] = act[env * tg.n_t + k] * (act_scale * c.tf(tg.o_tendon + k * TENDON_REC + 2));
+    }
+    tree_integrate<INTEG, E>(c, qj, vj, ok);
+    const bool all_ok = env_all_ok<E>(c, ok, lane < E ? lane : -1);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        int e, j;
+        if (joint_slot<E>(tg, lane, p, e, j) && env0 + e < n) { q[long(j) * n + env0 + e] = qj[p]; qd[long(j) * n + env0 + e] = vj[p]; }
+    }
+    if (lane < E && env0 + lane < n) feas[env0 + lane] = all_ok ? 1u : 0u;
+}
+
+// RoboyEnv.step fused around the tree step (the env layer of roboy_sim.hip's
+// msj_env_step_kernel for joint-tree robots; same semantics): the lanes that
+// own joint (e, j) rescale nothing themselves - lanes (e, k) rescale action k - hold their
+// joint and its goal, publish (q - goal)^2 and qd^2 into LDS where lane e sums them in joint
+// order; lane e evaluates reward / done, publishes the decision, and the joint lanes draw
+// their own goal component on done.
+template <int INTEG, int E>
+__global__ void __launch_bounds__(512)
+tree_env_step_aba(const TreeDev tg, const rbe::EnvParams ep, const rbe::GoalBox box,
+                  float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
+                  float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
+                  uint32_t *__restrict__ goal_count, const float *__restrict__ act,
+                  float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
+                  double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt, uint32_t *__restrict__ infeas_n,
+                  long n, uint64_t seed, uint64_t env_id0) {
+    constexpr int NP = Passes<E>::N;
+    extern __shared__ float4 lds_raw4[];
+    float *lds = reinterpret_cast<float *>(lds_raw4);
+    stage_tables(tg, lds, threadIdx.x, blockDim.x);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const long env0 = (long(blockIdx.x) * nw + wave) * E;
+    if (env0 >= n) return;
+    const Ctx c{tg, lds, lds + 4 * tg.n_vec4 + wave * (E * tg.ES), lane};
+    const int nq = tg.n_q;
+    float qj[NP], vj[NP], gj[NP];
+    bool ok[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        int e, j;
+        const bool js = joint_slot<E>(tg, lane, p, e, j);
+        const long env = env0 + e < n ? env0 + e : n - 1;
+        qj[p] = js ? q[long(j) * n + env] : 0.0f;
+        vj[p] = js ? qd[long(j) * n + env] : 0.0f;
+        gj[p] = js ? goal[long(j) * n + env] : 0.0f;
+    }
+    for (int it = lane; it < E * tg.n_t; it += 64) {
+        int e, k;
+        split<E>(it, tg.n_t, e, k);
+        const long env = env0 + e < n ? env0 + e : n - 1;
+        // clamp to the action box, then slope * (x - in_high) + out_high with two roundings (roboy_env.py:157-158)
+        const float x = fminf(fmaxf(act[env * tg.n_t + k], -1.0f), 1.0f);
+        (c.env(e) + tg.o_SPU)[k] = rbe::mul_then_add(ep.slope, x - 1.0f, ep.act_hi) * c.tf(tg.o_tendon + k * TENDON_REC + 2);
+    }
+    tree_integrate<INTEG, E>(c, qj, vj, ok);
+    // publish the per-joint terms: W region, [0..nq) flags, [nq..2nq) dq^2, [2nq..3nq) qd^2  (6 n_cr >= ... not guaranteed:
+    // use the link blocks instead - they are dead here: link j's slots 0, 1, 2)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        int e, j;
+        if (joint_slot<E>(tg, lane, p, e, j)) {
+            float *lk = c.link(e, j);
+            const float dq = qj[p] - gj[p];
+            lk[0] = ok[p] ? 1.0f : 0.0f; lk[1] = dq * dq; lk[2] = vj[p] * vj[p];
+        }
+    }
+    wave_sync();
+    // lane e (< E) is the env's accountant
+    const bool acct = lane < E && env0 + lane < n;
+    const long me = env0 + (lane < E ? lane : 0);
+    bool all_ok = true, dn = false, reached = false;
+    float r = 0.0f;
+    uint32_t sn = 0u;
+    if (acct) {
+        float dq2 = 0.0f, dv2 = 0.0f;
+        for (int j = 0; j < nq; ++j) {
+            const float *lk = c.link(lane, j);
+            all_ok = all_ok && (lk[0] != 0.0f); dq2 += lk[1]; dv2 += lk[2];
+        }
+        sn = step_num[me] + 1u;
+        r = rbe::env_reward(ep, dq2, dv2, all_ok, reached);
+        dn = reached || (sn > uint32_t(ep.max_len));
+    }
+    wave_sync();
+    if (lane < E) c.link(lane, 0)[0] = (acct && dn) ? 1.0f : 0.0f;
+    wave_sync();
+    // joint lanes: observation, goal redraw on done, state write-back
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        int e, j;
+        if (!(joint_slot<E>(tg, lane, p, e, j) && env0 + e < n)) continue;
+        const long env = env0 + e;
+        const bool edn = c.link(e, 0)[0] != 0.0f;
+        float oq = qj[p], ov = vj[p], og = gj[p];
+        if (edn) {
+            const uint64_t gid = env_id0 + uint64_t(env);
+            const uint32_t draw = goal_count[env];         // read before the accountant lane bumps it (below, after a sync)
+            auto draw_goal = [&](uint32_t d) {
+                const rb::Philox4 rnd = rb::philox_draw(seed, gid, d, rb::STREAM_GOALS, uint32_t(j >> 2));
+                return rbe::goal_value(box.lo[j], box.hi[j], rnd.v[j & 3]);
+            };
+            gj[p] = draw_goal(draw);                        // RoboyEnv.step: _set_new_goal (:67-68)
+            if (ep.auto_reset) {                            // VecEnv worker: env.reset() (:82-87)
+                gj[p] = draw_goal(draw + 1u);
+                qj[p] = 0.0f; vj[p] = 0.0f; oq = 0.0f; ov = 0.0f; og = gj[p];
+            }
+            goal[long(j) * n + env] = gj[p];
+        }
+        q[long(j) * n + env] = qj[p]; qd[long(j) * n + env] = vj[p];
+        float *orow = obs + env * (3 * nq);
+        orow[j] = oq; orow[nq + j] = ov; orow[2 * nq + j] = og;
+    }
+    wave_sync();
+    if (acct) {
+        float ret = ep_ret[me] + r;
+        uint32_t fz = all_ok ? 1u : 0u;
+        if (dn) {
+            ep_sum[me] += double(ret); ep_sum[n + me] += double(ret) * double(ret);
+            ep_cnt[me] += 1u; ep_cnt[n + me] += sn - 1u; ep_cnt[2 * n + me] += reached ? 1u : 0u;
+            goal_count[me] += ep.auto_reset ? 2u : 1u;
+            if (ep.auto_reset) { sn = 1u; fz = 1u; }
+            ret = 0.0f;
+        }
+        feas[me] = fz; step_num[me] = sn; ep_ret[me] = ret; reward[me] = r; done[me] = dn ? 1u : 0u;
+        if (!all_ok) infeas_n[me] += 1u;
+    }
+}
+
+// reset of the env layer for any n_q: zero pose, counter 1, a fresh goal, reset observation
+__global__ void tree_env_reset_kernel(const rbe::GoalBox box, float *q, float *qd, uint32_t *feas, float *goal,
+                                      uint32_t *step_num, float *ep_ret, uint32_t *goal_count, float *obs,
+                                      int n_q, long n, uint64_t seed, uint64_t env0) {
+    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t draw = goal_count[i];
+    goal_count[i] = draw + 1u;
+    for (int b = 0; 4 * b < n_q; ++b) {
+        const rb::Philox4 r = rb::philox_draw(seed, env0 + uint64_t(i), draw, rb::STREAM_GOALS, uint32_t(b));
+        for (int k = 0; k < 4 && 4 * b + k < n_q; ++k) {
+            const int j = 4 * b + k;
+            const float g = rbe::goal_value(box.lo[j], box.hi[j], r.v[k]);
+            q[j * n + i] = 0.0f; qd[j * n + i] = 0.0f; goal[j * n + i] = g;
+            if (obs) { obs[i * 3 * n_q + j] = 0.0f; obs[i * 3 * n_q + n_q + j] = 0.0f; obs[i * 3 * n_q + 2 * n_q + j] = g; }
+        }
+    }
+    feas[i] = 1u; step_num[i] = 1u; ep_ret[i] = 0.0f;
+}
+
+}  // namespace rbt

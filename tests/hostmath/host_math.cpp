@@ -33,7 +33,9 @@ static int run(const rb_robot_desc *d, double step_size, int nsub, int integ, lo
     if (rc) return rc;
     const int nt = d->n_t;
     for (long i = 0; i < n; ++i) {
-        const SpRow<T> row{sp + nt * i};
+        T u[16];
+        for (int k = 0; k < nt; ++k) u[k] = rb::MsjModel<T, 16>::prescale(c, k, sp[nt * i + k]);   // activation offsets
+        const SpRow<T> row{u};
         bool ok = integ == 0 ? rb::MsjModel<T, 16>::template step_sp<0, 0>(c, q + 3 * i, qd + 3 * i, row)
                              : rb::MsjModel<T, 16>::template step_sp<1, 0>(c, q + 3 * i, qd + 3 * i, row);
         feas[i] = ok ? 1 : 0;

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Round 2, first GPU pass: GPU test suite, the bench line as the driver runs it (--steps 20) and with defaults.
+set -o pipefail
+cd /root/repo
+OUT=/root/repo/gpurun_out
+mkdir -p $OUT
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -5 $OUT/pytest_gpu.log
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err; echo "bench20 rc=$?"
+timeout -k 10 400 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
