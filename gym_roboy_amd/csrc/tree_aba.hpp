@@ -60,26 +60,29 @@ constexpr int MAXVP = 1024; // via-points
 #define RB_TREE_SKIP 0      // timing-only builds: bit k set = phase P(k+1) left out (results wrong by construction)
 #endif
 constexpr int TREE_E = RB_TREE_E;   // envs per wave
-constexpr int LS = 48;      // floats per link in an env's working set (layout below)
-constexpr int LINK_REC = 24, TENDON_REC = 8, CROSS_REC = 8;
+constexpr int LS = 63;      // floats per link in an env's working set (layout below); odd: lanes that hold
+                            // different links of an env hit different LDS banks (a stride of 64 or 48 floats
+                            // cost 20- and 10-way conflicts in the per-link phases)
+constexpr int LINK_REC = 24, TENDON_REC = 8, CROSS_REC = 8, LEVEL_REC = 16;
 
 // Link block (LS floats), by phase:
-//   [ 0..11]  R (9, row-major), p (3)          P1 -> P3     then  I^A[0..17] spans [0..17]   P3 -> P5
-//   [12..17]  w (3), vO (3)                     P1 -> P3     (after P5:  a (6) at [0..5])
-//   [18..23]  z (3), sl = p x z (3)             P1 -> P6
-//   [24..29]  c (6)                             P1 -> P6
-//   [30..32]  I^A[18..20]                       P3 -> P5
-//   [33..38]  p^A (6)                           P3 -> P5
-//   [39..44]  U (6)                             P5 -> P6
-//   [45..47]  1/D, u, qdd                       P5 -> P7
-// I^A as 21 floats: AA (xx,yy,zz,xy,xz,yz), AL (3x3 row-major: rows angular, columns linear), LL (xx,yy,zz,xy,xz,yz).
-constexpr int O_RP = 0, O_V = 12, O_S = 18, O_C = 24, O_IA2 = 30, O_PA = 33, O_U = 39, O_D = 45, O_A = 0;
+//   [ 0..11]  R (9, row-major), p (3)          P1 -> P3  }  then I^A, full 6x6, row r at [6r..6r+5]   P3 -> P5
+//   [12..17]  w (3), vO (3)                     P1 -> P3  }  (after P5:  a (6) at [0..5])
+//   [36..41]  z (3), sl = p x z (3)             P1 -> P6
+//   [42..47]  c (6)                             P1 -> P6
+//   [48..53]  p^A (6)                           P3 -> P5
+//   [54..59]  U (6)                             P5 -> P6
+//   [60..62]  1/D, u, qdd                       P5 -> P7
+// I^A rows / columns: 0-2 angular, 3-5 linear.  The level passes (P1, P5, P6) give every link an OCTET of
+// lanes: lane r of the octet owns row r of the link's 6x6 / component r of its vectors; the octet exchanges
+// values by DPP (quad rotations, 8-lane sums) and, once per link, through the link's own LDS block.
+constexpr int O_RP = 0, O_V = 12, O_IA = 0, O_S = 36, O_C = 42, O_PA = 48, O_U = 54, O_D = 60, O_A = 0;
 
 struct TreeDev {
     int n_q, n_t, n_cr, n_levels, nsub, n_act;   // n_act: links some tendon ends on
     int lw_shift, q_shift;           // log2 of the lane slots per env in the level passes / joint passes
-    int ES, o_W, o_SQD, o_SPU, zoff;        // env stride (floats, multiple of 4) and offsets inside an env's block (SQ aliases W)
-    int o_parent, o_order, o_level_start, o_child_start, o_child_list, o_lc_start, o_lc_list, o_act_link, o_t_cr_start,
+    int ES, o_W, o_SQD, o_SPU, zoff;   // env stride (floats) and offsets inside an env's block (SQ aliases W)
+    int o_parent, o_order, o_level_start, o_child_start, o_child_list, o_lc_start, o_lc_list, o_act_link, o_t_cr_start, o_level,
         o_link, o_tendon, o_cross;   // word offsets into the table buffer
     float h, g[3], kps, pe_k2s, inv_pe_den, fv_c1l, fv_c2l, fv_c2s, fv_k;
     const float4 *g_words;           // all tables as one device buffer of 32-bit words, staged to LDS per workgroup
@@ -205,6 +208,26 @@ inline int tree_build(const rb_robot_desc *d, double step_size, int nsub, TreeHo
     t.o_lc_start = push_i(lc_start); t.o_lc_list = push_i(lc_list); t.o_act_link = push_i(act_link);
     t.o_t_cr_start = push_i(t_cr_start);
     t.n_act = n_act;
+    // level records: one per (level, slot x < lane width of the level passes), 16 words:
+    // i (-1: empty slot), parent, n_children, child_start, child 0..3, axis 3, origin 3, armature, damping
+    {
+        int lwid = 1;
+        while (lwid < max_width) lwid <<= 1;
+        pad4(); t.o_level = int(w.size());
+        for (int L = 0; L < nlev; ++L)
+            for (int x = 0; x < lwid; ++x) {
+                const int pos = level_start[L] + x;
+                const bool used = pos < level_start[L + 1];
+                const int i = used ? order[pos] : -1;
+                w.push_back(uint32_t(i)); w.push_back(uint32_t(used ? parent[i] : -1));
+                const int cs = used ? child_start[i] : 0, nch = used ? child_start[i + 1] - cs : 0;
+                w.push_back(uint32_t(nch)); w.push_back(uint32_t(cs));
+                for (int k = 0; k < 4; ++k) w.push_back(uint32_t(k < nch ? child_list[cs + k] : 0));
+                for (int a = 0; a < 3; ++a) w.push_back(f2w(used ? d->axis[3 * i + a] : 0.0));
+                for (int a = 0; a < 3; ++a) w.push_back(f2w(used ? d->origin[3 * i + a] : 0.0));
+                w.push_back(f2w(used ? d->armature[i] : 1.0)); w.push_back(f2w(used ? d->damping[i] : 0.0));
+            }
+    }
     pad4(); t.o_link = int(w.size());
     for (int i = 0; i < nq; ++i) {
         // axis 3, origin 3, com 3, inertia 6, mass, armature, damping, qlo, qhi, qdmax, pad 3
@@ -238,8 +261,8 @@ inline int tree_build(const rb_robot_desc *d, double step_size, int nsub, TreeHo
     t.o_W = nq * LS;
     t.o_SQD = t.o_W + wsz;
     t.o_SPU = t.o_SQD + nq;
-    t.ES = (t.o_SPU + nt + 3) / 4 * 4;
-    if ((t.ES / 4) % 2 == 0) t.ES += 4;             // odd multiple of 16 bytes: envs start in different banks
+    t.ES = t.o_SPU + nt;
+    while (t.ES % 32 != 17) ++t.ES;                 // the envs of a wave start 17 banks apart
     for (int a = 0; a < 3; ++a) t.g[a] = float(d->gravity[a]);
     t.kps = float(d->kp / sc);
     t.pe_k2s = float(log2e * d->kpe / (d->e0 * sc));
@@ -310,6 +333,21 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// lanes 0,1,2 of a quad hold components 0,1,2 of a vector: component (r+1)%3 and (r+2)%3 of the own lane r
+__device__ __forceinline__ float rot1(float v) { return dpp<0xC9>(v); }   // quad_perm [1,2,0,3]
+__device__ __forceinline__ float rot2(float v) { return dpp<0xD2>(v); }   // quad_perm [2,0,1,3]
+// sum over the 8 lanes of an octet, result in every lane: quad_perm(1,0,3,2), quad_perm(2,3,0,1), row_half_mirror
+__device__ __forceinline__ float sum8(float v) {
+    v += dpp<0xB1>(v);
+    v += dpp<0x4E>(v);
+    v += dpp<0x141>(v);
+    return v;
+}
+
 // item `it` of a phase with C items per env -> (env slot, item); E is small: a compare chain beats a division
 template <int E>
 __device__ __forceinline__ void split(int it, int C, int &e, int &x) {
@@ -350,41 +388,55 @@ __device__ __forceinline__ void stage_tables(const TreeDev &g, float *lds_tab, i
     __syncthreads();
 }
 
-// ---- P1: one link: frame, joint axis, spatial velocity, velocity-product acceleration ----
-__device__ __forceinline__ void p1_link(const Ctx &c, int e, int i) {
-    const int par = c.ti(c.t.o_parent + i);
-    const float *rec = c.tab + c.t.o_link + i * LINK_REC;
-    float *me = c.link(e, i);
+// level record of slot (L, x): 16 words, 4 x b128
+struct LevelRec { int i, par, nch, cs, ch[4]; float ax[3], org[3], arm, damp; };
+__device__ __forceinline__ LevelRec load_level(const Ctx &c, int L, int x) {
+    const float4 *p = reinterpret_cast<const float4 *>(c.tab + c.t.o_level + (((L << c.t.lw_shift) + x) * LEVEL_REC));
+    const float4 a = p[0], b = p[1], d = p[2], f = p[3];
+    LevelRec r;
+    r.i = __float_as_int(a.x); r.par = __float_as_int(a.y); r.nch = __float_as_int(a.z); r.cs = __float_as_int(a.w);
+    r.ch[0] = __float_as_int(b.x); r.ch[1] = __float_as_int(b.y); r.ch[2] = __float_as_int(b.z); r.ch[3] = __float_as_int(b.w);
+    r.ax[0] = d.x; r.ax[1] = d.y; r.ax[2] = d.z; r.org[0] = d.w; r.org[1] = f.x; r.org[2] = f.y; r.arm = f.z; r.damp = f.w;
+    return r;
+}
+
+// ---- P1, lane r of the link's octet: row r3 = r % 3 of the frame, component r3 of the vectors.
+//      Lanes 0-2 store; the other lanes of the octet compute the same rows again (their quads rotate alike). ----
+__device__ __forceinline__ void p1_octet(const Ctx &c, int e, int r, const LevelRec &lr) {
+    const int r3 = r >= 6 ? r - 6 : (r >= 3 ? r - 3 : r), n1 = r3 == 2 ? 0 : r3 + 1, n2 = r3 == 0 ? 2 : r3 - 1;
+    float *me = c.link(e, lr.i);
     const float *sq = c.env(e) + c.t.o_W, *sqd = c.env(e) + c.t.o_SQD;
-    M3 Rp = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
-    V3 pp = {0, 0, 0}, wp = {0, 0, 0}, vop = {0, 0, 0};
-    if (par >= 0) {
-        const float *pa = c.link(e, par);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Rp.m[k] = pa[O_RP + k];
-        pp = ld3(pa + O_RP + 9); wp = ld3(pa + O_V); vop = ld3(pa + O_V + 3);
+    // row r3 of the parent's frame, the parent's origin / velocity components this lane needs
+    V3 Rrow = {r3 == 0 ? 1.0f : 0.0f, r3 == 1 ? 1.0f : 0.0f, r3 == 2 ? 1.0f : 0.0f};
+    float pp = 0.0f, wp0 = 0.0f, wp1 = 0.0f, wp2 = 0.0f, vop = 0.0f;
+    if (lr.par >= 0) {
+        const float *pa = c.link(e, lr.par);
+        Rrow = ld3(pa + O_RP + 3 * r3);
+        pp = pa[O_RP + 9 + r3]; wp0 = pa[O_V + r3]; wp1 = pa[O_V + n1]; wp2 = pa[O_V + n2]; vop = pa[O_V + 3 + r3];
     }
-    const V3 ax = ld3(rec), org = ld3(rec + 3);
-    const float qi = sq[i], qdi = sqd[i];
+    const V3 ax = {lr.ax[0], lr.ax[1], lr.ax[2]}, org = {lr.org[0], lr.org[1], lr.org[2]};
+    const float qi = sq[lr.i], qdi = sqd[lr.i];
     float sn, cs;
     __sincosf(qi, &sn, &cs);
     // Rodrigues: I + sin K + (1 - cos) K^2
     const float oc = 1.0f - cs;
-    const M3 rot = {{1.0f - oc * (ax.y * ax.y + ax.z * ax.z), -sn * ax.z + oc * ax.x * ax.y, sn * ax.y + oc * ax.x * ax.z,
-                     sn * ax.z + oc * ax.x * ax.y, 1.0f - oc * (ax.x * ax.x + ax.z * ax.z), -sn * ax.x + oc * ax.y * ax.z,
-                     -sn * ax.y + oc * ax.x * ax.z, sn * ax.x + oc * ax.y * ax.z, 1.0f - oc * (ax.x * ax.x + ax.y * ax.y)}};
-    const M3 Ri = mul(Rp, rot);
-    const V3 pi = pp + mul(Rp, org);
-    const V3 zi = mul(Rp, ax);
-    const V3 sl = cross(pi, zi);
-    const V3 wi = wp + zi * qdi;
-    const V3 voi = vop + sl * qdi;
-    const V3 ca = cross(wp, zi) * qdi;                           // w_i x z_i = w_p x z_i
-    const V3 cl = (cross(wi, sl) + cross(voi, zi)) * qdi;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) me[O_RP + k] = Ri.m[k];
-    st3(me + O_RP + 9, pi); st3(me + O_V, wi); st3(me + O_V + 3, voi);
-    st3(me + O_S, zi); st3(me + O_S + 3, sl); st3(me + O_C, ca); st3(me + O_C + 3, cl);
+    const V3 c0 = {1.0f - oc * (ax.y * ax.y + ax.z * ax.z), sn * ax.z + oc * ax.x * ax.y, -sn * ax.y + oc * ax.x * ax.z};   // columns of rot
+    const V3 c1 = {-sn * ax.z + oc * ax.x * ax.y, 1.0f - oc * (ax.x * ax.x + ax.z * ax.z), sn * ax.x + oc * ax.y * ax.z};
+    const V3 c2 = {sn * ax.y + oc * ax.x * ax.z, -sn * ax.x + oc * ax.y * ax.z, 1.0f - oc * (ax.x * ax.x + ax.y * ax.y)};
+    const V3 Ri = {dot(Rrow, c0), dot(Rrow, c1), dot(Rrow, c2)};      // row r3 of R_p rot
+    const float p = pp + dot(Rrow, org);                              // component r3 of p_i
+    const float z = dot(Rrow, ax);                                    // ... of the joint axis
+    const float p1 = rot1(p), p2 = rot2(p), z1 = rot1(z), z2 = rot2(z);
+    const float sl = p1 * z2 - p2 * z1;                               // (p x z)[r3]
+    const float w = wp0 + z * qdi, vo = vop + sl * qdi;
+    const float ca = (wp1 * z2 - wp2 * z1) * qdi;                     // (w_p x z)[r3] qd   (w_i x z_i = w_p x z_i)
+    const float w1 = rot1(w), w2 = rot2(w), sl1 = rot1(sl), sl2 = rot2(sl), vo1 = rot1(vo), vo2 = rot2(vo);
+    const float cl = ((w1 * sl2 - w2 * sl1) + (vo1 * z2 - vo2 * z1)) * qdi;   // (w x sl + vO x z)[r3] qd
+    if (r < 3) {
+        st3(me + O_RP + 3 * r3, Ri);
+        me[O_RP + 9 + r3] = p; me[O_V + r3] = w; me[O_V + 3 + r3] = vo;
+        me[O_S + r3] = z; me[O_S + 3 + r3] = sl; me[O_C + r3] = ca; me[O_C + 3 + r3] = cl;
+    }
 }
 
 // world position and velocity of a point fixed to `link` (local coordinates r); link < 0: the base
@@ -474,88 +526,86 @@ __device__ __forceinline__ void p3_link(const Ctx &c, int e, int i) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) pA[k] = 0.0f;
     }
-    // all inputs are in registers: I^A[0..17] overwrites R, p, w, vO
+    // all inputs are in registers: the 6x6 overwrites R, p, w, vO.  IA (21) = AA sym, AL 3x3, LL sym
+    const float *AA = IA, *AL = IA + 6, *LL = IA + 15;
+    const float rows[36] = {AA[0], AA[3], AA[4], AL[0], AL[1], AL[2],
+                            AA[3], AA[1], AA[5], AL[3], AL[4], AL[5],
+                            AA[4], AA[5], AA[2], AL[6], AL[7], AL[8],
+                            AL[0], AL[3], AL[6], LL[0], LL[3], LL[4],
+                            AL[1], AL[4], AL[7], LL[3], LL[1], LL[5],
+                            AL[2], AL[5], AL[8], LL[4], LL[5], LL[2]};
 #pragma unroll
-    for (int k = 0; k < 18; ++k) me[k] = IA[k];
-#pragma unroll
-    for (int k = 18; k < 21; ++k) me[O_IA2 + k - 18] = IA[k];
+    for (int k = 0; k < 36; ++k) me[O_IA + k] = rows[k];
 #pragma unroll
     for (int k = 0; k < 6; ++k) me[O_PA + k] = pA[k];
 }
 
-// ---- P5: one link of the backward pass ----
-__device__ __forceinline__ void p5_link(const Ctx &c, int e, int i) {
+// ---- P5, lane r of the link's octet: row r of I^A / component r of p^A (lanes 6, 7 idle along) ----
+__device__ __forceinline__ void p5_octet(const Ctx &c, int e, int r, const LevelRec &lr) {
     const TreeDev &t = c.t;
-    float *me = c.link(e, i);
-    float IA[21], pA[6];
+    const int rr = r < 6 ? r : 5;
+    const bool row_lane = r < 6;
+    float *me = c.link(e, lr.i);
+    float row[6], pa;
 #pragma unroll
-    for (int k = 0; k < 18; ++k) IA[k] = me[k];
+    for (int k = 0; k < 6; ++k) row[k] = me[O_IA + 6 * rr + k];
+    pa = me[O_PA + rr];
+    auto add_child = [&](int ch) {
+        const float *cb = c.link(e, ch);
 #pragma unroll
-    for (int k = 18; k < 21; ++k) IA[k] = me[O_IA2 + k - 18];
+        for (int k = 0; k < 6; ++k) row[k] += cb[O_IA + 6 * rr + k];
+        pa += cb[O_PA + rr];
+    };
+    if (lr.nch > 0) add_child(lr.ch[0]);
+    if (lr.nch > 1) add_child(lr.ch[1]);
+    if (lr.nch > 2) add_child(lr.ch[2]);
+    if (lr.nch > 3) add_child(lr.ch[3]);
+    for (int k = 4; k < lr.nch; ++k) add_child(c.ti(t.o_child_list + lr.cs + k));
+    float s[6], cc[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) pA[k] = me[O_PA + k];
-    for (int idx = c.ti(t.o_child_start + i); idx < c.ti(t.o_child_start + i + 1); ++idx) {
-        const float *ch = c.link(e, c.ti(t.o_child_list + idx));
+    for (int k = 0; k < 6; ++k) { s[k] = me[O_S + k]; cc[k] = me[O_C + k]; }
+    const float qdi = (c.env(e) + t.o_SQD)[lr.i];
+    float U = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 18; ++k) IA[k] += ch[k];
-#pragma unroll
-        for (int k = 18; k < 21; ++k) IA[k] += ch[O_IA2 + k - 18];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) pA[k] += ch[O_PA + k];
-    }
-    const float *rec = c.tab + t.o_link + i * LINK_REC;
-    const V3 z = ld3(me + O_S), sl = ld3(me + O_S + 3);
-    const float *AA = IA, *AL = IA + 6, *LL = IA + 15;
-    M3 al;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) al.m[k] = AL[k];
-    const V3 Ua = symmul(AA, z) + mul(al, sl);
-    const V3 Ul = mulT(al, z) + symmul(LL, sl);
-    const float D = dot(z, Ua) + dot(sl, Ul) + rec[16];
+    for (int k = 0; k < 6; ++k) U += row[k] * s[k];
+    const float sr = row_lane ? me[O_S + rr] : 0.0f;                     // s_r (0 in the idle lanes: they add nothing)
+    const float D = sum8(sr * U) + lr.arm;
+    const float T = sum8(sr * pa);
     const float invD = __builtin_amdgcn_rcpf(D);
-    const float qdi = (c.env(e) + t.o_SQD)[i];
-    const V3 pa = {pA[0], pA[1], pA[2]}, pl = {pA[3], pA[4], pA[5]};
-    const float u = -rec[17] * qdi - (dot(z, pa) + dot(sl, pl));
-    st3(me + O_U, Ua); st3(me + O_U + 3, Ul);
-    me[O_D] = invD; me[O_D + 1] = u;
-    if (c.ti(t.o_parent + i) >= 0) {
-        // I^a = I^A - U U^T / D ;  p^a = p^A + I^a c + U u / D  (left in place for the parent to gather)
-        const V3 Ka = Ua * invD, Kl = Ul * invD;
-        float Ia[21];
-        Ia[0] = AA[0] - Ka.x * Ua.x; Ia[1] = AA[1] - Ka.y * Ua.y; Ia[2] = AA[2] - Ka.z * Ua.z;
-        Ia[3] = AA[3] - Ka.x * Ua.y; Ia[4] = AA[4] - Ka.x * Ua.z; Ia[5] = AA[5] - Ka.y * Ua.z;
-        Ia[6] = AL[0] - Ka.x * Ul.x; Ia[7] = AL[1] - Ka.x * Ul.y; Ia[8] = AL[2] - Ka.x * Ul.z;
-        Ia[9] = AL[3] - Ka.y * Ul.x; Ia[10] = AL[4] - Ka.y * Ul.y; Ia[11] = AL[5] - Ka.y * Ul.z;
-        Ia[12] = AL[6] - Ka.z * Ul.x; Ia[13] = AL[7] - Ka.z * Ul.y; Ia[14] = AL[8] - Ka.z * Ul.z;
-        Ia[15] = LL[0] - Kl.x * Ul.x; Ia[16] = LL[1] - Kl.y * Ul.y; Ia[17] = LL[2] - Kl.z * Ul.z;
-        Ia[18] = LL[3] - Kl.x * Ul.y; Ia[19] = LL[4] - Kl.x * Ul.z; Ia[20] = LL[5] - Kl.y * Ul.z;
-        const V3 ca = ld3(me + O_C), cl = ld3(me + O_C + 3);
-        M3 ial;
+    const float u = -lr.damp * qdi - T;
+    if (row_lane) me[O_U + rr] = U;
+    if (r == 0) { me[O_D] = invD; me[O_D + 1] = u; }
+    if (lr.par >= 0) {
+        // I^a = I^A - U U^T / D ;  p^a = p^A + I^a c + U u / D, left in place for the parent's octet to gather.
+        // The row needs all of U: through the block (LDS instructions of a wave execute in order)
+        wave_sync();
+        const float K = U * invD;
+        float acc = pa + U * (u * invD);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) ial.m[k] = Ia[6 + k];
-        const float ud = u * invD;
-        const V3 na = pa + symmul(Ia, ca) + mul(ial, cl) + Ua * ud;
-        const V3 nl = pl + mulT(ial, ca) + symmul(Ia + 15, cl) + Ul * ud;
-#pragma unroll
-        for (int k = 0; k < 18; ++k) me[k] = Ia[k];
-#pragma unroll
-        for (int k = 18; k < 21; ++k) me[O_IA2 + k - 18] = Ia[k];
-        st3(me + O_PA, na); st3(me + O_PA + 3, nl);
+        for (int k = 0; k < 6; ++k) {
+            const float ia = row[k] - K * me[O_U + k];
+            acc += ia * cc[k];
+            if (row_lane) me[O_IA + 6 * rr + k] = ia;
+        }
+        if (row_lane) me[O_PA + rr] = acc;
     }
 }
 
-// ---- P6: one link of the forward pass: spatial acceleration and qdd ----
-__device__ __forceinline__ void p6_link(const Ctx &c, int e, int i) {
+// ---- P6, lane r of the link's octet: component r of the spatial acceleration; qdd by an octet sum ----
+__device__ __forceinline__ void p6_octet(const Ctx &c, int e, int r, const LevelRec &lr) {
     const TreeDev &t = c.t;
-    float *me = c.link(e, i);
-    const int par = c.ti(t.o_parent + i);
-    V3 aa = {0.0f, 0.0f, 0.0f}, al = {-t.g[0], -t.g[1], -t.g[2]};       // base: fictitious acceleration -g
-    if (par >= 0) { const float *pa = c.link(e, par); aa = ld3(pa + O_A); al = ld3(pa + O_A + 3); }
-    aa = aa + ld3(me + O_C); al = al + ld3(me + O_C + 3);
-    const V3 Ua = ld3(me + O_U), Ul = ld3(me + O_U + 3);
-    const float qdd = (me[O_D + 1] - (dot(Ua, aa) + dot(Ul, al))) * me[O_D];
-    st3(me + O_A, aa + ld3(me + O_S) * qdd); st3(me + O_A + 3, al + ld3(me + O_S + 3) * qdd);
-    me[O_D + 2] = qdd;
+    const int rr = r < 6 ? r : 5;
+    const bool row_lane = r < 6;
+    float *me = c.link(e, lr.i);
+    float a = rr < 3 ? 0.0f : -(rr == 3 ? t.g[0] : (rr == 4 ? t.g[1] : t.g[2]));      // base: fictitious acceleration -g
+    if (lr.par >= 0) a = c.link(e, lr.par)[O_A + rr];
+    a += me[O_C + rr];
+    const float U = row_lane ? me[O_U + rr] : 0.0f;
+    const float qdd = (me[O_D + 1] - sum8(U * a)) * me[O_D];
+    const float anew = a + me[O_S + rr] * qdd;
+    // a overwrites row 0 of the (dead) I^A; nothing of this level reads it (children do, one level on)
+    if (row_lane) me[O_A + rr] = anew;
+    if (r == 0) me[O_D + 2] = qdd;
 }
 
 template <int E> struct Passes { static constexpr int N = (E * MAXQ + 63) / 64; };
@@ -581,13 +631,14 @@ __device__ __forceinline__ void tree_accel(const Ctx &c, const float *qj, const 
         if (joint_slot<E>(t, lane, p, e, j)) { (c.env(e) + t.o_W)[j] = qj[p]; (c.env(e) + t.o_SQD)[j] = vj[p]; }
     }
     wave_sync();
-    const int lw = 1 << t.lw_shift;
+    // level passes: slot = octet * 8 + r; octet -> (env, slot x of the level)
+    const int lw = 1 << t.lw_shift, n_slots = (E << t.lw_shift) * 8;
     // ---- P1: forward kinematics, one tree level at a time ----
     for (int L = 0; L < ((RB_TREE_SKIP & 1) ? 0 : t.n_levels); ++L) {
-        const int a = c.ti(t.o_level_start + L), cnt = c.ti(t.o_level_start + L + 1) - a;
-        for (int slot = lane; slot < (E << t.lw_shift); slot += 64) {
-            const int e = slot >> t.lw_shift, x = slot & (lw - 1);
-            if (x < cnt) p1_link(c, e, c.ti(t.o_order + a + x));
+        for (int slot = lane; slot < n_slots; slot += 64) {
+            const int o = slot >> 3, r = slot & 7, e = o >> t.lw_shift, x = o & (lw - 1);
+            const LevelRec lr = load_level(c, L, x);
+            if (lr.i >= 0) p1_octet(c, e, r, lr);
         }
         wave_sync();
     }
@@ -627,19 +678,19 @@ __device__ __forceinline__ void tree_accel(const Ctx &c, const float *qj, const 
     wave_sync();
     // ---- P5: articulated inertias, leaves to root ----
     for (int L = ((RB_TREE_SKIP & 16) ? 0 : t.n_levels) - 1; L >= 0; --L) {
-        const int a = c.ti(t.o_level_start + L), cnt = c.ti(t.o_level_start + L + 1) - a;
-        for (int slot = lane; slot < (E << t.lw_shift); slot += 64) {
-            const int e = slot >> t.lw_shift, x = slot & (lw - 1);
-            if (x < cnt) p5_link(c, e, c.ti(t.o_order + a + x));
+        for (int slot = lane; slot < n_slots; slot += 64) {
+            const int o = slot >> 3, r = slot & 7, e = o >> t.lw_shift, x = o & (lw - 1);
+            const LevelRec lr = load_level(c, L, x);
+            if (lr.i >= 0) p5_octet(c, e, r, lr);
         }
         wave_sync();
     }
     // ---- P6: accelerations, root to leaves ----
     for (int L = 0; L < ((RB_TREE_SKIP & 32) ? 0 : t.n_levels); ++L) {
-        const int a = c.ti(t.o_level_start + L), cnt = c.ti(t.o_level_start + L + 1) - a;
-        for (int slot = lane; slot < (E << t.lw_shift); slot += 64) {
-            const int e = slot >> t.lw_shift, x = slot & (lw - 1);
-            if (x < cnt) p6_link(c, e, c.ti(t.o_order + a + x));
+        for (int slot = lane; slot < n_slots; slot += 64) {
+            const int o = slot >> 3, r = slot & 7, e = o >> t.lw_shift, x = o & (lw - 1);
+            const LevelRec lr = load_level(c, L, x);
+            if (lr.i >= 0) p6_octet(c, e, r, lr);
         }
         wave_sync();
     }
