@@ -1,5 +1,5 @@
 // tree_aba.hpp - generic joint-tree robots (roboy-tendon-robot/1): E envs per WAVE,
-// articulated-body algorithm in world coordinates.
+// articulated-body algorithm in world coordinates, eight lanes per link.
 //
 // For robots outside the ball-joint class (msj_math.hpp) - e.g. the 20-DOF / 38-tendon upper
 // body of BASELINE.json configs[3] - one lane cannot hold an env.  Round 1 gave each env a whole
@@ -7,25 +7,33 @@
 // at 1-3 active lanes and the kernel was bound by wave-instruction issue (109 us at 8 192 envs,
 // profiles/r1_b).  This file replaces it:
 //
-//   * E (template, 4) envs share a wave; every phase maps lanes to (env, item) pairs, so the
-//     per-level passes of the tree run E times wider and each wave-instruction serves E envs;
 //   * forward dynamics by the articulated-body algorithm (Featherstone), O(n_q), with every
 //     spatial quantity expressed in WORLD coordinates about the WORLD ORIGIN.  Then the
 //     accumulation of articulated inertias / bias forces into the parent is a plain sum (no
 //     coordinate transforms), and there is no mass matrix, no factorisation, no substitution;
+//   * E (template, 2) envs share a wave, and in the level passes every link of a tree level gets
+//     an OCTET of lanes: lanes 0-2 own the angular rows / components, lanes 4-6 the linear ones
+//     (3 and 7 idle along).  Inside an octet values move by DPP only (quad rotations for cross
+//     products, a half swap, 8-lane sums); vectors are kept in "rotated" component order
+//     (k, k+1, k+2 for the lane that owns component k), which is what the quad rotations deliver;
+//   * a chain of links keeps its octet from level to level (tree_build assigns the slots), so
+//     parent -> child data (frame, velocity, acceleration) and child -> parent data (articulated
+//     inertia row, bias force) travel in REGISTERS; LDS is touched on the dependent path only at
+//     branch points.  The link's own spatial inertia is evaluated by its octet inside the
+//     backward pass, so no 6x6 per link is ever stored;
 //   * a tendon acts on the links only where it crosses from one link to another: segments
 //     between via-points of the same link have constant length and their forces cancel, so
 //     tree_build() folds them into a constant and keeps the "crossings" (1 per tendon on the
 //     upper body), each of which exerts +-W = +-F (x_a x u ; u) on its two links.
 //
-// Phases of one acceleration evaluation, lanes = (env, item):
-//   P1  links, level by level from the root:  R, p, joint axis s = (z ; p x z), spatial velocity
+// Phases of one acceleration evaluation:
+//   P1  level by level from the root, octets:  R, p, joint axis s = (z ; p x z), spatial velocity
 //       v = (w ; vO), velocity-product acceleration c
-//   P2  tendons:  crossing geometry, length, length rate, Hill force, wrench W per crossing
-//   P3  links:  spatial inertia about the origin -> I^A (21 floats), bias force p^A = v x* I v
-//   P4  (link, component):  p^A -= sum of the tendon wrenches on the link (owner gathers: no atomics)
-//   P5  links, level by level from the leaves:  gather children, U = I^A s, D, u, I^a, p^a
-//   P6  links, level by level from the root:  a, qdd
+//   P2  lanes = (env, tendon):  crossing geometry, length, length rate, Hill force, wrench W per crossing
+//   P4  lanes = (link, env, component):  pT = sum of the tendon wrenches on the link (owner gathers: no atomics)
+//   P5  level by level from the leaves, octets:  own spatial inertia row and bias force, children,
+//       U = I^A s, D, u, I^a, p^a
+//   P6  level by level from the root, octets:  a, qdd
 // Every accumulation is a gather by its owner lane in table order: results are bit-reproducible
 // and independent of which wave / slot an env occupies.  The phases of a wave are ordered by
 // wave_sync() alone (LDS instructions of one wave execute in issue order); a workgroup is a few
@@ -56,34 +64,36 @@ constexpr int MAXVP = 1024; // via-points
 #ifndef RB_TREE_E
 #define RB_TREE_E 2
 #endif
+#ifndef RB_TREE_MIN_WAVES
+#define RB_TREE_MIN_WAVES 4   // waves per SIMD the register allocation must allow (16 per CU: 8 192 upper-body envs in one go)
+#endif
 #ifndef RB_TREE_SKIP
 #define RB_TREE_SKIP 0      // timing-only builds: bit k set = phase P(k+1) left out (results wrong by construction)
 #endif
 constexpr int TREE_E = RB_TREE_E;   // envs per wave
-constexpr int LS = 63;      // floats per link in an env's working set (layout below); odd: lanes that hold
-                            // different links of an env hit different LDS banks (a stride of 64 or 48 floats
-                            // cost 20- and 10-way conflicts in the per-link phases)
-constexpr int LINK_REC = 24, TENDON_REC = 8, CROSS_REC = 8, LEVEL_REC = 16;
+constexpr int LS = 37;      // floats per link in an env's working set (layout below); odd: lanes that hold
+                            // different links of an env hit different LDS banks (strides of 64 / 48 floats
+                            // cost 20- / 10-way conflicts in the per-link phases)
+constexpr int TENDON_REC = 8, CROSS_REC = 8, REC1 = 12, REC5 = 24, XSLOT = 42;
 
 // Link block (LS floats), by phase:
-//   [ 0..11]  R (9, row-major), p (3)          P1 -> P3  }  then I^A, full 6x6, row r at [6r..6r+5]   P3 -> P5
-//   [12..17]  w (3), vO (3)                     P1 -> P3  }  (after P5:  a (6) at [0..5])
-//   [36..41]  z (3), sl = p x z (3)             P1 -> P6
-//   [42..47]  c (6)                             P1 -> P6
-//   [48..53]  p^A (6)                           P3 -> P5
-//   [54..59]  U (6)                             P5 -> P6
-//   [60..62]  1/D, u, qdd                       P5 -> P7
-// I^A rows / columns: 0-2 angular, 3-5 linear.  The level passes (P1, P5, P6) give every link an OCTET of
-// lanes: lane r of the octet owns row r of the link's 6x6 / component r of its vectors; the octet exchanges
-// values by DPP (quad rotations, 8-lane sums) and, once per link, through the link's own LDS block.
-constexpr int O_RP = 0, O_V = 12, O_IA = 0, O_S = 36, O_C = 42, O_PA = 48, O_U = 54, O_D = 60, O_A = 0;
+//   [ 0.. 8]  R (row-major)     [ 9..11]  p      [12..14]  w      [15..17]  vO       P1 -> P5
+//             then  U (6) at [0..5], 1/D, u, qdd at [6..8], a (6) at [9..14]        P5 / P6 -> P7
+//   [18..20]  z    [21..23]  sl = p x z    [24..26]  c angular    [27..29]  c linear  P1 -> P6
+//   [30..35]  pT: tendon wrenches on the link (added to the bias force)              P4 -> P5
+// Rows / components: 0-2 angular, 3-5 linear.
+constexpr int O_RP = 0, O_V = 12, O_U = 0, O_D = 6, O_A = 9, O_S = 18, O_C = 24, O_PT = 30;
+// level-record flags
+constexpr int F_INH = 1;        // the parent sits in the same octet one level up: its data arrive in registers
+constexpr int F_ASTORE = 2;     // some child sits in another octet: the acceleration goes through LDS as well
+constexpr int F_REGCHILD = 1;   // (P5) one child sits in the same octet one level down: its I^a / p^a arrive in registers
+constexpr int F_XWRITE = 2;     // (P5) the parent sits in another octet: I^a / p^a go to the link's exchange slot
 
 struct TreeDev {
-    int n_q, n_t, n_cr, n_levels, nsub, n_act;   // n_act: links some tendon ends on
-    int lw_shift, q_shift;           // log2 of the lane slots per env in the level passes / joint passes
-    int ES, o_W, o_SQD, o_SPU, zoff;   // env stride (floats) and offsets inside an env's block (SQ aliases W)
-    int o_parent, o_order, o_level_start, o_child_start, o_child_list, o_lc_start, o_lc_list, o_act_link, o_t_cr_start, o_level,
-        o_link, o_tendon, o_cross;   // word offsets into the table buffer
+    int n_q, n_t, n_cr, n_levels, nsub, n_x;   // n_x: exchange slots (links whose parent sits in another octet)
+    int lw_shift, q_shift;           // log2 of the octets per env in the level passes / of the lane slots per env in the joint passes
+    int ES, o_W, o_SQD, o_SPU, zoff; // env stride (floats) and offsets inside an env's block (SQ and the exchange slots alias W)
+    int o_lc_start, o_lc_list, o_lc_link, o_t_cr_start, o_rec1, o_rec5, o_ext_list, o_tendon, o_cross, o_joint;   // word offsets into the table buffer
     float h, g[3], kps, pe_k2s, inv_pe_den, fv_c1l, fv_c2l, fv_c2s, fv_k;
     const float4 *g_words;           // all tables as one device buffer of 32-bit words, staged to LDS per workgroup
     int n_vec4;
@@ -111,21 +121,38 @@ inline int tree_build(const rb_robot_desc *d, double step_size, int nsub, TreeHo
         level[i] = parent[i] < 0 ? 0 : level[parent[i]] + 1;
         nlev = level[i] + 1 > nlev ? level[i] + 1 : nlev;
     }
-    std::vector<int> order, level_start(nlev + 1, 0), child_start(nq + 1, 0), child_list;
+    std::vector<std::vector<int>> by_level(nlev), children(nq);
     int max_width = 1;
-    for (int L = 0; L < nlev; ++L) {
-        level_start[L] = int(order.size());
-        for (int i = 0; i < nq; ++i) if (level[i] == L) order.push_back(i);
-        const int wdt = int(order.size()) - level_start[L];
-        max_width = wdt > max_width ? wdt : max_width;
-    }
-    level_start[nlev] = nq;
     for (int i = 0; i < nq; ++i) {
-        child_start[i] = int(child_list.size());
-        for (int c = 0; c < nq; ++c) if (parent[c] == i) child_list.push_back(c);
+        by_level[level[i]].push_back(i);
+        if (parent[i] >= 0) children[parent[i]].push_back(i);
     }
-    child_start[nq] = int(child_list.size());
-    if (child_list.empty()) child_list.push_back(0);
+    for (int L = 0; L < nlev; ++L) max_width = int(by_level[L].size()) > max_width ? int(by_level[L].size()) : max_width;
+    int lw = 1, lw_shift = 0;
+    while (lw < max_width) { lw <<= 1; ++lw_shift; }
+    // Octet slots of the level passes.  A link inherits its parent's slot when it can (first child
+    // served), so that a chain of links stays in one octet and hands its data on in registers; that
+    // needs the whole level to fit one pass of the wave (E * lw octets of 8 lanes <= 64 lanes).
+    const bool chain_ok = TREE_E * lw * 8 <= 64;
+    std::vector<int> slot(nq, -1), inh(nq, 0), reg_child(nq, -1);
+    for (int L = 0; L < nlev; ++L) {
+        std::vector<char> used(lw, 0);
+        if (chain_ok)
+            for (int i : by_level[L]) {
+                const int par = parent[i];
+                if (par >= 0 && reg_child[par] < 0 && !used[slot[par]]) { slot[i] = slot[par]; used[slot[i]] = 1; inh[i] = 1; reg_child[par] = i; }
+            }
+        for (int i : by_level[L]) {
+            if (slot[i] >= 0) continue;
+            int x = 0;
+            while (used[x]) ++x;
+            slot[i] = x; used[x] = 1;
+        }
+    }
+    // exchange slots: links that hand I^a / p^a to a parent in another octet
+    std::vector<int> xslot(nq, -1);
+    int n_x = 0;
+    for (int i = 0; i < nq; ++i) if (parent[i] >= 0 && !inh[i]) xslot[i] = n_x++;
     // zero pose => every link frame is a pure translation: rest lengths, constant segments
     std::vector<double> org(3 * nq);
     for (int i = 0; i < nq; ++i)
@@ -172,30 +199,27 @@ inline int tree_build(const rb_robot_desc *d, double step_size, int nsub, TreeHo
     }
     t_cr_start[nt] = int(cross.size());
     const int ncr = int(cross.size());
-    // P4's lists: for every link that a tendon ends on, the crossings incident to it with the sign
-    // of their wrench in p^A (fext_la += W, fext_lb -= W, p^A -= fext): entry = W offset (6 * crossing)
-    // << 1 | (1 if the link is lb, i.e. +W).  Links sorted by falling list length (lanes of one pass
-    // then loop about equally long), every list padded to a multiple of 4 with entries that point at
-    // the env block's zero slot (6 * n_cr), so the gather loop runs 4 independent loads per trip.
-    const int ncr_ = int(cross.size());
-    const int zoff = 6 * ncr_ > nq ? 6 * ncr_ : nq;      // zero slot: behind W and behind SQ, which aliases W's start
+    // P4's lists: for every link, the crossings incident to it with the sign of their wrench in p^A
+    // (fext_la += W, fext_lb -= W, p^A -= fext): entry = W offset (6 * crossing) << 1 | (1 if the link is lb,
+    // i.e. +W).  Links sorted by falling list length (lanes of one pass then loop about equally long),
+    // every list padded to a multiple of 4 with entries that point at the env block's zero slot, so the
+    // gather loop runs 4 independent loads per trip.  Links without tendons have empty lists (pT = 0).
+    const int zoff = 6 * ncr > nq ? 6 * ncr : nq;      // zero slot: behind W and behind SQ, which aliases W's start
     std::vector<std::vector<int>> inc(nq);
-    for (int c = 0; c < ncr_; ++c) {
+    for (int c = 0; c < ncr; ++c) {
         if (cross[c].la >= 0) inc[cross[c].la].push_back((6 * c) << 1);
         if (cross[c].lb >= 0) inc[cross[c].lb].push_back(((6 * c) << 1) | 1);
     }
-    std::vector<int> act_link;
-    for (int i = 0; i < nq; ++i) if (!inc[i].empty()) act_link.push_back(i);
-    std::stable_sort(act_link.begin(), act_link.end(), [&](int a, int b) { return inc[a].size() > inc[b].size(); });
-    std::vector<int> lc_start, lc_list;     // lc_start: [n_act + 1], then act_link ids follow in their own table
-    for (int i : act_link) {
+    std::vector<int> lc_link(nq);
+    for (int i = 0; i < nq; ++i) lc_link[i] = i;
+    std::stable_sort(lc_link.begin(), lc_link.end(), [&](int a, int b) { return inc[a].size() > inc[b].size(); });
+    std::vector<int> lc_start, lc_list;
+    for (int i : lc_link) {
         lc_start.push_back(int(lc_list.size()));
         for (int en : inc[i]) lc_list.push_back(en);
         while (lc_list.size() % 4) lc_list.push_back(zoff << 1);
     }
     lc_start.push_back(int(lc_list.size()));
-    const int n_act = int(act_link.size());
-    if (act_link.empty()) act_link.push_back(0);
     if (lc_list.empty()) lc_list.assign(4, zoff << 1);
 
     std::vector<uint32_t> &w = out.words;
@@ -203,41 +227,50 @@ inline int tree_build(const rb_robot_desc *d, double step_size, int nsub, TreeHo
     auto pad4 = [&]() { while (w.size() % 4) w.push_back(0u); };
     auto push_i = [&](const std::vector<int> &v) { pad4(); const int off = int(w.size()); for (int x : v) w.push_back(uint32_t(x)); return off; };
     TreeDev &t = out.dev;
-    t.o_parent = push_i(parent); t.o_order = push_i(order); t.o_level_start = push_i(level_start);
-    t.o_child_start = push_i(child_start); t.o_child_list = push_i(child_list);
-    t.o_lc_start = push_i(lc_start); t.o_lc_list = push_i(lc_list); t.o_act_link = push_i(act_link);
+    t.o_lc_start = push_i(lc_start); t.o_lc_list = push_i(lc_list); t.o_lc_link = push_i(lc_link);
     t.o_t_cr_start = push_i(t_cr_start);
-    t.n_act = n_act;
-    // level records: one per (level, slot x < lane width of the level passes), 16 words:
-    // i (-1: empty slot), parent, n_children, child_start, child 0..3, axis 3, origin 3, armature, damping
-    {
-        int lwid = 1;
-        while (lwid < max_width) lwid <<= 1;
-        pad4(); t.o_level = int(w.size());
-        for (int L = 0; L < nlev; ++L)
-            for (int x = 0; x < lwid; ++x) {
-                const int pos = level_start[L] + x;
-                const bool used = pos < level_start[L + 1];
-                const int i = used ? order[pos] : -1;
-                w.push_back(uint32_t(i)); w.push_back(uint32_t(used ? parent[i] : -1));
-                const int cs = used ? child_start[i] : 0, nch = used ? child_start[i + 1] - cs : 0;
-                w.push_back(uint32_t(nch)); w.push_back(uint32_t(cs));
-                for (int k = 0; k < 4; ++k) w.push_back(uint32_t(k < nch ? child_list[cs + k] : 0));
-                for (int a = 0; a < 3; ++a) w.push_back(f2w(used ? d->axis[3 * i + a] : 0.0));
-                for (int a = 0; a < 3; ++a) w.push_back(f2w(used ? d->origin[3 * i + a] : 0.0));
-                w.push_back(f2w(used ? d->armature[i] : 1.0)); w.push_back(f2w(used ? d->damping[i] : 0.0));
-            }
-    }
-    pad4(); t.o_link = int(w.size());
+    // exchange slots of the children that sit in another octet, per link
+    std::vector<int> ext_start(nq + 1, 0), ext_list;
     for (int i = 0; i < nq; ++i) {
-        // axis 3, origin 3, com 3, inertia 6, mass, armature, damping, qlo, qhi, qdmax, pad 3
-        for (int a = 0; a < 3; ++a) w.push_back(f2w(d->axis[3 * i + a]));
-        for (int a = 0; a < 3; ++a) w.push_back(f2w(d->origin[3 * i + a]));
-        for (int a = 0; a < 3; ++a) w.push_back(f2w(d->com[3 * i + a]));
-        for (int a = 0; a < 6; ++a) w.push_back(f2w(d->inertia[6 * i + a]));
-        w.push_back(f2w(d->mass[i])); w.push_back(f2w(d->armature[i])); w.push_back(f2w(d->damping[i]));
-        w.push_back(f2w(d->q_lo[i])); w.push_back(f2w(d->q_hi[i])); w.push_back(f2w(d->qd_max[i]));
-        for (int a = 0; a < 3; ++a) w.push_back(0u);
+        ext_start[i] = int(ext_list.size());
+        for (int c : children[i]) if (!inh[c]) ext_list.push_back(xslot[c]);
+    }
+    ext_start[nq] = int(ext_list.size());
+    if (ext_list.empty()) ext_list.push_back(0);
+    t.o_ext_list = push_i(ext_list);
+    // level records, one per (level, octet slot x < lw); empty slots have i = -1
+    std::vector<int> at(size_t(nlev) * lw, -1);
+    for (int i = 0; i < nq; ++i) at[size_t(level[i]) * lw + slot[i]] = i;
+    pad4(); t.o_rec1 = int(w.size());
+    for (int q = 0; q < nlev * lw; ++q) {          // P1 / P6: i, parent, flags, 0, axis 3, origin 3, 0, 0
+        const int i = at[q];
+        const bool used = i >= 0;
+        bool astore = false;
+        if (used) for (int c : children[i]) astore = astore || !inh[c];
+        w.push_back(uint32_t(i)); w.push_back(uint32_t(used ? parent[i] : -1));
+        w.push_back(uint32_t(used ? (inh[i] ? F_INH : 0) | (astore ? F_ASTORE : 0) : 0)); w.push_back(0u);
+        for (int a = 0; a < 3; ++a) w.push_back(f2w(used ? d->axis[3 * i + a] : 0.0));
+        for (int a = 0; a < 3; ++a) w.push_back(f2w(used ? d->origin[3 * i + a] : 0.0));
+        w.push_back(0u); w.push_back(0u);
+    }
+    pad4(); t.o_rec5 = int(w.size());
+    for (int q = 0; q < nlev * lw; ++q) {          // P5: i, parent, flags, n_ext, ext 0..3, ext_start, xslot, 0, 0, mass, com 3, inertia 6, armature, damping
+        const int i = at[q];
+        const bool used = i >= 0;
+        const int es = used ? ext_start[i] : 0, ne = used ? ext_start[i + 1] - es : 0;
+        w.push_back(uint32_t(i)); w.push_back(uint32_t(used ? parent[i] : -1));
+        w.push_back(uint32_t(used ? (reg_child[i] >= 0 ? F_REGCHILD : 0) | (xslot[i] >= 0 ? F_XWRITE : 0) : 0));
+        w.push_back(uint32_t(ne));
+        for (int k = 0; k < 4; ++k) w.push_back(uint32_t(k < ne ? ext_list[es + k] : 0));
+        w.push_back(uint32_t(es)); w.push_back(uint32_t(used && xslot[i] >= 0 ? xslot[i] : 0)); w.push_back(0u); w.push_back(0u);
+        w.push_back(f2w(used ? d->mass[i] : 0.0));
+        for (int a = 0; a < 3; ++a) w.push_back(f2w(used ? d->com[3 * i + a] : 0.0));
+        for (int a = 0; a < 6; ++a) w.push_back(f2w(used ? d->inertia[6 * i + a] : 0.0));
+        w.push_back(f2w(used ? d->armature[i] : 1.0)); w.push_back(f2w(used ? d->damping[i] : 0.0));
+    }
+    pad4(); t.o_joint = int(w.size());
+    for (int i = 0; i < nq; ++i) {                  // limits: qlo, qhi, qdmax, 0
+        w.push_back(f2w(d->q_lo[i])); w.push_back(f2w(d->q_hi[i])); w.push_back(f2w(d->qd_max[i])); w.push_back(0u);
     }
     pad4(); t.o_tendon = int(w.size());
     for (double x : t_rec) w.push_back(f2w(x));
@@ -250,19 +283,20 @@ inline int tree_build(const rb_robot_desc *d, double step_size, int nsub, TreeHo
     pad4();
     out.table_floats = w.size();
 
-    t.n_q = nq; t.n_t = nt; t.n_cr = ncr; t.n_levels = nlev; t.nsub = nsub; t.h = float(step_size / nsub);
-    int lw = 1; t.lw_shift = 0;
-    while (lw < max_width) { lw <<= 1; ++t.lw_shift; }
+    t.n_q = nq; t.n_t = nt; t.n_cr = ncr; t.n_levels = nlev; t.nsub = nsub; t.n_x = n_x; t.h = float(step_size / nsub);
+    t.lw_shift = lw_shift;
     int qw = 1; t.q_shift = 0;
     while (qw < nq) { qw <<= 1; ++t.q_shift; }
-    // env block: links | W (6 per crossing, then a zero slot of 6; SQ aliases the start during P1) | SQD | SPU
-    const int wsz = zoff + 6;
+    // env block: links | W (6 per crossing, then a zero slot of 6; SQ aliases the start during P1, the
+    // exchange slots alias it during P5) | SQD | SPU
+    int wsz = zoff + 6;
+    if (XSLOT * n_x > wsz) wsz = XSLOT * n_x;
     t.zoff = zoff;
     t.o_W = nq * LS;
     t.o_SQD = t.o_W + wsz;
     t.o_SPU = t.o_SQD + nq;
     t.ES = t.o_SPU + nt;
-    while (t.ES % 32 != 17) ++t.ES;                 // the envs of a wave start 17 banks apart
+    if (t.ES % 2 == 0) ++t.ES;                      // odd: the envs of a wave start in different banks
     for (int a = 0; a < 3; ++a) t.g[a] = float(d->gravity[a]);
     t.kps = float(d->kp / sc);
     t.pe_k2s = float(log2e * d->kpe / (d->e0 * sc));
@@ -365,8 +399,9 @@ struct Ctx {
     int lane;
     __device__ __forceinline__ int ti(int off) const { return __float_as_int(tab[off]); }
     __device__ __forceinline__ float tf(int off) const { return tab[off]; }
-    __device__ __forceinline__ float *env(int e) const { return ws + e * t.ES; }
-    __device__ __forceinline__ float *link(int e, int i) const { return ws + e * t.ES + i * LS; }
+    // 24-bit multiplies (one full-rate v_mad_u32_u24; a 32-bit v_mul_lo is a quarter-rate instruction)
+    __device__ __forceinline__ float *env(int e) const { return ws + __mul24(e, t.ES); }
+    __device__ __forceinline__ float *link(int e, int i) const { return ws + (__mul24(e, t.ES) + __mul24(i, LS)); }
 };
 
 // Copy the robot tables to LDS: 16-byte loads, issued in batches before their stores.
@@ -388,55 +423,101 @@ __device__ __forceinline__ void stage_tables(const TreeDev &g, float *lds_tab, i
     __syncthreads();
 }
 
-// level record of slot (L, x): 16 words, 4 x b128
-struct LevelRec { int i, par, nch, cs, ch[4]; float ax[3], org[3], arm, damp; };
-__device__ __forceinline__ LevelRec load_level(const Ctx &c, int L, int x) {
-    const float4 *p = reinterpret_cast<const float4 *>(c.tab + c.t.o_level + (((L << c.t.lw_shift) + x) * LEVEL_REC));
-    const float4 a = p[0], b = p[1], d = p[2], f = p[3];
-    LevelRec r;
-    r.i = __float_as_int(a.x); r.par = __float_as_int(a.y); r.nch = __float_as_int(a.z); r.cs = __float_as_int(a.w);
-    r.ch[0] = __float_as_int(b.x); r.ch[1] = __float_as_int(b.y); r.ch[2] = __float_as_int(b.z); r.ch[3] = __float_as_int(b.w);
-    r.ax[0] = d.x; r.ax[1] = d.y; r.ax[2] = d.z; r.org[0] = d.w; r.org[1] = f.x; r.org[2] = f.y; r.arm = f.z; r.damp = f.w;
+// swap the halves of an octet: lane k gets the value of lane 4 + k and vice versa
+// (row_half_mirror: i <-> 7 - i, then quad_perm [3,2,1,0])
+__device__ __forceinline__ float swap_half(float v) { return dpp<0x1B>(dpp<0x141>(v)); }
+
+// lane r of an octet
+struct OctLane {
+    int half, kk, n1, n2, row6;    // half: 0 angular / 1 linear; kk: own component (idle lanes shadow 2); n1, n2: the next two, cyclically
+    bool act;                      // owns a row
+    __device__ __forceinline__ explicit OctLane(int r) {
+        half = r >> 2;
+        const int k = r & 3;
+        act = k < 3;
+        kk = act ? k : 2;
+        n1 = kk == 2 ? 0 : kk + 1; n2 = kk == 0 ? 2 : kk - 1;
+        row6 = 3 * half + kk;
+    }
+};
+
+// ---- level records ----
+struct Rec1 { int i, par, flags; float ax[3], org[3]; };
+__device__ __forceinline__ Rec1 load_rec1(const Ctx &c, int L, int x) {
+    const float4 *p = reinterpret_cast<const float4 *>(c.tab + c.t.o_rec1 + __mul24((L << c.t.lw_shift) + x, REC1));
+    const float4 a = p[0], b = p[1], d = p[2];
+    Rec1 r;
+    r.i = __float_as_int(a.x); r.par = __float_as_int(a.y); r.flags = __float_as_int(a.z);
+    r.ax[0] = b.x; r.ax[1] = b.y; r.ax[2] = b.z; r.org[0] = b.w; r.org[1] = d.x; r.org[2] = d.y;
+    return r;
+}
+// P5's record in two parts: the integers (prefetched one level ahead: they give the addresses) and the
+// link's constants (loaded with the link's data at the top of the body)
+struct Rec5 { int i, par, flags, n_ext, ext[4], es, xslot, q; };
+__device__ __forceinline__ Rec5 load_rec5(const Ctx &c, int L, int x) {
+    const int q = (L << c.t.lw_shift) + x;
+    const float4 *p = reinterpret_cast<const float4 *>(c.tab + c.t.o_rec5 + __mul24(q, REC5));
+    const float4 a = p[0], b = p[1], d = p[2];
+    Rec5 r;
+    r.i = __float_as_int(a.x); r.par = __float_as_int(a.y); r.flags = __float_as_int(a.z); r.n_ext = __float_as_int(a.w);
+    r.ext[0] = __float_as_int(b.x); r.ext[1] = __float_as_int(b.y); r.ext[2] = __float_as_int(b.z); r.ext[3] = __float_as_int(b.w);
+    r.es = __float_as_int(d.x); r.xslot = __float_as_int(d.y); r.q = q;
+    return r;
+}
+struct Rec5c { float m, com[3], I6[6], arm, damp; };
+__device__ __forceinline__ Rec5c load_rec5c(const Ctx &c, int q) {
+    const float4 *p = reinterpret_cast<const float4 *>(c.tab + c.t.o_rec5 + __mul24(q, REC5) + 12);
+    const float4 f = p[0], g = p[1], h = p[2];
+    Rec5c r;
+    r.m = f.x; r.com[0] = f.y; r.com[1] = f.z; r.com[2] = f.w;
+    r.I6[0] = g.x; r.I6[1] = g.y; r.I6[2] = g.z; r.I6[3] = g.w; r.I6[4] = h.x; r.I6[5] = h.y; r.arm = h.z; r.damp = h.w;
     return r;
 }
 
-// ---- P1, lane r of the link's octet: row r3 = r % 3 of the frame, component r3 of the vectors.
-//      Lanes 0-2 store; the other lanes of the octet compute the same rows again (their quads rotate alike). ----
-__device__ __forceinline__ void p1_octet(const Ctx &c, int e, int r, const LevelRec &lr) {
-    const int r3 = r >= 6 ? r - 6 : (r >= 3 ? r - 3 : r), n1 = r3 == 2 ? 0 : r3 + 1, n2 = r3 == 0 ? 2 : r3 - 1;
+// ---- P1: frame, joint axis, spatial velocity, velocity-product acceleration of one link.
+//      Every lane of the octet computes row kk of the frame / component kk of the vectors (both halves
+//      alike, so the quad rotations work in each); the angular half stores R, p, z, c_ang, the linear
+//      half w, vO, sl, c_lin.  `cy` carries (row of R, p, w, vO) down the chain. ----
+struct Carry1 { V3 Rrow; float p, w, vo; };
+__device__ __forceinline__ void p1_body(const Ctx &c, int e, const OctLane &o, const Rec1 &lr, float qi, float qdi, Carry1 &cy) {
     float *me = c.link(e, lr.i);
-    const float *sq = c.env(e) + c.t.o_W, *sqd = c.env(e) + c.t.o_SQD;
-    // row r3 of the parent's frame, the parent's origin / velocity components this lane needs
-    V3 Rrow = {r3 == 0 ? 1.0f : 0.0f, r3 == 1 ? 1.0f : 0.0f, r3 == 2 ? 1.0f : 0.0f};
-    float pp = 0.0f, wp0 = 0.0f, wp1 = 0.0f, wp2 = 0.0f, vop = 0.0f;
-    if (lr.par >= 0) {
-        const float *pa = c.link(e, lr.par);
-        Rrow = ld3(pa + O_RP + 3 * r3);
-        pp = pa[O_RP + 9 + r3]; wp0 = pa[O_V + r3]; wp1 = pa[O_V + n1]; wp2 = pa[O_V + n2]; vop = pa[O_V + 3 + r3];
+    V3 Rrow = cy.Rrow;
+    float pp = cy.p, wp0 = cy.w, wp1 = rot1(cy.w), wp2 = rot2(cy.w), vop = cy.vo;
+    if (!(lr.flags & F_INH)) {
+        Rrow = {o.kk == 0 ? 1.0f : 0.0f, o.kk == 1 ? 1.0f : 0.0f, o.kk == 2 ? 1.0f : 0.0f};
+        pp = 0.0f; wp0 = 0.0f; wp1 = 0.0f; wp2 = 0.0f; vop = 0.0f;
+        if (lr.par >= 0) {
+            const float *pa = c.link(e, lr.par);
+            Rrow = ld3(pa + O_RP + 3 * o.kk);
+            pp = pa[O_RP + 9 + o.kk]; wp0 = pa[O_V + o.kk]; wp1 = pa[O_V + o.n1]; wp2 = pa[O_V + o.n2]; vop = pa[O_V + 3 + o.kk];
+        }
     }
     const V3 ax = {lr.ax[0], lr.ax[1], lr.ax[2]}, org = {lr.org[0], lr.org[1], lr.org[2]};
-    const float qi = sq[lr.i], qdi = sqd[lr.i];
     float sn, cs;
     __sincosf(qi, &sn, &cs);
-    // Rodrigues: I + sin K + (1 - cos) K^2
+    // Rodrigues: I + sin K + (1 - cos) K^2, by columns
     const float oc = 1.0f - cs;
-    const V3 c0 = {1.0f - oc * (ax.y * ax.y + ax.z * ax.z), sn * ax.z + oc * ax.x * ax.y, -sn * ax.y + oc * ax.x * ax.z};   // columns of rot
+    const V3 c0 = {1.0f - oc * (ax.y * ax.y + ax.z * ax.z), sn * ax.z + oc * ax.x * ax.y, -sn * ax.y + oc * ax.x * ax.z};
     const V3 c1 = {-sn * ax.z + oc * ax.x * ax.y, 1.0f - oc * (ax.x * ax.x + ax.z * ax.z), sn * ax.x + oc * ax.y * ax.z};
     const V3 c2 = {sn * ax.y + oc * ax.x * ax.z, -sn * ax.x + oc * ax.y * ax.z, 1.0f - oc * (ax.x * ax.x + ax.y * ax.y)};
-    const V3 Ri = {dot(Rrow, c0), dot(Rrow, c1), dot(Rrow, c2)};      // row r3 of R_p rot
-    const float p = pp + dot(Rrow, org);                              // component r3 of p_i
+    const V3 Ri = {dot(Rrow, c0), dot(Rrow, c1), dot(Rrow, c2)};      // row kk of R_p rot
+    const float p = pp + dot(Rrow, org);                              // component kk of p_i
     const float z = dot(Rrow, ax);                                    // ... of the joint axis
     const float p1 = rot1(p), p2 = rot2(p), z1 = rot1(z), z2 = rot2(z);
-    const float sl = p1 * z2 - p2 * z1;                               // (p x z)[r3]
+    const float sl = p1 * z2 - p2 * z1;                               // (p x z)[kk]
     const float w = wp0 + z * qdi, vo = vop + sl * qdi;
-    const float ca = (wp1 * z2 - wp2 * z1) * qdi;                     // (w_p x z)[r3] qd   (w_i x z_i = w_p x z_i)
+    const float ca = (wp1 * z2 - wp2 * z1) * qdi;                     // (w_p x z)[kk] qd   (w_i x z_i = w_p x z_i)
     const float w1 = rot1(w), w2 = rot2(w), sl1 = rot1(sl), sl2 = rot2(sl), vo1 = rot1(vo), vo2 = rot2(vo);
-    const float cl = ((w1 * sl2 - w2 * sl1) + (vo1 * z2 - vo2 * z1)) * qdi;   // (w x sl + vO x z)[r3] qd
-    if (r < 3) {
-        st3(me + O_RP + 3 * r3, Ri);
-        me[O_RP + 9 + r3] = p; me[O_V + r3] = w; me[O_V + 3 + r3] = vo;
-        me[O_S + r3] = z; me[O_S + 3 + r3] = sl; me[O_C + r3] = ca; me[O_C + 3 + r3] = cl;
+    const float cl = ((w1 * sl2 - w2 * sl1) + (vo1 * z2 - vo2 * z1)) * qdi;   // (w x sl + vO x z)[kk] qd
+    if (o.act) {
+        if (o.half == 0) {
+            st3(me + O_RP + 3 * o.kk, Ri);
+            me[O_RP + 9 + o.kk] = p; me[O_S + o.kk] = z; me[O_C + o.kk] = ca;
+        } else {
+            me[O_V + o.kk] = w; me[O_V + 3 + o.kk] = vo; me[O_S + 3 + o.kk] = sl; me[O_C + 3 + o.kk] = cl;
+        }
     }
+    cy.Rrow = Ri; cy.p = p; cy.w = w; cy.vo = vo;
 }
 
 // world position and velocity of a point fixed to `link` (local coordinates r); link < 0: the base
@@ -484,128 +565,202 @@ __device__ __forceinline__ void p2_tendon(const Ctx &c, int e, int k) {
     }
 }
 
-// ---- P3: one link: spatial inertia about the world origin, bias force ----
-__device__ __forceinline__ void p3_link(const Ctx &c, int e, int i) {
-    const float *rec = c.tab + c.t.o_link + i * LINK_REC;
-    float *me = c.link(e, i);
-    const float m = rec[15];
-    const float *I6 = rec + 9;
-    float IA[21], pA[6];
-    if (m != 0.0f || I6[0] != 0.0f || I6[1] != 0.0f || I6[2] != 0.0f) {
-        M3 R;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) R.m[k] = me[O_RP + k];
-        const V3 p = ld3(me + O_RP + 9), w = ld3(me + O_V), vo = ld3(me + O_V + 3);
-        const V3 cw = p + mul(R, ld3(rec + 6));
-        // Iw = R I R^T (symmetric)
-        M3 RI;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const V3 row = {R.m[3 * r], R.m[3 * r + 1], R.m[3 * r + 2]};
-            const V3 ri = symmul(I6, row);     // (R I)_row = I row (I symmetric)
-            RI.m[3 * r] = ri.x; RI.m[3 * r + 1] = ri.y; RI.m[3 * r + 2] = ri.z;
-        }
-        auto rowdot = [&](int r1, int r2) {
-            return RI.m[3 * r1] * R.m[3 * r2] + RI.m[3 * r1 + 1] * R.m[3 * r2 + 1] + RI.m[3 * r1 + 2] * R.m[3 * r2 + 2];
-        };
-        const float c2 = dot(cw, cw);
-        IA[0] = rowdot(0, 0) + m * (c2 - cw.x * cw.x); IA[1] = rowdot(1, 1) + m * (c2 - cw.y * cw.y);
-        IA[2] = rowdot(2, 2) + m * (c2 - cw.z * cw.z);
-        IA[3] = rowdot(0, 1) - m * cw.x * cw.y; IA[4] = rowdot(0, 2) - m * cw.x * cw.z; IA[5] = rowdot(1, 2) - m * cw.y * cw.z;
-        const V3 h = cw * m;
-        // AL = [h]x  (rows angular, columns linear)
-        IA[6] = 0.0f; IA[7] = -h.z; IA[8] = h.y; IA[9] = h.z; IA[10] = 0.0f; IA[11] = -h.x; IA[12] = -h.y; IA[13] = h.x; IA[14] = 0.0f;
-        IA[15] = m; IA[16] = m; IA[17] = m; IA[18] = 0.0f; IA[19] = 0.0f; IA[20] = 0.0f;
-        const V3 Iva = symmul(IA, w) + cross(h, vo), Ivl = vo * m - cross(h, w);
-        const V3 pa = cross(w, Iva) + cross(vo, Ivl), pl = cross(w, Ivl);
-        pA[0] = pa.x; pA[1] = pa.y; pA[2] = pa.z; pA[3] = pl.x; pA[4] = pl.y; pA[5] = pl.z;
-    } else {
-        // massless virtual link (the x / y joints of a ball joint)
-#pragma unroll
-        for (int k = 0; k < 21; ++k) IA[k] = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) pA[k] = 0.0f;
-    }
-    // all inputs are in registers: the 6x6 overwrites R, p, w, vO.  IA (21) = AA sym, AL 3x3, LL sym
-    const float *AA = IA, *AL = IA + 6, *LL = IA + 15;
-    const float rows[36] = {AA[0], AA[3], AA[4], AL[0], AL[1], AL[2],
-                            AA[3], AA[1], AA[5], AL[3], AL[4], AL[5],
-                            AA[4], AA[5], AA[2], AL[6], AL[7], AL[8],
-                            AL[0], AL[3], AL[6], LL[0], LL[3], LL[4],
-                            AL[1], AL[4], AL[7], LL[3], LL[1], LL[5],
-                            AL[2], AL[5], AL[8], LL[4], LL[5], LL[2]};
-#pragma unroll
-    for (int k = 0; k < 36; ++k) me[O_IA + k] = rows[k];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) me[O_PA + k] = pA[k];
-}
-
-// ---- P5, lane r of the link's octet: row r of I^A / component r of p^A (lanes 6, 7 idle along) ----
-__device__ __forceinline__ void p5_octet(const Ctx &c, int e, int r, const LevelRec &lr) {
+// ---- P5: backward pass of one link.  Lane (half, kk) owns row row6 = 3 half + kk of the link's 6x6 and
+//      component row6 of its 6-vectors; rows and vectors are held split in "own-half" and "other-half"
+//      columns, each in rotated order (kk, kk+1, kk+2): rO[j] = I[row6][3 half + (kk+j)%3],
+//      rX[j] = I[row6][3 (1 - half) + (kk+j)%3].  `cy` carries (rO, rX, p^a) up the chain. ----
+struct Carry5 { float rO[3], rX[3], pa; };
+__device__ __forceinline__ void p5_body(const Ctx &c, int e, const OctLane &o, const Rec5 &lr, Carry5 &cy) {
     const TreeDev &t = c.t;
-    const int rr = r < 6 ? r : 5;
-    const bool row_lane = r < 6;
     float *me = c.link(e, lr.i);
-    float row[6], pa;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) row[k] = me[O_IA + 6 * rr + k];
-    pa = me[O_PA + rr];
-    auto add_child = [&](int ch) {
-        const float *cb = c.link(e, ch);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) row[k] += cb[O_IA + 6 * rr + k];
-        pa += cb[O_PA + rr];
-    };
-    if (lr.nch > 0) add_child(lr.ch[0]);
-    if (lr.nch > 1) add_child(lr.ch[1]);
-    if (lr.nch > 2) add_child(lr.ch[2]);
-    if (lr.nch > 3) add_child(lr.ch[3]);
-    for (int k = 4; k < lr.nch; ++k) add_child(c.ti(t.o_child_list + lr.cs + k));
-    float s[6], cc[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { s[k] = me[O_S + k]; cc[k] = me[O_C + k]; }
+    const Rec5c lc = load_rec5c(c, lr.q);
+    const int k = o.kk, n1 = o.n1, n2 = o.n2, hO = 3 * o.half, hX = 3 - hO;
+    // own link's data, component order (k, n1, n2) by lane-dependent addresses
+    const V3 Rk = ld3(me + O_RP + 3 * k), R1 = ld3(me + O_RP + 3 * n1), R2 = ld3(me + O_RP + 3 * n2);
+    const float pk = me[O_RP + 9 + k], p1 = me[O_RP + 9 + n1], p2 = me[O_RP + 9 + n2];
+    const float wk = me[O_V + k], w1 = me[O_V + n1], w2 = me[O_V + n2];
+    const float vk = me[O_V + 3 + k], v1 = me[O_V + 3 + n1], v2 = me[O_V + 3 + n2];
+    const float sO[3] = {me[O_S + hO + k], me[O_S + hO + n1], me[O_S + hO + n2]};
+    const float sX[3] = {me[O_S + hX + k], me[O_S + hX + n1], me[O_S + hX + n2]};
+    const float cO[3] = {me[O_C + hO + k], me[O_C + hO + n1], me[O_C + hO + n2]};
+    const float cX[3] = {me[O_C + hX + k], me[O_C + hX + n1], me[O_C + hX + n2]};
+    const float pT = me[O_PT + o.row6];
     const float qdi = (c.env(e) + t.o_SQD)[lr.i];
-    float U = 0.0f;
+    // spatial inertia of the link about the world origin, row row6
+    const V3 com = {lc.com[0], lc.com[1], lc.com[2]};
+    const float m = lc.m;
+    const float ck = pk + dot(Rk, com), c1 = p1 + dot(R1, com), c2 = p2 + dot(R2, com);     // world COM, rotated order
+    const float hk = m * ck, h1 = m * c1, h2 = m * c2;
+    const V3 tt = symmul(lc.I6, Rk);                       // I R_k^T  (I symmetric)
+    const float Ikk = dot(tt, Rk) + m * (c1 * c1 + c2 * c2);
+    const float Ik1 = dot(tt, R1) - hk * c1, Ik2 = dot(tt, R2) - hk * c2;
+    float rO[3], rX[3];
+    // angular row k: [ Ibar row | [h]x row ] ;  linear row k: [ m e_k | -[h]x row ] ;  [h]x row k = (0, -h2, h1) in rotated order
+    rO[0] = o.half ? m : Ikk; rO[1] = o.half ? 0.0f : Ik1; rO[2] = o.half ? 0.0f : Ik2;
+    rX[0] = 0.0f; rX[1] = o.half ? h2 : -h2; rX[2] = o.half ? -h1 : h1;
+    // I v:  angular (Ibar w + h x vO)[k],  linear (m vO - h x w)[k]
+    const float X = o.half ? (m * vk - (h1 * w2 - h2 * w1)) : (Ikk * wk + Ik1 * w1 + Ik2 * w2 + (h1 * v2 - h2 * v1));
+    const float X1 = rot1(X), X2 = rot2(X);
+    const float Y = swap_half(X), Y1 = rot1(Y), Y2 = rot2(Y);
+    // bias force v x* (I v):  angular (w x Iv_a + vO x Iv_l)[k],  linear (w x Iv_l)[k];  plus the tendon wrenches
+    float pa = (w1 * X2 - w2 * X1) + (o.half ? 0.0f : (v1 * Y2 - v2 * Y1)) + pT;
+    // children: the one below in the same octet (registers), the others through their exchange slots
+    if (lr.flags & F_REGCHILD) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) U += row[k] * s[k];
-    const float sr = row_lane ? me[O_S + rr] : 0.0f;                     // s_r (0 in the idle lanes: they add nothing)
-    const float D = sum8(sr * U) + lr.arm;
+        for (int j = 0; j < 3; ++j) { rO[j] += cy.rO[j]; rX[j] += cy.rX[j]; }
+        pa += cy.pa;
+    }
+    float *X0 = c.env(e) + t.o_W;
+    auto add_ext = [&](int xs) {
+        const float *row = X0 + __mul24(xs, XSLOT) + 6 * o.row6;
+        rO[0] += row[hO + k]; rO[1] += row[hO + n1]; rO[2] += row[hO + n2];
+        rX[0] += row[hX + k]; rX[1] += row[hX + n1]; rX[2] += row[hX + n2];
+        pa += X0[__mul24(xs, XSLOT) + 36 + o.row6];
+    };
+    if (lr.n_ext > 0) add_ext(lr.ext[0]);
+    if (lr.n_ext > 1) add_ext(lr.ext[1]);
+    if (lr.n_ext > 2) add_ext(lr.ext[2]);
+    if (lr.n_ext > 3) add_ext(lr.ext[3]);
+    for (int q = 4; q < lr.n_ext; ++q) add_ext(c.ti(t.o_ext_list + lr.es + q));
+    const float U = rO[0] * sO[0] + rO[1] * sO[1] + rO[2] * sO[2] + rX[0] * sX[0] + rX[1] * sX[1] + rX[2] * sX[2];
+    const float sr = o.act ? sO[0] : 0.0f;                 // s_row6 (idle lanes add nothing to the sums)
+    const float D = sum8(sr * U) + lc.arm;
     const float T = sum8(sr * pa);
     const float invD = __builtin_amdgcn_rcpf(D);
-    const float u = -lr.damp * qdi - T;
-    if (row_lane) me[O_U + rr] = U;
-    if (r == 0) { me[O_D] = invD; me[O_D + 1] = u; }
-    if (lr.par >= 0) {
-        // I^a = I^A - U U^T / D ;  p^a = p^A + I^a c + U u / D, left in place for the parent's octet to gather.
-        // The row needs all of U: through the block (LDS instructions of a wave execute in order)
-        wave_sync();
-        const float K = U * invD;
-        float acc = pa + U * (u * invD);
+    const float u = -lc.damp * qdi - T;
+    // U of the whole octet, in this lane's column order
+    const float UO[3] = {U, rot1(U), rot2(U)};
+    const float Us = swap_half(U);
+    const float UX[3] = {Us, rot1(Us), rot2(Us)};
+    const float K = U * invD;
+    float acc = pa + U * (u * invD);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const float ia = row[k] - K * me[O_U + k];
-            acc += ia * cc[k];
-            if (row_lane) me[O_IA + 6 * rr + k] = ia;
+    for (int j = 0; j < 3; ++j) {
+        rO[j] -= K * UO[j]; rX[j] -= K * UX[j];           // I^a = I^A - U U^T / D
+        acc += rO[j] * cO[j] + rX[j] * cX[j];              // p^a = p^A + I^a c + U u / D
+    }
+    // U, 1/D, u for the forward pass overwrite R (every lane has read what it needs from the block)
+    if (o.act) me[O_U + o.row6] = U;
+    if (o.act && o.row6 == 0) { me[O_D] = invD; me[O_D + 1] = u; }
+    if ((lr.flags & F_XWRITE) && o.act) {
+        float *row = X0 + __mul24(lr.xslot, XSLOT) + 6 * o.row6;
+        row[hO + k] = rO[0]; row[hO + n1] = rO[1]; row[hO + n2] = rO[2];
+        row[hX + k] = rX[0]; row[hX + n1] = rX[1]; row[hX + n2] = rX[2];
+        X0[__mul24(lr.xslot, XSLOT) + 36 + o.row6] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { cy.rO[j] = rO[j]; cy.rX[j] = rX[j]; }
+    cy.pa = acc;
+}
+
+// ---- P6: forward pass of one link: component row6 of the spatial acceleration, qdd by an octet sum.
+//      `a` carries the parent's acceleration down the chain. ----
+struct Data6 { float cr, sr, U, invD, u; };
+__device__ __forceinline__ Data6 load_data6(const Ctx &c, int e, const OctLane &o, int i) {
+    const float *me = c.link(e, i);
+    Data6 d;
+    d.cr = me[O_C + o.row6]; d.sr = me[O_S + o.row6]; d.U = o.act ? me[O_U + o.row6] : 0.0f; d.invD = me[O_D]; d.u = me[O_D + 1];
+    return d;
+}
+__device__ __forceinline__ void p6_body(const Ctx &c, int e, const OctLane &o, const Rec1 &lr, const Data6 &d, float a0, float &a) {
+    float *me = c.link(e, lr.i);
+    float ap = a;
+    if (!(lr.flags & F_INH)) ap = lr.par >= 0 ? c.link(e, lr.par)[O_A + o.row6] : a0;
+    ap += d.cr;
+    const float qdd = (d.u - sum8(d.U * ap)) * d.invD;
+    a = ap + d.sr * qdd;
+    if ((lr.flags & F_ASTORE) && o.act) me[O_A + o.row6] = a;
+    if (o.act && o.row6 == 0) me[O_D + 2] = qdd;
+}
+
+// The three level sweeps.  Every link of a level gets an octet of lanes: slot = octet * 8 + r, octet ->
+// (env, slot x of the level).  The first pass of a level (slot = lane) is the chained one: its record
+// (and, where cheap, its data) for the NEXT level is requested before this level's work, and the carry
+// registers hand data from level to level.  Robots so wide that a level needs several passes
+// (E * lw * 8 > 64) have no inheriting links (tree_build), so their extra passes carry nothing.
+template <int E>
+__device__ __forceinline__ void sweep_p1(const Ctx &c) {
+    const TreeDev &t = c.t;
+    const int lw = 1 << t.lw_shift, n_slots = (E << t.lw_shift) * 8;
+    const OctLane o(c.lane & 7);
+    const int e0 = (c.lane >> 3) >> t.lw_shift, x0 = (c.lane >> 3) & (lw - 1);
+    const bool first = c.lane < n_slots;
+    const float *sq = c.env(first ? e0 : 0) + t.o_W, *sqd = c.env(first ? e0 : 0) + t.o_SQD;
+    Carry1 cy = {{0.0f, 0.0f, 0.0f}, 0.0f, 0.0f, 0.0f};
+    Rec1 cur = load_rec1(c, 0, x0);
+    float qi = cur.i >= 0 ? sq[cur.i] : 0.0f, qdi = cur.i >= 0 ? sqd[cur.i] : 0.0f;
+    for (int L = 0; L < t.n_levels; ++L) {
+        Rec1 nxt = cur;
+        float nqi = 0.0f, nqdi = 0.0f;
+        if (L + 1 < t.n_levels) {
+            nxt = load_rec1(c, L + 1, x0);
+            nqi = nxt.i >= 0 ? sq[nxt.i] : 0.0f; nqdi = nxt.i >= 0 ? sqd[nxt.i] : 0.0f;
         }
-        if (row_lane) me[O_PA + rr] = acc;
+        if (first && cur.i >= 0) p1_body(c, e0, o, cur, qi, qdi, cy);
+        for (int slot = c.lane + 64; slot < n_slots; slot += 64) {
+            const int oc = slot >> 3, e = oc >> t.lw_shift;
+            const Rec1 lr = load_rec1(c, L, oc & (lw - 1));
+            Carry1 none = {{0.0f, 0.0f, 0.0f}, 0.0f, 0.0f, 0.0f};
+            if (lr.i >= 0) p1_body(c, e, o, lr, (c.env(e) + t.o_W)[lr.i], (c.env(e) + t.o_SQD)[lr.i], none);
+        }
+        wave_sync();
+        cur = nxt; qi = nqi; qdi = nqdi;
     }
 }
 
-// ---- P6, lane r of the link's octet: component r of the spatial acceleration; qdd by an octet sum ----
-__device__ __forceinline__ void p6_octet(const Ctx &c, int e, int r, const LevelRec &lr) {
+template <int E>
+__device__ __forceinline__ void sweep_p5(const Ctx &c) {
     const TreeDev &t = c.t;
-    const int rr = r < 6 ? r : 5;
-    const bool row_lane = r < 6;
-    float *me = c.link(e, lr.i);
-    float a = rr < 3 ? 0.0f : -(rr == 3 ? t.g[0] : (rr == 4 ? t.g[1] : t.g[2]));      // base: fictitious acceleration -g
-    if (lr.par >= 0) a = c.link(e, lr.par)[O_A + rr];
-    a += me[O_C + rr];
-    const float U = row_lane ? me[O_U + rr] : 0.0f;
-    const float qdd = (me[O_D + 1] - sum8(U * a)) * me[O_D];
-    const float anew = a + me[O_S + rr] * qdd;
-    // a overwrites row 0 of the (dead) I^A; nothing of this level reads it (children do, one level on)
-    if (row_lane) me[O_A + rr] = anew;
-    if (r == 0) me[O_D + 2] = qdd;
+    const int lw = 1 << t.lw_shift, n_slots = (E << t.lw_shift) * 8;
+    const OctLane o(c.lane & 7);
+    const int e0 = (c.lane >> 3) >> t.lw_shift, x0 = (c.lane >> 3) & (lw - 1);
+    const bool first = c.lane < n_slots;
+    Carry5 cy = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, 0.0f};
+    Rec5 cur = load_rec5(c, t.n_levels - 1, x0);
+    for (int L = t.n_levels - 1; L >= 0; --L) {
+        Rec5 nxt = cur;
+        if (L > 0) nxt = load_rec5(c, L - 1, x0);
+        if (first && cur.i >= 0) p5_body(c, e0, o, cur, cy);
+        for (int slot = c.lane + 64; slot < n_slots; slot += 64) {
+            const int oc = slot >> 3, e = oc >> t.lw_shift;
+            const Rec5 lr = load_rec5(c, L, oc & (lw - 1));
+            Carry5 none = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, 0.0f};
+            if (lr.i >= 0) p5_body(c, e, o, lr, none);
+        }
+        wave_sync();
+        cur = nxt;
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void sweep_p6(const Ctx &c) {
+    const TreeDev &t = c.t;
+    const int lw = 1 << t.lw_shift, n_slots = (E << t.lw_shift) * 8;
+    const OctLane o(c.lane & 7);
+    const int e0 = (c.lane >> 3) >> t.lw_shift, x0 = (c.lane >> 3) & (lw - 1);
+    const bool first = c.lane < n_slots;
+    const float g0 = t.g[0], g1 = t.g[1], g2 = t.g[2];   // scalars first: a lane-indexed t.g[] becomes a global load from the kernarg
+    const float a0 = o.half ? -(o.kk == 0 ? g0 : (o.kk == 1 ? g1 : g2)) : 0.0f;    // base: fictitious acceleration -g
+    float a = 0.0f;
+    Rec1 cur = load_rec1(c, 0, x0);
+    Data6 d = load_data6(c, first ? e0 : 0, o, cur.i >= 0 ? cur.i : 0);
+    for (int L = 0; L < t.n_levels; ++L) {
+        Rec1 nxt = cur;
+        Data6 nd = d;
+        if (L + 1 < t.n_levels) {
+            nxt = load_rec1(c, L + 1, x0);
+            nd = load_data6(c, first ? e0 : 0, o, nxt.i >= 0 ? nxt.i : 0);
+        }
+        if (first && cur.i >= 0) p6_body(c, e0, o, cur, d, a0, a);
+        for (int slot = c.lane + 64; slot < n_slots; slot += 64) {
+            const int oc = slot >> 3, e = oc >> t.lw_shift;
+            const Rec1 lr = load_rec1(c, L, oc & (lw - 1));
+            float none = 0.0f;
+            if (lr.i >= 0) p6_body(c, e, o, lr, load_data6(c, e, o, lr.i), a0, none);
+        }
+        wave_sync();
+        cur = nxt; d = nd;
+    }
 }
 
 template <int E> struct Passes { static constexpr int N = (E * MAXQ + 63) / 64; };
@@ -630,18 +785,11 @@ __device__ __forceinline__ void tree_accel(const Ctx &c, const float *qj, const 
         int e, j;
         if (joint_slot<E>(t, lane, p, e, j)) { (c.env(e) + t.o_W)[j] = qj[p]; (c.env(e) + t.o_SQD)[j] = vj[p]; }
     }
+    // the zero slot behind W that pads P4's lists (the exchange slots of P5 may have covered it)
+    if (lane < 6 * E) (c.env(lane / 6) + t.o_W + t.zoff)[lane % 6] = 0.0f;
     wave_sync();
-    // level passes: slot = octet * 8 + r; octet -> (env, slot x of the level)
-    const int lw = 1 << t.lw_shift, n_slots = (E << t.lw_shift) * 8;
     // ---- P1: forward kinematics, one tree level at a time ----
-    for (int L = 0; L < ((RB_TREE_SKIP & 1) ? 0 : t.n_levels); ++L) {
-        for (int slot = lane; slot < n_slots; slot += 64) {
-            const int o = slot >> 3, r = slot & 7, e = o >> t.lw_shift, x = o & (lw - 1);
-            const LevelRec lr = load_level(c, L, x);
-            if (lr.i >= 0) p1_octet(c, e, r, lr);
-        }
-        wave_sync();
-    }
+    if (!(RB_TREE_SKIP & 1)) sweep_p1<E>(c);
     // ---- P2: tendons (SQ is dead: W overwrites it) ----
     for (int it = lane; it < ((RB_TREE_SKIP & 2) ? 0 : E * t.n_t); it += 64) {
         int e, k;
@@ -649,19 +797,12 @@ __device__ __forceinline__ void tree_accel(const Ctx &c, const float *qj, const 
         p2_tendon(c, e, k);
     }
     wave_sync();
-    // ---- P3: link inertias and bias forces ----
-    for (int it = lane; it < ((RB_TREE_SKIP & 4) ? 0 : E * t.n_q); it += 64) {
-        int e, i;
-        split<E>(it, t.n_q, e, i);
-        p3_link(c, e, i);
-    }
-    wave_sync();
-    // ---- P4: p^A -= tendon wrenches on the link; lanes = (link with tendons, env, component), link-major,
+    // ---- P4: pT = tendon wrenches on the link (enters the bias force); lanes = (link, env, component), link-major,
     //      lists sorted by falling length and padded to 4: every trip is 4 independent loads, added in list order ----
-    for (int it = lane; it < ((RB_TREE_SKIP & 8) ? 0 : t.n_act * E * 6); it += 64) {
+    for (int it = lane; it < ((RB_TREE_SKIP & 8) ? 0 : t.n_q * E * 6); it += 64) {
         const int t2 = it / 6, comp = it - 6 * t2;
         const int a = t2 / E, e = t2 - a * E;
-        const int i = c.ti(t.o_act_link + a);
+        const int i = c.ti(t.o_lc_link + a);
         const float *W = c.env(e) + t.o_W + comp;
         float acc = 0.0f;
         const int s0 = c.ti(t.o_lc_start + a), s1 = c.ti(t.o_lc_start + a + 1);
@@ -673,27 +814,13 @@ __device__ __forceinline__ void tree_accel(const Ctx &c, const float *qj, const 
             acc += (en.z & 1) ? w2 : -w2;
             acc += (en.w & 1) ? w3 : -w3;
         }
-        c.link(e, i)[O_PA + comp] += acc;
+        c.link(e, i)[O_PT + comp] = acc;
     }
     wave_sync();
-    // ---- P5: articulated inertias, leaves to root ----
-    for (int L = ((RB_TREE_SKIP & 16) ? 0 : t.n_levels) - 1; L >= 0; --L) {
-        for (int slot = lane; slot < n_slots; slot += 64) {
-            const int o = slot >> 3, r = slot & 7, e = o >> t.lw_shift, x = o & (lw - 1);
-            const LevelRec lr = load_level(c, L, x);
-            if (lr.i >= 0) p5_octet(c, e, r, lr);
-        }
-        wave_sync();
-    }
+    // ---- P5: own inertia, children, articulated quantities, leaves to root ----
+    if (!(RB_TREE_SKIP & 16)) sweep_p5<E>(c);
     // ---- P6: accelerations, root to leaves ----
-    for (int L = 0; L < ((RB_TREE_SKIP & 32) ? 0 : t.n_levels); ++L) {
-        for (int slot = lane; slot < n_slots; slot += 64) {
-            const int o = slot >> 3, r = slot & 7, e = o >> t.lw_shift, x = o & (lw - 1);
-            const LevelRec lr = load_level(c, L, x);
-            if (lr.i >= 0) p6_octet(c, e, r, lr);
-        }
-        wave_sync();
-    }
+    if (!(RB_TREE_SKIP & 32)) sweep_p6<E>(c);
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         int e, j;
@@ -714,12 +841,10 @@ __device__ __forceinline__ void tree_integrate(const Ctx &c, float *qj, float *v
     for (int p = 0; p < NP; ++p) {
         int e, j;
         joint[p] = joint_slot<E>(t, c.lane, p, e, j);
-        const float *rec = c.tab + t.o_link + (joint[p] ? j : 0) * LINK_REC;
-        vmax[p] = joint[p] ? rec[20] : 0.0f; lo[p] = joint[p] ? rec[18] : 0.0f; hi[p] = joint[p] ? rec[19] : 0.0f;
+        const float *rec = c.tab + t.o_joint + (joint[p] ? j : 0) * 4;
+        vmax[p] = joint[p] ? rec[2] : 0.0f; lo[p] = joint[p] ? rec[0] : 0.0f; hi[p] = joint[p] ? rec[1] : 0.0f;
         ok[p] = true;
     }
-    // the zero slot behind W that pads P4's lists
-    if (c.lane < 6 * E) (c.env(c.lane / 6) + t.o_W + t.zoff)[c.lane % 6] = 0.0f;
     const float h = t.h;
     auto sat = [&](float v, int p) { return __builtin_amdgcn_fmed3f(v, -vmax[p], vmax[p]); };
     for (int sub = 0; sub < t.nsub; ++sub) {
@@ -784,7 +909,7 @@ __device__ __forceinline__ bool env_all_ok(const Ctx &c, const bool *ok, int e_q
 }
 
 template <int INTEG, int E>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512, RB_TREE_MIN_WAVES)
 tree_step_aba(const TreeDev tg, float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
               const float *__restrict__ act, float act_scale, long n) {
     constexpr int NP = Passes<E>::N;
@@ -830,7 +955,7 @@ tree_step_aba(const TreeDev tg, float *__restrict__ q, float *__restrict__ qd, u
 // order; lane e evaluates reward / done, publishes the decision, and the joint lanes draw
 // their own goal component on done.
 template <int INTEG, int E>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512, RB_TREE_MIN_WAVES)
 tree_env_step_aba(const TreeDev tg, const rbe::EnvParams ep, const rbe::GoalBox box,
                   float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
                   float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
