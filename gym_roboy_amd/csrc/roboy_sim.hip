@@ -54,13 +54,13 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define RB_BIG_BLOCK_EULER 256
 #endif
 #ifndef RB_BIG_UNROLL_EULER
-#define RB_BIG_UNROLL_EULER 1
+#define RB_BIG_UNROLL_EULER 2
 #endif
 #ifndef RB_BIG_BLOCK_RK4
 #define RB_BIG_BLOCK_RK4 256
 #endif
 #ifndef RB_BIG_UNROLL_RK4
-#define RB_BIG_UNROLL_RK4 1
+#define RB_BIG_UNROLL_RK4 2
 #endif
 using rbe::EnvParams;
 using rbe::GoalBox;
@@ -256,27 +256,31 @@ msj_rollout_fused(const Const8 c, float *__restrict__ q, float *__restrict__ qd,
     feas[i] = ok ? 1u : 0u;    // feasibility of the last step, as after n_steps single steps
 }
 
-__global__ void reset_kernel(float *q, float *qd, uint32_t *feas, const uint8_t *mask, int n_q, long n) {
+// State layout: SoA planes [n_q][n] for the env-per-lane / tendon-per-lane kernels, env-major rows
+// [n][n_q] for the joint-tree kernels (rows != 0), tree_aba.hpp.
+__device__ __forceinline__ long state_index(long i, int j, int n_q, long n, int rows) { return rows ? i * n_q + j : long(j) * n + i; }
+
+__global__ void reset_kernel(float *q, float *qd, uint32_t *feas, const uint8_t *mask, int n_q, long n, int rows) {
     const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (mask && !mask[i]) return;
-    for (int j = 0; j < n_q; ++j) { q[j * n + i] = 0.0f; qd[j * n + i] = 0.0f; }
+    for (int j = 0; j < n_q; ++j) { q[state_index(i, j, n_q, n, rows)] = 0.0f; qd[state_index(i, j, n_q, n, rows)] = 0.0f; }
     feas[i] = 1u;
 }
 
 // read-back staging: [n][n_q] q rows | [n][n_q] qd rows | [n] feasibility bytes in
 // one buffer: one kernel, one device-to-host copy, one synchronisation
-__global__ void pack_state_kernel(const float *q, const float *qd, const uint32_t *feas, float *rows, int n_q, long n) {
+__global__ void pack_state_kernel(const float *q, const float *qd, const uint32_t *feas, float *rows, int n_q, long n, int src_rows) {
     const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float *rq = rows + i * n_q, *rv = rows + n * n_q + i * n_q;
-    for (int j = 0; j < n_q; ++j) { rq[j] = q[j * n + i]; rv[j] = qd[j * n + i]; }
+    for (int j = 0; j < n_q; ++j) { rq[j] = q[state_index(i, j, n_q, n, src_rows)]; rv[j] = qd[state_index(i, j, n_q, n, src_rows)]; }
     reinterpret_cast<uint8_t *>(rows + 2 * n * n_q)[i] = feas[i] ? 1 : 0;
 }
-__global__ void unpack_rows_kernel(const float *rows, float *planes, int n_q, long n) {
+__global__ void unpack_rows_kernel(const float *rows, float *planes, int n_q, long n, int dst_rows) {
     const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    for (int j = 0; j < n_q; ++j) planes[j * n + i] = rows[i * n_q + j];
+    for (int j = 0; j < n_q; ++j) planes[state_index(i, j, n_q, n, dst_rows)] = rows[i * n_q + j];
 }
 __global__ void feas_from_u8_kernel(const uint8_t *f, uint32_t *o, long n) {
     const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -583,7 +587,7 @@ int read_state_host(rb_sim *s, float *q, float *qd, uint8_t *feasible) {
     const long n = s->n;
     const size_t plane = sizeof(float) * size_t(n) * s->n_q;
     hipLaunchKernelGGL(pack_state_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s->stream,
-                       s->d_q, s->d_qd, s->d_feas, s->d_state_rows, s->n_q, n);
+                       s->d_q, s->d_qd, s->d_feas, s->d_state_rows, s->n_q, n, s->tree ? 1 : 0);
     RB_HIP(hipGetLastError());
     RB_HIP(hipMemcpyAsync(s->h_state_rows, s->d_state_rows, 2 * plane + size_t(n), hipMemcpyDeviceToHost, s->stream));
     RB_HIP(hipStreamSynchronize(s->stream));
@@ -790,7 +794,7 @@ int rb_reset(rb_sim *s, const uint8_t *mask) {
         d_mask = s->d_u8;
     }
     hipLaunchKernelGGL(reset_kernel, dim3(blocks_for(s->n, 256)), dim3(256), 0, s->stream,
-                       s->d_q, s->d_qd, s->d_feas, d_mask, s->n_q, s->n);
+                       s->d_q, s->d_qd, s->d_feas, d_mask, s->n_q, s->n, s->tree ? 1 : 0);
     RB_HIP(hipGetLastError());
     RB_HIP(hipStreamSynchronize(s->stream));
     return RB_OK;
@@ -802,10 +806,10 @@ int rb_set_state(rb_sim *s, const float *q, const float *qd, const uint8_t *feas
     const long n = s->n;
     const unsigned g = blocks_for(n, 256);
     RB_HIP(hipMemcpyAsync(s->d_rows, q, sizeof(float) * n * s->n_q, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(unpack_rows_kernel, dim3(g), dim3(256), 0, s->stream, s->d_rows, s->d_q, s->n_q, n);
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3(g), dim3(256), 0, s->stream, s->d_rows, s->d_q, s->n_q, n, s->tree ? 1 : 0);
     RB_HIP(hipStreamSynchronize(s->stream));
     RB_HIP(hipMemcpyAsync(s->d_rows, qd, sizeof(float) * n * s->n_q, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(unpack_rows_kernel, dim3(g), dim3(256), 0, s->stream, s->d_rows, s->d_qd, s->n_q, n);
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3(g), dim3(256), 0, s->stream, s->d_rows, s->d_qd, s->n_q, n, s->tree ? 1 : 0);
     const uint8_t *d_f = nullptr;
     if (feasible) {
         RB_HIP(hipMemcpyAsync(s->d_u8, feasible, size_t(n), hipMemcpyHostToDevice, s->stream));
@@ -1006,7 +1010,7 @@ int rb_env_set_goal(rb_sim *s, const float *goal_q, const uint32_t *step_num) {
     if (!s->env_ready) return fail(RB_EINVAL, "rb_env_configure has not been called");
     const long n = s->n;
     RB_HIP(hipMemcpyAsync(s->d_rows, goal_q, sizeof(float) * n * s->n_q, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(unpack_rows_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s->stream, s->d_rows, s->d_goal, s->n_q, n);
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s->stream, s->d_rows, s->d_goal, s->n_q, n, s->tree ? 1 : 0);
     RB_HIP(hipGetLastError());
     if (step_num)
         RB_HIP(hipMemcpyAsync(s->d_step_num, step_num, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s->stream));

@@ -42,6 +42,9 @@
 // The model is DESIGN.md §2; oracle/physics_np.py (Jacobian-sum M, RNE bias, dense solve) is what
 // this is checked against; tools/proto/aba_world.py is the fp64 prototype of this formulation
 // (agrees with the oracle to 3e-15).  Algorithmic HBM bytes per env step: 4 (4 n_q + n_t + 1).
+// State layout in HBM for this kernel class: env-major rows q[n][n_q], qd[n][n_q], goal[n][n_q] (a wave's
+// E envs are one contiguous run; the SoA planes of the env-per-lane kernels would cost a cache line per
+// joint and wave: 6.4x the algorithmic bytes by PMC).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -928,8 +931,8 @@ tree_step_aba(const TreeDev tg, float *__restrict__ q, float *__restrict__ qd, u
         int e, j;
         const bool js = joint_slot<E>(tg, lane, p, e, j);
         const long env = env0 + e < n ? env0 + e : n - 1;
-        qj[p] = js ? q[long(j) * n + env] : 0.0f;
-        vj[p] = js ? qd[long(j) * n + env] : 0.0f;
+        qj[p] = js ? q[env * tg.n_q + j] : 0.0f;          // env-major rows [n][n_q]: a wave's E envs are contiguous
+        vj[p] = js ? qd[env * tg.n_q + j] : 0.0f;
     }
     // activation offsets u = ksg * set-point (what the tendon phase consumes), once per env step
     for (int it = lane; it < E * tg.n_t; it += 64) {
@@ -943,7 +946,7 @@ tree_step_aba(const TreeDev tg, float *__restrict__ q, float *__restrict__ qd, u
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         int e, j;
-        if (joint_slot<E>(tg, lane, p, e, j) && env0 + e < n) { q[long(j) * n + env0 + e] = qj[p]; qd[long(j) * n + env0 + e] = vj[p]; }
+        if (joint_slot<E>(tg, lane, p, e, j) && env0 + e < n) { q[(env0 + e) * tg.n_q + j] = qj[p]; qd[(env0 + e) * tg.n_q + j] = vj[p]; }
     }
     if (lane < E && env0 + lane < n) feas[env0 + lane] = all_ok ? 1u : 0u;
 }
@@ -979,9 +982,9 @@ tree_env_step_aba(const TreeDev tg, const rbe::EnvParams ep, const rbe::GoalBox 
         int e, j;
         const bool js = joint_slot<E>(tg, lane, p, e, j);
         const long env = env0 + e < n ? env0 + e : n - 1;
-        qj[p] = js ? q[long(j) * n + env] : 0.0f;
-        vj[p] = js ? qd[long(j) * n + env] : 0.0f;
-        gj[p] = js ? goal[long(j) * n + env] : 0.0f;
+        qj[p] = js ? q[env * tg.n_q + j] : 0.0f;          // env-major rows [n][n_q]: a wave's E envs are contiguous
+        vj[p] = js ? qd[env * tg.n_q + j] : 0.0f;
+        gj[p] = js ? goal[env * tg.n_q + j] : 0.0f;
     }
     for (int it = lane; it < E * tg.n_t; it += 64) {
         int e, k;
@@ -1043,9 +1046,9 @@ tree_env_step_aba(const TreeDev tg, const rbe::EnvParams ep, const rbe::GoalBox 
                 gj[p] = draw_goal(draw + 1u);
                 qj[p] = 0.0f; vj[p] = 0.0f; oq = 0.0f; ov = 0.0f; og = gj[p];
             }
-            goal[long(j) * n + env] = gj[p];
+            goal[env * nq + j] = gj[p];
         }
-        q[long(j) * n + env] = qj[p]; qd[long(j) * n + env] = vj[p];
+        q[env * nq + j] = qj[p]; qd[env * nq + j] = vj[p];
         float *orow = obs + env * (3 * nq);
         orow[j] = oq; orow[nq + j] = ov; orow[2 * nq + j] = og;
     }
@@ -1078,7 +1081,7 @@ __global__ void tree_env_reset_kernel(const rbe::GoalBox box, float *q, float *q
         for (int k = 0; k < 4 && 4 * b + k < n_q; ++k) {
             const int j = 4 * b + k;
             const float g = rbe::goal_value(box.lo[j], box.hi[j], r.v[k]);
-            q[j * n + i] = 0.0f; qd[j * n + i] = 0.0f; goal[j * n + i] = g;
+            q[i * n_q + j] = 0.0f; qd[i * n_q + j] = 0.0f; goal[i * n_q + j] = g;
             if (obs) { obs[i * 3 * n_q + j] = 0.0f; obs[i * 3 * n_q + n_q + j] = 0.0f; obs[i * 3 * n_q + 2 * n_q + j] = g; }
         }
     }

@@ -98,6 +98,9 @@ class PPO:
         if dist is not None and dist.is_available() and dist.is_initialized():
             for p in self.policy.parameters():          # same initial weights on every rank
                 dist.broadcast(p.data, 0)
+            # ... but each rank's own exploration noise and minibatch order: the reference seeds worker
+            # `rank` with seed + rank (/root/reference/gym_roboy/train_parallel.py:24)
+            torch.manual_seed(seed + dist.get_rank())
         multi_rank = dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.use_graphs = bool(use_graphs) and self.device.type == "cuda" and hasattr(env, "step_dev") and not multi_rank
         self.opt = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5)

@@ -156,6 +156,9 @@ int rb_step(rb_sim *sim, const float *act, float act_scale,
 int rb_sample_goals(rb_sim *sim, const uint8_t *mask, float *goal_q);
 
 /* ---- device-pointer entry points (asynchronous on the handle's stream) ---- */
+/* The library's own state buffers, in place.  Layout by kernel class: ball-joint robots keep SoA planes
+ * q[n_q][n_envs], qd[n_q][n_envs] (one env per lane reads a plane element each); joint-tree robots keep
+ * env-major rows q[n_envs][n_q], qd[n_envs][n_q] (a wave owns a few whole envs).  feasible[n_envs] either way. */
 int rb_state_ptrs(rb_sim *sim, float **d_q, float **d_qd, uint32_t **d_feasible);
 int rb_step_dev(rb_sim *sim, const float *d_act, float act_scale);
 /* n_steps per-step launches; step t reads slab (t % ring) of d_act_ring

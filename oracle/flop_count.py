@@ -31,17 +31,26 @@ def _lib():
 def count_msj_step(desc, integrator, q, qd, sp, step_size=0.1, n_substeps=1):
     """One instrumented env step of the ball-joint closed form.  Returns
     (counts dict, q', qd', feasible)."""
-    lib = _lib()
+    return _count(_lib().fc_msj_step, desc, integrator, q, qd, sp, step_size, n_substeps)
+
+
+def count_tree_step(desc, integrator, q, qd, sp, step_size=0.1, n_substeps=1):
+    """One instrumented env step of the joint-tree form (articulated-body algorithm in world
+    coordinates, tendons as link crossings: what csrc/tree_aba.hpp evaluates)."""
+    return _count(_lib().fc_tree_step, desc, integrator, q, qd, sp, step_size, n_substeps)
+
+
+def _count(fn, desc, integrator, q, qd, sp, step_size, n_substeps):
     q = np.array(q, dtype=np.float64)
     qd = np.array(qd, dtype=np.float64)
     sp = np.ascontiguousarray(sp, dtype=np.float64)
     out = np.zeros(5, np.uint64)
     feas = ctypes.c_ubyte(0)
-    rc = lib.fc_msj_step(ctypes.byref(desc.as_c_struct()), ctypes.c_double(step_size), int(n_substeps),
+    rc = fn(ctypes.byref(desc.as_c_struct()), ctypes.c_double(step_size), int(n_substeps),
                          int(integrator), q.ctypes.data_as(ctypes.c_void_p), qd.ctypes.data_as(ctypes.c_void_p),
                          sp.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(feas))
     if rc:
-        raise RuntimeError("fc_msj_step failed: %d" % rc)
+        raise RuntimeError("flop-count step failed: %d" % rc)
     counts = {k: int(v) for k, v in zip(FIELDS, out)}
     counts["flops"] = sum(counts[k] for k in FIELDS)
     # fewest VALU instructions that can carry these operations: every add fused with a multiply where
@@ -57,12 +66,20 @@ def table():
     q = rng.uniform(0.5 * desc.q_lo, 0.5 * desc.q_hi)
     qd = rng.uniform(-0.5 * desc.qd_max, 0.5 * desc.qd_max)
     sp = rng.uniform(-0.3, 0.3, desc.n_t)
-    out = {"_about": "floating-point operations per env step, counted by oracle/flop_count.cpp (the kernels' closed "
-                     "form instantiated with a tallying scalar); flops = add + mul + div + minmax + trans; "
+    out = {"_about": "floating-point operations per env step, counted by oracle/flop_count.cpp (MsjRobot: the kernels' closed "
+                     "form instantiated with a tallying scalar; UpperBodyRobot: a scalar restatement of tree_aba.hpp's algorithm); flops = add + mul + div + minmax + trans; "
                      "regenerate with `python -m oracle.flop_count`"}
     for name, integ in (("euler", 0), ("rk4", 1)):
         c, *_ = count_msj_step(desc, integ, q, qd, sp)
         out["MsjRobot/%s" % name] = c
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    desc = UpperBodyRobot().get_description()
+    q = rng.uniform(0.5 * desc.q_lo, 0.5 * desc.q_hi)
+    qd = rng.uniform(-0.5 * desc.qd_max, 0.5 * desc.qd_max)
+    sp = rng.uniform(-0.3, 0.3, desc.n_t)
+    for name, integ in (("euler", 0), ("rk4", 1)):
+        c, *_ = count_tree_step(desc, integ, q, qd, sp)
+        out["UpperBodyRobot/%s" % name] = c
     return out
 
 

@@ -81,8 +81,8 @@ def test_bench_collective_path_with_one_rccl_rank():
     assert d["n_gpus"] == 1 and d["steps"] == 20
     c = d["collective"]
     assert c["ok"] and c["world_size"] == 1 and c["backend"].startswith("rccl")
-    assert c["allreduce_calls"] == d["repeats"] + 1            # one per timed region (+ the rehearsal region)
-    assert c["n_env_steps_allreduced"] == c["expected"] == 262144.0 * (16 + 5 + 20 * (d["repeats"] + 1))
+    assert c["allreduce_calls"] == d["repeats"] + 2            # one per timed region (+ the rehearsal and the sizing region)
+    assert c["n_env_steps_allreduced"] == c["expected"] == 262144.0 * (16 + 5 + 20 * (d["repeats"] + 2))
     assert d["sanity"]["allreduced_stats"][6] == c["expected"]
     assert d["ms_per_step"] * 1e3 < 1.25 * d["roofline"]["launch_us_events"]
 
@@ -94,5 +94,5 @@ def test_bench_collective_with_full_chunks():
     d = _run(["--gpus", "1", "--steps", "250", "--warmup", "10", "--no-also", "--no-cpu-baseline",
               "--workload", "msj-4096-euler", "--repeats", "3"], env=env)
     c = d["collective"]
-    assert c["ok"] and c["allreduce_calls"] == 3 * 4 and c["every_steps"] == 100
+    assert c["ok"] and c["allreduce_calls"] == 3 * 4 and c["every_steps"] == 100     # --repeats given: no sizing region
     assert c["expected"] == 4096.0 * (16 + 10 + 250 * 4)

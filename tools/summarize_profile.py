@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Turn one tools/gpu_r2_profile.sh run (gpurun_out/<tag>/) into the committed summaries under profiles/<tag>/:
+kernel_stats.csv / domain_stats.csv (rocprofv3 --kernel-trace --stats of the default bench command), the bench
+JSON lines, hbm_traffic_pmc.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes per workload, FETCH_SIZE
+doubled as MI355X_MICROARCH.md's HBM section prescribes for gfx950) and sq_counters.json.
+
+    python tools/summarize_profile.py r2_a
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2_a"
+SRC = os.path.join(ROOT, "gpurun_out", tag)
+DST = os.path.join(ROOT, "profiles", tag)
+os.makedirs(DST, exist_ok=True)
+STEP_KERNELS = ("msj_step_env_per_lane", "msj_step_tendon_per_lane", "tree_step_aba", "msj_env_step_kernel")
+
+
+def counters(dirname):
+    """{kernel name: {counter: [values per dispatch]}} of one pass, step kernels only"""
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(SRC, dirname, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if any(k in row["Kernel_Name"] for k in STEP_KERNELS):
+                out[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return out
+
+
+def mean_tail(v, skip=10):
+    v = v[skip:] if len(v) > 2 * skip else v
+    return sum(v) / len(v), len(v)
+
+
+for name in ("bench_unprofiled.json", "bench_under_rocprof.json", "bench_2rank_gloo.json"):
+    p = os.path.join(SRC, name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(DST, name))
+for f in glob.glob(os.path.join(SRC, "prof_stats", "**", "*_stats.csv"), recursive=True):
+    base = os.path.basename(f).split("_", 1)[1]
+    shutil.copy(f, os.path.join(DST, base))
+
+traffic = {}
+for d in sorted(glob.glob(os.path.join(SRC, "pmc_*_FETCH_SIZE"))):
+    w = os.path.basename(d)[len("pmc_"):-len("_FETCH_SIZE")]
+    fetch = counters(os.path.basename(d))
+    write = counters("pmc_%s_WRITE_SIZE" % w)
+    if not fetch or not write:
+        continue
+    # the dominant step kernel of the pass = the one with the most dispatches
+    kern = max(fetch, key=lambda k: len(fetch[k]["FETCH_SIZE"]))
+    fm, fn = mean_tail(fetch[kern]["FETCH_SIZE"])
+    wm, wn = mean_tail(write[kern]["WRITE_SIZE"])
+    traffic[w] = {"FETCH_SIZE": {"dispatches": fn, "mean_KiB": fm}, "WRITE_SIZE": {"dispatches": wn, "mean_KiB": wm},
+                  "kernel": kern, "hbm_bytes_per_launch": (2.0 * fm + wm) * 1024.0,
+                  "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md HBM section); "
+                                "WRITE_SIZE as reported; KiB -> bytes"}
+with open(os.path.join(DST, "hbm_traffic_pmc.json"), "w") as fh:
+    json.dump(traffic, fh, indent=1, sort_keys=True)
+    fh.write("\n")
+
+sq = {}
+for d in sorted(glob.glob(os.path.join(SRC, "pmc_*_SQ1"))):
+    w = os.path.basename(d)[len("pmc_"):-len("_SQ1")]
+    merged = collections.defaultdict(dict)
+    for part in ("SQ1", "SQ2"):
+        for kern, cs in counters("pmc_%s_%s" % (w, part)).items():
+            for cname, vals in cs.items():
+                merged[kern][cname] = mean_tail(vals)[0]
+    if not merged:
+        continue
+    kern = max(merged, key=lambda k: merged[k].get("SQ_WAVES", 0))
+    c = merged[kern]
+    waves = c.get("SQ_WAVES", 0) or 1.0
+    per_wave = {k: c[k] / waves for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES") if k in c}
+    frac = {k: c[k] / c["SQ_WAVE_CYCLES"] for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") if k in c and c.get("SQ_WAVE_CYCLES")}
+    sq[w] = {"kernel": kern, "per_launch": dict(c), "per_wave": per_wave, "fraction_of_wave_cycles": frac,
+             "note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, cycle constants)"}
+with open(os.path.join(DST, "sq_counters.json"), "w") as fh:
+    json.dump(sq, fh, indent=1, sort_keys=True)
+    fh.write("\n")
+print("wrote", DST, sorted(os.listdir(DST)))
+for w, t in traffic.items():
+    print("%-24s %10.0f B/launch  %s" % (w, t["hbm_bytes_per_launch"], t["kernel"][:70]))
+for w, s in sq.items():
+    print(w, {k: round(v, 1) for k, v in s["per_wave"].items()}, {k: round(v, 3) for k, v in s["fraction_of_wave_cycles"].items()})
