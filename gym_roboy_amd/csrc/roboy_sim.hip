@@ -546,12 +546,13 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale) {
         const size_t lds = rbt::tree_lds_bytes(s->tree_host, wv);
         const long per_block = long(wv) * rbt::TREE_E;
         const unsigned tree_blocks = unsigned((n + per_block - 1) / per_block);
-        if (s->integrator == RB_EULER)
-            hipLaunchKernelGGL((rbt::tree_step_aba<0, rbt::TREE_E>), dim3(tree_blocks), dim3(64 * wv), lds, s->stream,
-                               s->tree_host.dev, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
-        else
-            hipLaunchKernelGGL((rbt::tree_step_aba<1, rbt::TREE_E>), dim3(tree_blocks), dim3(64 * wv), lds, s->stream,
-                               s->tree_host.dev, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
+#define RB_TREE_LAUNCH(INTEG, SP)                                                                                  \
+    hipLaunchKernelGGL((rbt::tree_step_aba<INTEG, rbt::TREE_E, SP>), dim3(tree_blocks), dim3(64 * wv), lds, s->stream, \
+                       s->tree_host.dev, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n)
+        const bool sp = s->tree_host.dev.single_pass != 0;
+        if (s->integrator == RB_EULER) { if (sp) RB_TREE_LAUNCH(0, true); else RB_TREE_LAUNCH(0, false); }
+        else                           { if (sp) RB_TREE_LAUNCH(1, true); else RB_TREE_LAUNCH(1, false); }
+#undef RB_TREE_LAUNCH
     } else if (s->ntx) {
 #define RB_NT_LAUNCH(INTEG, B)                                                                          \
     hipLaunchKernelGGL((msj_step_env_per_lane_nt<INTEG, B>), dim3(blocks_for(n, B)), dim3(B), 0,       \
@@ -701,10 +702,12 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
         s->tree_waves = rbt::tree_pick_waves(th);
         // more than 64 KiB of dynamic LDS per workgroup has to be granted per kernel
         const int lds_max = 160 * 1024;
-        RB_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rbt::tree_step_aba<0, rbt::TREE_E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-        RB_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rbt::tree_step_aba<1, rbt::TREE_E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-        RB_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rbt::tree_env_step_aba<0, rbt::TREE_E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-        RB_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rbt::tree_env_step_aba<1, rbt::TREE_E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+#define RB_TREE_ATTR(K) RB_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max))
+        RB_TREE_ATTR((rbt::tree_step_aba<0, rbt::TREE_E, true>)); RB_TREE_ATTR((rbt::tree_step_aba<1, rbt::TREE_E, true>));
+        RB_TREE_ATTR((rbt::tree_step_aba<0, rbt::TREE_E, false>)); RB_TREE_ATTR((rbt::tree_step_aba<1, rbt::TREE_E, false>));
+        RB_TREE_ATTR((rbt::tree_env_step_aba<0, rbt::TREE_E, true>)); RB_TREE_ATTR((rbt::tree_env_step_aba<1, rbt::TREE_E, true>));
+        RB_TREE_ATTR((rbt::tree_env_step_aba<0, rbt::TREE_E, false>)); RB_TREE_ATTR((rbt::tree_env_step_aba<1, rbt::TREE_E, false>));
+#undef RB_TREE_ATTR
     }
     RB_TRY(hipMemsetAsync(s->d_goal_count, 0, sizeof(uint32_t) * size_t(n_envs), s->stream));
     RB_TRY(hipMalloc(&s->d_infeas_n, sizeof(uint32_t) * size_t(n_envs)));
@@ -1028,12 +1031,14 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
         const int wv = s->tree_waves;
         const size_t lds = rbt::tree_lds_bytes(s->tree_host, wv);
         const long per_block = long(wv) * rbt::TREE_E;
-#define RB_TREE_ENV_LAUNCH(INTEG)                                                                          \
-    hipLaunchKernelGGL((rbt::tree_env_step_aba<INTEG, rbt::TREE_E>), dim3(unsigned((n + per_block - 1) / per_block)), dim3(64 * wv), lds, s->stream, \
+#define RB_TREE_ENV_LAUNCH(INTEG, SP)                                                                        \
+    hipLaunchKernelGGL((rbt::tree_env_step_aba<INTEG, rbt::TREE_E, SP>), dim3(unsigned((n + per_block - 1) / per_block)), dim3(64 * wv), lds, s->stream, \
                        s->tree_host.dev, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, \
                        s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done, s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, \
                        n, s->seed, uint64_t(s->env0))
-        if (s->integrator == RB_EULER) RB_TREE_ENV_LAUNCH(0); else RB_TREE_ENV_LAUNCH(1);
+        const bool sp = s->tree_host.dev.single_pass != 0;
+        if (s->integrator == RB_EULER) { if (sp) RB_TREE_ENV_LAUNCH(0, true); else RB_TREE_ENV_LAUNCH(0, false); }
+        else                           { if (sp) RB_TREE_ENV_LAUNCH(1, true); else RB_TREE_ENV_LAUNCH(1, false); }
 #undef RB_TREE_ENV_LAUNCH
         RB_HIP(hipGetLastError());
         s->env_steps += double(n);

@@ -168,3 +168,53 @@ def test_fused_env_layer_on_the_upper_body_matches_host_replay(upper_body, auto_
                                     "n_infeasible_steps", "n_env_steps", "sum_reward")])
     np.testing.assert_allclose(got, host.stats, rtol=1e-4, atol=5e-2)
     vec.close(); host.stepper.close()
+
+
+def _hand_robot(msj_robot, n_fingers=6):
+    """A palm on one revolute with `n_fingers` two-joint fingers: the tree level of the finger bases is wider
+    than one pass of a wave holds (2 envs x 8 octet slots x 8 lanes > 64), so the joint-tree kernel takes its
+    multi-pass form (no register chaining), and a link with more than 4 children in other octets gathers the
+    rest through the child list.  Tendons: two per finger, each crossing two links; one routed palm -> base -> palm
+    -> tip with a same-link segment in between."""
+    import math
+    from gym_roboy_amd.envs.robots import RobotDescription
+    from gym_roboy_amd.envs.robots.description import FORMAT_TAG
+
+    def joint(name, parent, axis, origin, mass, com, limit):
+        return {"name": name, "parent": parent, "axis": axis, "origin": origin, "mass": mass, "com": com,
+                "inertia": [2e-4 * mass / 0.05, 2e-4 * mass / 0.05, 1e-4 * mass / 0.05, 0.0, 0.0, 0.0] if mass else [0.0] * 6,
+                "armature": 0.05, "damping": 0.3, "limit": [-limit, limit], "max_velocity": math.pi / 6}
+    joints = [joint("palm", -1, [0, 1, 0], [0, 0, 0.0], 0.4, [0, 0, 0.04], 0.5)]
+    tendons = []
+    for f in range(n_fingers):
+        ang = 2 * math.pi * f / n_fingers
+        ox, oy = 0.05 * math.cos(ang), 0.05 * math.sin(ang)
+        b = len(joints)
+        joints.append(joint("f%d_base" % f, 0, [-math.sin(ang), math.cos(ang), 0.0], [ox, oy, 0.08], 0.05, [0, 0, 0.02], 0.6))
+        joints.append(joint("f%d_tip" % f, b, [-math.sin(ang), math.cos(ang), 0.0], [0, 0, 0.04], 0.03, [0, 0, 0.015], 0.6))
+        for sgn in (1.0, -1.0):
+            px, py = ox + sgn * 0.012 * math.cos(ang), oy + sgn * 0.012 * math.sin(ang)
+            tendons.append({"name": "f%d_%s" % (f, "flex" if sgn > 0 else "ext"), "f_max": 20.0,
+                            "via_points": [{"link": -1, "pos": [px * 1.2, py * 1.2, -0.03]},
+                                           {"link": 0, "pos": [px, py, 0.05]}, {"link": 0, "pos": [px, py, 0.075]},
+                                           {"link": b, "pos": [sgn * 0.012 * math.cos(ang), sgn * 0.012 * math.sin(ang), 0.03]},
+                                           {"link": b + 1, "pos": [sgn * 0.010 * math.cos(ang), sgn * 0.010 * math.sin(ang), 0.03]}]})
+    spec = {"format": FORMAT_TAG, "name": "hand", "gravity": [0.0, 0.0, -9.81], "joints": joints, "tendons": tendons,
+            "muscle": {"kp": 10.0, "setpoint_scale": 0.02, "v_max": 8.0, "fl_width": 0.45, "kpe": 4.0, "e0": 0.6,
+                       "fv_a": 0.25, "fv_n": 1.5}}
+    desc = RobotDescription(spec)
+
+    class Hand(type(msj_robot)):
+        @classmethod
+        def get_description(cls):
+            return desc
+    return Hand(), desc
+
+
+@pytest.mark.parametrize("integrator", ["euler", "rk4"])
+def test_wide_tree_takes_the_multi_pass_form_and_matches_the_oracle(msj_robot, integrator):
+    from oracle.c_oracle import COracle
+    robot, desc = _hand_robot(msj_robot)
+    assert desc.n_q == 13 and desc.n_t == 12
+    _check(robot, COracle(desc, "f64"), 301, integrator, 1, seed=11)
+    _check(robot, COracle(desc, "f64"), 7, integrator, 2, seed=12)
