@@ -149,7 +149,10 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
     ring = torch.empty(RING * slab, dtype=torch.float32, device="cuda")
     for r in range(RING):
         sim.fill_actions_dev(ring.data_ptr() + 4 * r * slab, r)
-    # statistics all-reduce: 64 bytes, enqueued IN-LINE on the launch stream (a non-async
+    # Episode statistics: every rank reduces its envs' counters on the device (rb_env_stats_dev) after every
+    # STATS_EVERY steps and at the end of every timed region - at N = 1 too, so that every N runs the same
+    # per-GPU work and the scaling curve measures the collective alone - and N > 1 all-reduces the block.
+    # The all-reduce: 64 bytes, enqueued IN-LINE on the launch stream (a non-async
     # c10d op runs on the current stream).  Measured on one MI355X (profiles/r1_b/
     # rccl_one_rank_rehearsal.log): letting the collective run concurrently on a second
     # stream (async_op=True, or an own side stream) slows the graph-replayed step kernels
@@ -165,14 +168,16 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
         buf = stats_ring[state["chunk"] % 2]
         state["chunk"] += 1
         nat.check(sim._lib.rb_env_stats_dev(sim.handle, ctypes.c_void_p(buf.data_ptr()), 0))
+        state["last"] = buf
+        state["calls"] += 1
+        if dist is None:                                            # one GPU: the local reduction alone
+            return
         if dist.get_backend() == "nccl":
             dist.all_reduce(buf)                                    # RCCL over xGMI
         else:                                                       # rehearsal over gloo: through the host
             host = buf.cpu()
             dist.all_reduce(host)
             buf.copy_(host)
-        state["last"] = buf
-        state["calls"] += 1
 
     def rollout(k, final_reduce=False):
         """k per-step launches; the statistics block is all-reduced after every full
@@ -185,10 +190,10 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
             done += chunk
             state["steps_issued"] += chunk
             reduced = False
-            if dist is not None and chunk == STATS_EVERY:
+            if chunk == STATS_EVERY:
                 reduce_stats()
                 reduced = True
-        if dist is not None and final_reduce and not reduced:
+        if final_reduce and not reduced:
             reduce_stats()
 
     def timed_region():
@@ -210,9 +215,8 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
             state["steps_issued"] += chunk
             if done == steps:
                 ev1.record(stream)
-            if dist is not None:
-                if chunk == STATS_EVERY or done == steps:
-                    reduce_stats()               # at least one per region, whatever K is
+            if chunk == STATS_EVERY or done == steps:
+                reduce_stats()                   # at least one per region, whatever K is (one GPU: the local reduction alone)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0          # this rank: start of the region -> its work is complete
         if dist is not None:

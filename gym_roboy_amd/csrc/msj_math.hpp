@@ -329,16 +329,16 @@ struct MsjModel {
         for (int j = 0; j < 3; ++j) out[j] = tclamp(v[j], -c.qdmax[j], c.qdmax[j]);
     }
 
-    // velocity saturation + joint limits; returns false when a limit was hit
+    // velocity saturation + joint limits; returns false when a limit was hit.  A joint beyond a limit is
+    // clamped onto it and keeps only the inward part of its (saturated) velocity: the velocity box shrinks
+    // to [-vmax, 0] at the upper limit and to [0, vmax] at the lower one, so one clamp does both.
     static RB_HD bool limit(const C &c, T q[3], T qd[3]) {
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            T v = tclamp(qd[j], -c.qdmax[j], c.qdmax[j]);
             const bool over = q[j] > c.qhi[j], under = q[j] < c.qlo[j];
-            if (over) { q[j] = c.qhi[j]; v = tmin(v, T(0)); }
-            if (under) { q[j] = c.qlo[j]; v = tmax(v, T(0)); }
-            qd[j] = v;
+            qd[j] = tclamp(qd[j], under ? T(0) : -c.qdmax[j], over ? T(0) : c.qdmax[j]);
+            q[j] = tclamp(q[j], c.qlo[j], c.qhi[j]);
             ok = ok && !(over || under);
         }
         return ok;

@@ -89,10 +89,14 @@ struct SpLds {
     __device__ __forceinline__ float operator()(int k) const { return col[k * stride]; }
 };
 
+// set-point -> activation offset, per tendon: act_scale * ksg_k, multiplied out on the host once per launch
+// (on the device the product of two kernarg scalars costs a v_mov and a v_mul per lane and tendon)
+struct Scale8 { float v[NT8]; };
+
 template <int INTEG, int BLOCK, int UNROLL>
 __global__ void __launch_bounds__(BLOCK)
 msj_step_env_per_lane(const Const8 c, float *__restrict__ q, float *__restrict__ qd,
-                      uint32_t *__restrict__ feas, const float *__restrict__ act, float act_scale, long n) {
+                      uint32_t *__restrict__ feas, const float *__restrict__ act, const Scale8 us, long n) {
     const long i = long(blockIdx.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     float qq[3], vv[3], sp[NT8];
@@ -100,10 +104,10 @@ msj_step_env_per_lane(const Const8 c, float *__restrict__ q, float *__restrict__
     const float4 a1 = reinterpret_cast<const float4 *>(act)[2 * i + 1];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { qq[j] = q[j * n + i]; vv[j] = qd[j * n + i]; }
-    // activation offsets u_k = ksg_k * (act_scale * action_k): what the model's tendon loop consumes
+    // activation offsets u_k = (act_scale * ksg_k) * action_k: what the model's tendon loop consumes
     const float a[NT8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-    for (int k = 0; k < NT8; ++k) sp[k] = a[k] * (act_scale * c.ten[k].ksg);
+    for (int k = 0; k < NT8; ++k) sp[k] = a[k] * us.v[k];
     bool ok;
     if (UNROLL >= NT8) {
         ok = rb::MsjModel<float, NT8>::template step_sp<INTEG, UNROLL>(c, qq, vv, rb::SpArray<float, NT8>{sp});
@@ -222,7 +226,7 @@ msj_step_tendon_per_lane(const Const8 c, const rb::MsjTendon<float> *__restrict_
 template <int INTEG, int BLOCK, int UNROLL>
 __global__ void __launch_bounds__(BLOCK)
 msj_rollout_fused(const Const8 c, float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
-                  const float *__restrict__ act_ring, int ring, int n_steps, float act_scale, long n) {
+                  const float *__restrict__ act_ring, int ring, int n_steps, const Scale8 us, long n) {
     const long i = long(blockIdx.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     float qq[3], vv[3];
@@ -237,7 +241,7 @@ msj_rollout_fused(const Const8 c, float *__restrict__ q, float *__restrict__ qd,
         const float a[NT8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
         float sp[NT8];
 #pragma unroll
-        for (int k = 0; k < NT8; ++k) sp[k] = a[k] * (act_scale * c.ten[k].ksg);
+        for (int k = 0; k < NT8; ++k) sp[k] = a[k] * us.v[k];
         if (t + 1 < n_steps) {   // next step's action: in flight under this step's arithmetic
             slab = slab + 1 == ring ? 0 : slab + 1;
             const float4 *nx = rec + long(slab) * 2 * n;
@@ -428,40 +432,70 @@ msj_env_step_kernel(const CONST c, const EnvParams e, const GoalBox box,
     reward[i] = r; done[i] = dn ? 1u : 0u;
 }
 
-// rb_env_stats: block-reduce the per-env accumulators in fp64, one atomic per
-// block and statistic (runs once per reporting interval, not per step)
+// rb_env_stats: reduce the per-env accumulators in fp64, ONE launch and nothing else (no memset, no copy:
+// the statistics run at the end of every reporting interval of a rollout).  Every block leaves its 8 partial
+// sums in `partials`, takes a ticket, and the block that arrives last adds the partials up - thread b owns
+// block b's row, then a fixed shuffle / LDS tree - and writes the result to `out` and, if given, `out2`
+// (the caller's device buffer).  The sum has a fixed order: bit-reproducible, unlike float atomics.
+// Hand-off as MI355X_MICROARCH.md prescribes: stores -> agent-scope release -> vmcnt(0) -> ticket; the last
+// block: ticket value -> agent-scope acquire -> barrier -> plain loads.
+constexpr int STATS_BLOCKS = 256;
 __global__ void __launch_bounds__(256)
 stats_reduce_kernel(const double *ep_sum, const uint32_t *ep_cnt, const float *ep_ret, const uint32_t *infeas_n,
-                    const uint32_t *feas, double *out, double env_steps, long n) {
-    __shared__ double sh[4][7];
-    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+                    const uint32_t *feas, double *partials, unsigned int *ticket, double *out, double *out2,
+                    double env_steps, long n) {
+    __shared__ double sh[4][8];
+    __shared__ bool last;
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // [sum return, sum return^2, n_episodes, sum length, n_goal, n_infeasible, -, running returns]
     for (long i = long(blockIdx.x) * 256 + threadIdx.x; i < n; i += long(gridDim.x) * 256) {
         if (ep_sum) {
             v[0] += ep_sum[i]; v[1] += ep_sum[n + i];
 #pragma unroll
             for (int k = 0; k < 3; ++k) v[2 + k] += double(ep_cnt[k * n + i]);
-            v[6] += double(ep_ret[i]);
+            v[7] += double(ep_ret[i]);
             v[5] += double(infeas_n[i]);     // env layer: infeasible env-steps since the reset
         } else {
             v[5] += feas[i] ? 0.0 : 1.0;     // plain rollouts: envs flagged infeasible right now
         }
     }
+    auto block_sum = [&]() {                 // -> sh[0][k] in threads 0..7 after the barrier
 #pragma unroll
-    for (int k = 0; k < 7; ++k)
-        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 7; ++k) sh[w][k] = v[k];
+        for (int k = 0; k < 8; ++k)
+            for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0)
+            for (int k = 0; k < 8; ++k) sh[w][k] = v[k];
+        __syncthreads();
+    };
+    block_sum();
+    if (threadIdx.x < 8)
+        partials[blockIdx.x * 8 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    if (threadIdx.x == 0) last = false;
     __syncthreads();
-    if (threadIdx.x < 7) {
-        const double t = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
-        // out: [sum return, sum return^2, n_episodes, sum length, n_goal, n_infeasible, (n_env_steps), sum reward]
-        const int slot = threadIdx.x < 6 ? threadIdx.x : 7;
-        // sum reward = finished returns + running returns
-        if (threadIdx.x == 6) unsafeAtomicAdd(out + 7, t + sh[0][0] + sh[1][0] + sh[2][0] + sh[3][0]);
-        else unsafeAtomicAdd(out + slot, t);
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 7) out[6] = env_steps;
+    __syncthreads();
+    if (!last) return;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = threadIdx.x < gridDim.x ? __hip_atomic_load(partials + threadIdx.x * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    __syncthreads();
+    block_sum();
+    if (threadIdx.x < 8) {
+        double t = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        // out: [sum return, sum return^2, n_episodes, sum length, n_goal, n_infeasible, n_env_steps, sum reward]
+        if (threadIdx.x == 6) t = env_steps;
+        if (threadIdx.x == 7) t += sh[0][0] + sh[1][0] + sh[2][0] + sh[3][0];      // sum reward = finished + running returns
+        out[threadIdx.x] = t;
+        if (out2) out2[threadIdx.x] = t;
+    }
+    if (threadIdx.x == 0) *ticket = 0u;       // ready for the next launch (same stream: ordered behind this kernel)
 }
 
 __global__ void env_reset_kernel(const GoalBox box, float *q, float *qd, uint32_t *feas, float *goal,
@@ -514,7 +548,7 @@ struct rb_sim {
     double *d_ep_sum = nullptr;      // [2][n]: sum of episode returns, sum of squared returns
     uint32_t *d_ep_cnt = nullptr;    // [3][n]: episodes, summed episode length, goals reached
     uint32_t *d_step_num = nullptr, *d_infeas_n = nullptr;
-    double *d_stats = nullptr;   // [8] scratch of the reduction
+    double *d_stats = nullptr;   // [8] result of the reduction, then [STATS_BLOCKS][8] block partials, then the ticket word
     double env_steps = 0.0;      // env steps issued since the statistics were reset
     // host I/O staging
     float *d_rows = nullptr;   // [n][max(n_q, n_t)]
@@ -538,9 +572,11 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale) {
     // workgroup spread over the CUs, tendon loop fully unrolled for ILP.
     // Large batches are VALU-issue-bound: rolled tendon loop (one 16-dword
     // scalar load per trip, 53 VGPRs, 8 waves/SIMD).  Measured: DESIGN.md §7.
+    Scale8 us;
+    for (int k = 0; k < NT8; ++k) us.v[k] = act_scale * s->c8.ten[k].ksg;
 #define RB_STEP_LAUNCH(INTEG, B, U)                                                                   \
     hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U>), dim3(blocks_for(n, B)), dim3(B), 0,      \
-                       s->stream, s->c8, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n)
+                       s->stream, s->c8, s->d_q, s->d_qd, s->d_feas, d_act, us, n)
     if (s->tree) {
         const int wv = s->tree_waves;
         const size_t lds = rbt::tree_lds_bytes(s->tree_host, wv);
@@ -712,7 +748,8 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
     RB_TRY(hipMemsetAsync(s->d_goal_count, 0, sizeof(uint32_t) * size_t(n_envs), s->stream));
     RB_TRY(hipMalloc(&s->d_infeas_n, sizeof(uint32_t) * size_t(n_envs)));
     RB_TRY(hipMemsetAsync(s->d_infeas_n, 0, sizeof(uint32_t) * size_t(n_envs), s->stream));
-    RB_TRY(hipMalloc(&s->d_stats, sizeof(double) * 8));
+    RB_TRY(hipMalloc(&s->d_stats, sizeof(double) * 8 * (STATS_BLOCKS + 2)));
+    RB_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(double) * 8 * (STATS_BLOCKS + 2), s->stream));
 #undef RB_TRY
     *out = s;
     (void)rb_select_kernel(s, RB_KERNEL_AUTO);
@@ -928,9 +965,11 @@ int rb_rollout_fused_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, 
     if (s->tree || s->ntx) return fail(RB_EUNSUPPORTED, "fused rollout is built for 8-tendon ball-joint robots");
     if (n_steps == 0) return RB_OK;
     const long n = s->n;
+    Scale8 us;
+    for (int k = 0; k < NT8; ++k) us.v[k] = act_scale * s->c8.ten[k].ksg;
 #define RB_FUSED_LAUNCH(INTEG, B, U)                                                                  \
     hipLaunchKernelGGL((msj_rollout_fused<INTEG, B, U>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream, \
-                       s->c8, s->d_q, s->d_qd, s->d_feas, d_ring, ring, n_steps, act_scale, n)
+                       s->c8, s->d_q, s->d_qd, s->d_feas, d_ring, ring, n_steps, us, n)
     const bool euler = s->integrator == RB_EULER;
     if (n <= RB_SMALL_BATCH) { if (euler) RB_FUSED_LAUNCH(0, 64, 8); else RB_FUSED_LAUNCH(1, 64, 8); }
     else                     { if (euler) RB_FUSED_LAUNCH(0, RB_BIG_BLOCK_EULER, RB_BIG_UNROLL_EULER); else RB_FUSED_LAUNCH(1, RB_BIG_BLOCK_RK4, RB_BIG_UNROLL_RK4); }
@@ -1068,15 +1107,15 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
     return RB_OK;
 }
 
-static int stats_launch(rb_sim *s, int reset) {
-    RB_HIP(hipMemsetAsync(s->d_stats, 0, sizeof(double) * 8, s->stream));
+static int stats_launch(rb_sim *s, double *d_out2) {
     unsigned g = blocks_for(s->n, 256);
-    if (g > 1024) g = 1024;
+    if (g > unsigned(STATS_BLOCKS)) g = STATS_BLOCKS;
+    double *partials = s->d_stats + 8;
+    unsigned int *ticket = reinterpret_cast<unsigned int *>(s->d_stats + 8 * (STATS_BLOCKS + 1));
     hipLaunchKernelGGL(stats_reduce_kernel, dim3(g), dim3(256), 0, s->stream,
-                       s->env_ready ? s->d_ep_sum : nullptr, s->d_ep_cnt, s->d_ep_ret, s->d_infeas_n, s->d_feas, s->d_stats,
-                       s->env_steps, s->n);
+                       s->env_ready ? s->d_ep_sum : nullptr, s->d_ep_cnt, s->d_ep_ret, s->d_infeas_n, s->d_feas,
+                       partials, ticket, s->d_stats, d_out2, s->env_steps, s->n);
     RB_HIP(hipGetLastError());
-    (void)reset;
     return RB_OK;
 }
 static int stats_reset(rb_sim *s) {
@@ -1092,16 +1131,15 @@ static int stats_reset(rb_sim *s) {
 int rb_env_stats_dev(rb_sim *s, double *d_stats8, int reset) {
     if (check(s) || !d_stats8) return fail(RB_EINVAL, "null argument");
     RB_HIP(hipSetDevice(s->device));
-    int rc = stats_launch(s, reset);
+    int rc = stats_launch(s, d_stats8);
     if (rc) return rc;
-    RB_HIP(hipMemcpyAsync(d_stats8, s->d_stats, sizeof(double) * 8, hipMemcpyDeviceToDevice, s->stream));
     return reset ? stats_reset(s) : RB_OK;
 }
 
 int rb_env_stats(rb_sim *s, double *stats8, int reset) {
     if (check(s) || !stats8) return fail(RB_EINVAL, "null argument");
     RB_HIP(hipSetDevice(s->device));
-    int rc = stats_launch(s, reset);
+    int rc = stats_launch(s, nullptr);
     if (rc) return rc;
     RB_HIP(hipMemcpyAsync(stats8, s->d_stats, sizeof(double) * 8, hipMemcpyDeviceToHost, s->stream));
     RB_HIP(hipStreamSynchronize(s->stream));
