@@ -19,6 +19,7 @@
 #include "../../include/roboy_sim.h"
 #include "msj_build.hpp"
 #include "msj_math.hpp"
+#include "msj_baked.hpp"
 #include "philox.hpp"
 #include "env_common.hpp"
 #include "tree_aba.hpp"
@@ -62,6 +63,11 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #ifndef RB_BIG_UNROLL_RK4
 #define RB_BIG_UNROLL_RK4 2
 #endif
+// kernels instantiated on MsjRobot's baked constant table (msj_baked.hpp) unroll the tendon loop by this much
+// (U = 2 / 4 / 8: RK4 16.96 / 16.63 / 16.77 us, Euler 2M 36.9 / 35.2 / 35.3 us)
+#ifndef RB_BAKED_UNROLL
+#define RB_BAKED_UNROLL 4
+#endif
 using rbe::EnvParams;
 using rbe::GoalBox;
 using rbe::goal_value;
@@ -83,6 +89,13 @@ using ConstX = rb::MsjConst<float, NTX>;
 // sp(k) with one ds_read_b32 instead of selecting among 8 registers with a
 // runtime index (7 v_cndmask + 14 SALU per trip before).  [NT8][BLOCK] floats,
 // lane-contiguous rows: conflict-free.
+// robot constants of a kernel instance: the kernarg copy, or (BK) MsjRobot's compile-time table, which the
+// compiler folds into the instruction stream
+template <bool BK, typename CONST>
+__device__ __forceinline__ const CONST &robot_consts(const CONST &kernarg) {
+    if constexpr (BK) return rbk::BAKED; else return kernarg;
+}
+
 struct SpLds {
     const float *col;   // &lds[0][threadIdx.x]
     int stride;         // BLOCK
@@ -93,10 +106,11 @@ struct SpLds {
 // (on the device the product of two kernarg scalars costs a v_mov and a v_mul per lane and tendon)
 struct Scale8 { float v[NT8]; };
 
-template <int INTEG, int BLOCK, int UNROLL>
+template <int INTEG, int BLOCK, int UNROLL, bool BK = false>
 __global__ void __launch_bounds__(BLOCK)
-msj_step_env_per_lane(const Const8 c, float *__restrict__ q, float *__restrict__ qd,
+msj_step_env_per_lane(const Const8 c_arg, float *__restrict__ q, float *__restrict__ qd,
                       uint32_t *__restrict__ feas, const float *__restrict__ act, const Scale8 us, long n) {
+    const Const8 &c = robot_consts<BK>(c_arg);
     const long i = long(blockIdx.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     float qq[3], vv[3], sp[NT8];
@@ -223,10 +237,11 @@ msj_step_tendon_per_lane(const Const8 c, const rb::MsjTendon<float> *__restrict_
 // env's 32-byte action record is read.  Instantiated with the same BLOCK/UNROLL
 // (and the same set-point source) as msj_step_env_per_lane uses for the batch
 // size, so the arithmetic and hence the result is bit-identical to n_steps single steps.
-template <int INTEG, int BLOCK, int UNROLL>
+template <int INTEG, int BLOCK, int UNROLL, bool BK = false>
 __global__ void __launch_bounds__(BLOCK)
-msj_rollout_fused(const Const8 c, float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
+msj_rollout_fused(const Const8 c_arg, float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
                   const float *__restrict__ act_ring, int ring, int n_steps, const Scale8 us, long n) {
+    const Const8 &c = robot_consts<BK>(c_arg);
     const long i = long(blockIdx.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     float qq[3], vv[3];
@@ -334,15 +349,16 @@ __device__ __forceinline__ void draw_goal3(const GoalBox &box, uint64_t seed, ui
 }
 
 // UNROLL = 0: run-time tendon count (ConstX, c.nt tendons, action rows of c.nt floats)
-template <int INTEG, int BLOCK, int UNROLL, typename CONST = Const8>
+template <int INTEG, int BLOCK, int UNROLL, typename CONST = Const8, bool BK = false>
 __global__ void __launch_bounds__(BLOCK)
-msj_env_step_kernel(const CONST c, const EnvParams e, const GoalBox box,
+msj_env_step_kernel(const CONST c_arg, const EnvParams e, const GoalBox box,
                     float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
                     float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
                     uint32_t *__restrict__ goal_count, const float *__restrict__ act,
                     float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
                     double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt, uint32_t *__restrict__ infeas_n,
                     long n, uint64_t seed, uint64_t env0) {
+    const CONST &c = robot_consts<BK>(c_arg);
     const long i = long(blockIdx.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     float qq[3], vv[3], gg[3];
@@ -530,6 +546,7 @@ struct rb_sim {
     Const8 c8;
     ConstX cx;               // ball-joint robots with n_t != 8 (ntx = true)
     bool ntx = false;
+    bool baked = false;      // c8 equals MsjRobot's compile-time table (msj_baked.hpp): the BK kernel instances apply
     rb::MsjTendon<float> *d_ten = nullptr;   // device copy of c8.ten for the tendon-per-lane form
     int kernel_choice = RB_KERNEL_AUTO;
     // generic joint-tree robots (tree_aba.hpp): a few envs per wave, articulated-body algorithm
@@ -577,6 +594,9 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale) {
 #define RB_STEP_LAUNCH(INTEG, B, U)                                                                   \
     hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U>), dim3(blocks_for(n, B)), dim3(B), 0,      \
                        s->stream, s->c8, s->d_q, s->d_qd, s->d_feas, d_act, us, n)
+#define RB_STEP_LAUNCH_BK(INTEG, B, U)                                                                \
+    hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U, true>), dim3(blocks_for(n, B)), dim3(B), 0, \
+                       s->stream, s->c8, s->d_q, s->d_qd, s->d_feas, d_act, us, n)
     if (s->tree) {
         const int wv = s->tree_waves;
         const size_t lds = rbt::tree_lds_bytes(s->tree_host, wv);
@@ -605,11 +625,16 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale) {
             hipLaunchKernelGGL((msj_step_tendon_per_lane<1>), dim3(g), dim3(64), 0, s->stream,
                                s->c8, s->d_ten, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
     } else if (n <= RB_SMALL_BATCH) {
-        if (s->integrator == RB_EULER) RB_STEP_LAUNCH(0, 64, 8); else RB_STEP_LAUNCH(1, 64, 8);
+        if (s->baked) { if (s->integrator == RB_EULER) RB_STEP_LAUNCH_BK(0, 64, 8); else RB_STEP_LAUNCH_BK(1, 64, 8); }
+        else          { if (s->integrator == RB_EULER) RB_STEP_LAUNCH(0, 64, 8); else RB_STEP_LAUNCH(1, 64, 8); }
+    } else if (s->baked) {
+        if (s->integrator == RB_EULER) RB_STEP_LAUNCH_BK(0, RB_BIG_BLOCK_EULER, RB_BAKED_UNROLL);
+        else RB_STEP_LAUNCH_BK(1, RB_BIG_BLOCK_RK4, RB_BAKED_UNROLL);
     } else {
         if (s->integrator == RB_EULER) RB_STEP_LAUNCH(0, RB_BIG_BLOCK_EULER, RB_BIG_UNROLL_EULER);
         else RB_STEP_LAUNCH(1, RB_BIG_BLOCK_RK4, RB_BIG_UNROLL_RK4);
     }
+#undef RB_STEP_LAUNCH_BK
 #undef RB_STEP_LAUNCH
     RB_HIP(hipGetLastError());
     return RB_OK;
@@ -665,6 +690,16 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
     if (!s) return fail(RB_ENOMEM, "out of host memory");
     std::string why;
     int rc = rb::msj_build<float, NT8>(robot, step_size, n_substeps, &s->c8, why);
+    if (rc == RB_OK) {
+        // bit-for-bit equal to the baked table?  (field by field: the struct has alignment padding)
+        const Const8 &a = s->c8, &b = rbk::BAKED_HOST;
+        auto same = [](const float *x, const float *y, int n) { return std::memcmp(x, y, sizeof(float) * size_t(n)) == 0; };
+        bool eq = same(a.IO, b.IO, 6) && same(a.mc, b.mc, 3) && same(a.g, b.g, 3) && same(a.arm, b.arm, 3) && same(a.damp, b.damp, 3) &&
+                  same(a.qlo, b.qlo, 3) && same(a.qhi, b.qhi, 3) && same(a.qdmax, b.qdmax, 3) && same(&a.kps, &b.kps, 8) &&
+                  a.nsub == b.nsub && a.simple == b.simple && a.nt == b.nt;
+        for (int k = 0; k < NT8 && eq; ++k) eq = same(a.ten[k].A, b.ten[k].A, 16);
+        s->baked = eq;
+    }
     if (rc == RB_EUNSUPPORTED && robot->n_t != NT8) {
         // a ball-joint robot with another tendon count: same closed form, run-time count
         std::string why_x;
@@ -970,9 +1005,17 @@ int rb_rollout_fused_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, 
 #define RB_FUSED_LAUNCH(INTEG, B, U)                                                                  \
     hipLaunchKernelGGL((msj_rollout_fused<INTEG, B, U>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream, \
                        s->c8, s->d_q, s->d_qd, s->d_feas, d_ring, ring, n_steps, us, n)
+#define RB_FUSED_LAUNCH_BK(INTEG, B, U)                                                               \
+    hipLaunchKernelGGL((msj_rollout_fused<INTEG, B, U, true>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream, \
+                       s->c8, s->d_q, s->d_qd, s->d_feas, d_ring, ring, n_steps, us, n)
     const bool euler = s->integrator == RB_EULER;
+    if (s->baked) {
+        if (n <= RB_SMALL_BATCH) { if (euler) RB_FUSED_LAUNCH_BK(0, 64, 8); else RB_FUSED_LAUNCH_BK(1, 64, 8); }
+        else                     { if (euler) RB_FUSED_LAUNCH_BK(0, RB_BIG_BLOCK_EULER, RB_BAKED_UNROLL); else RB_FUSED_LAUNCH_BK(1, RB_BIG_BLOCK_RK4, RB_BAKED_UNROLL); }
+    } else
     if (n <= RB_SMALL_BATCH) { if (euler) RB_FUSED_LAUNCH(0, 64, 8); else RB_FUSED_LAUNCH(1, 64, 8); }
     else                     { if (euler) RB_FUSED_LAUNCH(0, RB_BIG_BLOCK_EULER, RB_BIG_UNROLL_EULER); else RB_FUSED_LAUNCH(1, RB_BIG_BLOCK_RK4, RB_BIG_UNROLL_RK4); }
+#undef RB_FUSED_LAUNCH_BK
 #undef RB_FUSED_LAUNCH
     RB_HIP(hipGetLastError());
     s->env_steps += double(n) * n_steps;
@@ -1094,6 +1137,15 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
                        s->stream, s->cx, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal,          \
                        s->d_step_num, s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done,      \
                        s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, n, s->seed, uint64_t(s->env0))
+#define RB_ENV_LAUNCH_BK(INTEG, B, U)                                                                    \
+    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, U, Const8, true>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream, \
+                       s->c8, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num,      \
+                       s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done, s->d_ep_sum,       \
+                       s->d_ep_cnt, s->d_infeas_n, n, s->seed, uint64_t(s->env0))
+    if (s->baked) {
+        if (n <= RB_SMALL_BATCH) { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_BK(0, 64, 8); else RB_ENV_LAUNCH_BK(1, 64, 8); }
+        else                     { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_BK(0, RB_BIG_BLOCK_EULER, RB_BAKED_UNROLL); else RB_ENV_LAUNCH_BK(1, RB_BIG_BLOCK_RK4, RB_BAKED_UNROLL); }
+    } else
     if (s->ntx) {
         if (n <= RB_SMALL_BATCH) { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_NT(0, 64); else RB_ENV_LAUNCH_NT(1, 64); }
         else                     { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_NT(0, 256); else RB_ENV_LAUNCH_NT(1, 256); }
@@ -1101,6 +1153,7 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
     if (n <= RB_SMALL_BATCH) { if (s->integrator == RB_EULER) RB_ENV_LAUNCH(0, 64, 8); else RB_ENV_LAUNCH(1, 64, 8); }
     else                     { if (s->integrator == RB_EULER) RB_ENV_LAUNCH(0, RB_BIG_BLOCK_EULER, RB_BIG_UNROLL_EULER); else RB_ENV_LAUNCH(1, RB_BIG_BLOCK_RK4, RB_BIG_UNROLL_RK4); }
 #undef RB_ENV_LAUNCH_NT
+#undef RB_ENV_LAUNCH_BK
 #undef RB_ENV_LAUNCH
     RB_HIP(hipGetLastError());
     s->env_steps += double(n);

@@ -112,3 +112,14 @@ def test_bench_never_prints_outside_its_json_line():
     # fd 1 itself points at stderr for the whole run (RCCL prints a banner on stdout)
     assert src.count("print(") == 0
     assert src.count("os.write(json_fd") == 1 and "os.dup2(2, 1)" in src
+
+
+def test_committed_baked_constant_table_is_current(tmp_path):
+    """gym_roboy_amd/csrc/msj_baked.hpp (MsjRobot's closed-form constants as literals, used by the BK kernel
+    instances) must be what csrc/gen_msj_baked.cpp produces from the robot description today."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_msj_baked
+    fresh = gen_msj_baked.generate(str(tmp_path / "msj_baked.hpp"))
+    committed = os.path.join(ROOT, "gym_roboy_amd", "csrc", "msj_baked.hpp")
+    assert open(fresh).read() == open(committed).read(), "run python tools/gen_msj_baked.py and rebuild"
