@@ -91,6 +91,7 @@ constexpr int F_INH = 1;        // the parent sits in the same octet one level u
 constexpr int F_ASTORE = 2;     // some child sits in another octet: the acceleration goes through LDS as well
 constexpr int F_REGCHILD = 1;   // (P5) one child sits in the same octet one level down: its I^a / p^a arrive in registers
 constexpr int F_XWRITE = 2;     // (P5) the parent sits in another octet: I^a / p^a go to the link's exchange slot
+constexpr int F_MASSLESS = 4;   // (P5) no mass, no inertia (the x / y joints of a ball joint): nothing of its own to add
 
 struct TreeDev {
     int n_q, n_t, n_cr, n_levels, nsub, n_x;   // n_x: exchange slots (links whose parent sits in another octet)
@@ -263,7 +264,8 @@ inline int tree_build(const rb_robot_desc *d, double step_size, int nsub, TreeHo
         const bool used = i >= 0;
         const int es = used ? ext_start[i] : 0, ne = used ? ext_start[i + 1] - es : 0;
         w.push_back(uint32_t(i)); w.push_back(uint32_t(used ? parent[i] : -1));
-        w.push_back(uint32_t(used ? (reg_child[i] >= 0 ? F_REGCHILD : 0) | (xslot[i] >= 0 ? F_XWRITE : 0) : 0));
+        const bool massless = used && d->mass[i] == 0.0 && d->inertia[6 * i] == 0.0 && d->inertia[6 * i + 1] == 0.0 && d->inertia[6 * i + 2] == 0.0;
+        w.push_back(uint32_t(used ? (reg_child[i] >= 0 ? F_REGCHILD : 0) | (xslot[i] >= 0 ? F_XWRITE : 0) | (massless ? F_MASSLESS : 0) : 0));
         w.push_back(uint32_t(ne));
         for (int k = 0; k < 4; ++k) w.push_back(uint32_t(k < ne ? ext_list[es + k] : 0));
         w.push_back(uint32_t(es)); w.push_back(uint32_t(used && xslot[i] >= 0 ? xslot[i] : 0)); w.push_back(0u); w.push_back(0u);
@@ -581,34 +583,37 @@ __device__ __forceinline__ void p5_body(const Ctx &c, int e, const OctLane &o, c
     const Rec5c lc = load_rec5c(c, lr.q);
     const int k = o.kk, n1 = o.n1, n2 = o.n2, hO = 3 * o.half, hX = 3 - hO;
     // own link's data, component order (k, n1, n2) by lane-dependent addresses
-    const V3 Rk = ld3(me + O_RP + 3 * k), R1 = ld3(me + O_RP + 3 * n1), R2 = ld3(me + O_RP + 3 * n2);
-    const float pk = me[O_RP + 9 + k], p1 = me[O_RP + 9 + n1], p2 = me[O_RP + 9 + n2];
-    const float wk = me[O_V + k], w1 = me[O_V + n1], w2 = me[O_V + n2];
-    const float vk = me[O_V + 3 + k], v1 = me[O_V + 3 + n1], v2 = me[O_V + 3 + n2];
     const float sO[3] = {me[O_S + hO + k], me[O_S + hO + n1], me[O_S + hO + n2]};
     const float sX[3] = {me[O_S + hX + k], me[O_S + hX + n1], me[O_S + hX + n2]};
     const float cO[3] = {me[O_C + hO + k], me[O_C + hO + n1], me[O_C + hO + n2]};
     const float cX[3] = {me[O_C + hX + k], me[O_C + hX + n1], me[O_C + hX + n2]};
     const float pT = me[O_PT + o.row6];
     const float qdi = (c.env(e) + t.o_SQD)[lr.i];
-    // spatial inertia of the link about the world origin, row row6
-    const V3 com = {lc.com[0], lc.com[1], lc.com[2]};
-    const float m = lc.m;
-    const float ck = pk + dot(Rk, com), c1 = p1 + dot(R1, com), c2 = p2 + dot(R2, com);     // world COM, rotated order
-    const float hk = m * ck, h1 = m * c1, h2 = m * c2;
-    const V3 tt = symmul(lc.I6, Rk);                       // I R_k^T  (I symmetric)
-    const float Ikk = dot(tt, Rk) + m * (c1 * c1 + c2 * c2);
-    const float Ik1 = dot(tt, R1) - hk * c1, Ik2 = dot(tt, R2) - hk * c2;
-    float rO[3], rX[3];
-    // angular row k: [ Ibar row | [h]x row ] ;  linear row k: [ m e_k | -[h]x row ] ;  [h]x row k = (0, -h2, h1) in rotated order
-    rO[0] = o.half ? m : Ikk; rO[1] = o.half ? 0.0f : Ik1; rO[2] = o.half ? 0.0f : Ik2;
-    rX[0] = 0.0f; rX[1] = o.half ? h2 : -h2; rX[2] = o.half ? -h1 : h1;
-    // I v:  angular (Ibar w + h x vO)[k],  linear (m vO - h x w)[k]
-    const float X = o.half ? (m * vk - (h1 * w2 - h2 * w1)) : (Ikk * wk + Ik1 * w1 + Ik2 * w2 + (h1 * v2 - h2 * v1));
-    const float X1 = rot1(X), X2 = rot2(X);
-    const float Y = swap_half(X), Y1 = rot1(Y), Y2 = rot2(Y);
-    // bias force v x* (I v):  angular (w x Iv_a + vO x Iv_l)[k],  linear (w x Iv_l)[k];  plus the tendon wrenches
-    float pa = (w1 * X2 - w2 * X1) + (o.half ? 0.0f : (v1 * Y2 - v2 * Y1)) + pT;
+    float rO[3] = {0.0f, 0.0f, 0.0f}, rX[3] = {0.0f, 0.0f, 0.0f};
+    float pa = pT;                                         // the tendon wrenches on the link
+    if (!(lr.flags & F_MASSLESS)) {                        // (whole levels of massless links take this uniformly)
+        const V3 Rk = ld3(me + O_RP + 3 * k), R1 = ld3(me + O_RP + 3 * n1), R2 = ld3(me + O_RP + 3 * n2);
+        const float pk = me[O_RP + 9 + k], p1 = me[O_RP + 9 + n1], p2 = me[O_RP + 9 + n2];
+        const float wk = me[O_V + k], w1 = me[O_V + n1], w2 = me[O_V + n2];
+        const float vk = me[O_V + 3 + k], v1 = me[O_V + 3 + n1], v2 = me[O_V + 3 + n2];
+        // spatial inertia of the link about the world origin, row row6
+        const V3 com = {lc.com[0], lc.com[1], lc.com[2]};
+        const float m = lc.m;
+        const float ck = pk + dot(Rk, com), c1 = p1 + dot(R1, com), c2 = p2 + dot(R2, com);     // world COM, rotated order
+        const float hk = m * ck, h1 = m * c1, h2 = m * c2;
+        const V3 tt = symmul(lc.I6, Rk);                   // I R_k^T  (I symmetric)
+        const float Ikk = dot(tt, Rk) + m * (c1 * c1 + c2 * c2);
+        const float Ik1 = dot(tt, R1) - hk * c1, Ik2 = dot(tt, R2) - hk * c2;
+        // angular row k: [ Ibar row | [h]x row ] ;  linear row k: [ m e_k | -[h]x row ] ;  [h]x row k = (0, -h2, h1) in rotated order
+        rO[0] = o.half ? m : Ikk; rO[1] = o.half ? 0.0f : Ik1; rO[2] = o.half ? 0.0f : Ik2;
+        rX[1] = o.half ? h2 : -h2; rX[2] = o.half ? -h1 : h1;
+        // I v:  angular (Ibar w + h x vO)[k],  linear (m vO - h x w)[k]
+        const float X = o.half ? (m * vk - (h1 * w2 - h2 * w1)) : (Ikk * wk + Ik1 * w1 + Ik2 * w2 + (h1 * v2 - h2 * v1));
+        const float X1 = rot1(X), X2 = rot2(X);
+        const float Y = swap_half(X), Y1 = rot1(Y), Y2 = rot2(Y);
+        // bias force v x* (I v):  angular (w x Iv_a + vO x Iv_l)[k],  linear (w x Iv_l)[k]
+        pa += (w1 * X2 - w2 * X1) + (o.half ? 0.0f : (v1 * Y2 - v2 * Y1));
+    }
     // children: the one below in the same octet (registers), the others through their exchange slots
     if (lr.flags & F_REGCHILD) {
 #pragma unroll
