@@ -586,25 +586,26 @@ __device__ __forceinline__ void tree_integrate(const Ctx &c, float *qj, float *v
 #pragma unroll
             for (int p = 0; p < NP; ++p) { vj[p] = sat(vj[p] + h * a[p], p); qj[p] = qj[p] + h * vj[p]; }
         } else {
-            const float hh = 0.5f * h, h6 = h * (1.0f / 6.0f);
-            float k1q[NP], k1v[NP], k2q[NP], k2v[NP], k3q[NP], k3v[NP], k4q[NP], k4v[NP], qs[NP];
+            // RK4 with every stage velocity saturated, as a loop over the four stages (one copy of the
+            // acceleration code instead of four: a quarter of the instructions to fetch and far fewer
+            // registers live across it); the weighted sums accumulate in the order k1 + 2 k2 + 2 k3 + k4
+            const float h6 = h * (1.0f / 6.0f);
+            float kq[NP], kv[NP], qs[NP], qa[NP], va[NP];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) k1q[p] = sat(vj[p], p);
-            tree_accel<E, SP>(c, qj, k1q, k1v);
+            for (int p = 0; p < NP; ++p) { kq[p] = sat(vj[p], p); qs[p] = qj[p]; qa[p] = 0.0f; va[p] = 0.0f; }
+#pragma unroll 1
+            for (int st = 0; st < 4; ++st) {
+                tree_accel<E, SP>(c, qs, kq, kv);
+                const float wgt = (st == 0 || st == 3) ? 1.0f : 2.0f, cst = st == 2 ? h : 0.5f * h;
 #pragma unroll
-            for (int p = 0; p < NP; ++p) { k2q[p] = sat(vj[p] + hh * k1v[p], p); qs[p] = qj[p] + hh * k1q[p]; }
-            tree_accel<E, SP>(c, qs, k2q, k2v);
-#pragma unroll
-            for (int p = 0; p < NP; ++p) { k3q[p] = sat(vj[p] + hh * k2v[p], p); qs[p] = qj[p] + hh * k2q[p]; }
-            tree_accel<E, SP>(c, qs, k3q, k3v);
-#pragma unroll
-            for (int p = 0; p < NP; ++p) { k4q[p] = sat(vj[p] + h * k3v[p], p); qs[p] = qj[p] + h * k3q[p]; }
-            tree_accel<E, SP>(c, qs, k4q, k4v);
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                qj[p] = qj[p] + h6 * (k1q[p] + 2.0f * k2q[p] + 2.0f * k3q[p] + k4q[p]);
-                vj[p] = vj[p] + h6 * (k1v[p] + 2.0f * k2v[p] + 2.0f * k3v[p] + k4v[p]);
+                for (int p = 0; p < NP; ++p) {
+                    qa[p] += wgt * kq[p]; va[p] += wgt * kv[p];
+                    qs[p] = qj[p] + cst * kq[p];             // state of the next stage ...
+                    kq[p] = sat(vj[p] + cst * kv[p], p);     // ... and its (saturated) velocity
+                }
             }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { qj[p] = qj[p] + h6 * qa[p]; vj[p] = vj[p] + h6 * va[p]; }
         }
         // velocity saturation + joint limits
 #pragma unroll
