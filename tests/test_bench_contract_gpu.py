@@ -96,3 +96,24 @@ def test_bench_collective_with_full_chunks():
     c = d["collective"]
     assert c["ok"] and c["allreduce_calls"] == 3 * 4 and c["every_steps"] == 100     # --repeats given: no sizing region
     assert c["expected"] == 4096.0 * (16 + 10 + 250 * 4)
+
+
+def test_bench_two_ranks_share_the_gpu_over_gloo():
+    """The N > 1 launch shape of the driver (torch.distributed.run, one rank per process) rehearsed with two ranks
+    on the one GPU of the box and the tiny collectives over gloo: both ranks run the headline shard, rank 0 prints
+    the one line, the all-reduced env-step count covers both ranks.  Throughput means nothing here (the ranks share a GPU)."""
+    env = dict(os.environ, ROBOY_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29671", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "20", "--warmup", "5", "--repeats", "3"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 2 * 262144 and d["scaling"] == "weak"
+    c = d["collective"]
+    assert c["ok"] and c["world_size"] == 2 and c["backend"] == "gloo"
+    assert c["allreduce_calls"] == 3 + 1                      # three timed regions + the rehearsal (--repeats given: no sizing region)
+    assert c["n_env_steps_allreduced"] == 2 * 262144.0 * (16 + 5 + 20 * 4)
+    assert d["cpu_baseline"] is None and d["also"] == []
