@@ -1,10 +1,7 @@
 // env_common.hpp - definitions shared by the fused env-layer kernels of both
 // robot classes (roboy_sim.hip: ball-joint robots; tree_kernels.hpp: joint trees).
 #pragma once
-#include <hip/hip_runtime.h>
-
-#include <cstdint>
-
+#include "rtc_compat.hpp"
 #include "philox.hpp"
 
 namespace rbe {

@@ -1,0 +1,158 @@
+// msj_jit.hpp - run-time specialisation of the env-per-lane kernels (msj_kernels.hpp) to ONE robot: the robot's
+// closed-form constants are written into the source as hex-float literals and the kernels compiled with hiprtc,
+// exactly what msj_baked.hpp does ahead of time for MsjRobot (+6 % on the RK4 step: no scalar loads in the tendon
+// loop, sub-expressions shared between tendons, literal addends).  Host code.
+//
+// hiprtc is loaded with dlopen, so the library has no link-time dependency on it; if it is missing, or the
+// compilation fails, the handle keeps running the kernarg instances (an optimisation, not a fallback of the
+// physics: both are the same source).  ROBOY_SIM_JIT=0 switches it off.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "msj_math.hpp"
+
+namespace rbj {
+
+struct Module {
+    hipModule_t mod = nullptr;
+    hipFunction_t step[2] = {nullptr, nullptr};   // msj_step_env_per_lane<INTEG, 256, 4, true>
+    hipFunction_t env[2] = {nullptr, nullptr};    // msj_env_step_kernel<INTEG, 256, 4, Const8, true>
+    hipFunction_t rollout[2] = {nullptr, nullptr};   // msj_rollout_fused<INTEG, 256, 4, true>
+};
+
+struct Rtc {
+    decltype(&hiprtcCreateProgram) create = nullptr;
+    decltype(&hiprtcAddNameExpression) add_name = nullptr;
+    decltype(&hiprtcCompileProgram) compile = nullptr;
+    decltype(&hiprtcGetProgramLogSize) log_size = nullptr;
+    decltype(&hiprtcGetProgramLog) log = nullptr;
+    decltype(&hiprtcGetLoweredName) lowered = nullptr;
+    decltype(&hiprtcGetCodeSize) code_size = nullptr;
+    decltype(&hiprtcGetCode) code = nullptr;
+    decltype(&hiprtcDestroyProgram) destroy = nullptr;
+    bool ok = false;
+};
+
+inline const Rtc &rtc() {
+    static Rtc r = [] {
+        Rtc x;
+        void *h = dlopen("libhiprtc.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/libhiprtc.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return x;
+#define RBJ_SYM(field, name) x.field = reinterpret_cast<decltype(x.field)>(dlsym(h, name))
+        RBJ_SYM(create, "hiprtcCreateProgram"); RBJ_SYM(add_name, "hiprtcAddNameExpression");
+        RBJ_SYM(compile, "hiprtcCompileProgram"); RBJ_SYM(log_size, "hiprtcGetProgramLogSize");
+        RBJ_SYM(log, "hiprtcGetProgramLog"); RBJ_SYM(lowered, "hiprtcGetLoweredName");
+        RBJ_SYM(code_size, "hiprtcGetCodeSize"); RBJ_SYM(code, "hiprtcGetCode"); RBJ_SYM(destroy, "hiprtcDestroyProgram");
+#undef RBJ_SYM
+        x.ok = x.create && x.add_name && x.compile && x.log_size && x.log && x.lowered && x.code_size && x.code && x.destroy;
+        return x;
+    }();
+    return r;
+}
+
+// the aggregate initialiser of an MsjConst<float, 8>, every float as an exact hex literal
+inline std::string table_text(const rb::MsjConst<float, 8> &c) {
+    std::string s = "{{";
+    char buf[64];
+    auto f = [&](float v) { std::snprintf(buf, sizeof buf, "%af,", double(v)); s += buf; };
+    for (int k = 0; k < 8; ++k) {
+        const auto &t = c.ten[k];
+        s += "{{"; f(t.A[0]); f(t.A[1]); f(t.A[2]); s += "},{"; f(t.B[0]); f(t.B[1]); f(t.B[2]); s += "},{";
+        f(t.B2[0]); f(t.B2[1]); f(t.B2[2]); s += "},";
+        f(t.ab2); f(t.il0s); f(t.elcs); f(t.ksg); f(t.fmax); f(t.inv_vl0); f(t.pad); s += "},";
+    }
+    s += "},{"; for (int a = 0; a < 6; ++a) f(c.IO[a]);
+    s += "},{"; for (int a = 0; a < 3; ++a) f(c.mc[a]);
+    s += "},{"; for (int a = 0; a < 3; ++a) f(c.g[a]);
+    s += "},{"; for (int a = 0; a < 3; ++a) f(c.arm[a]);
+    s += "},{"; for (int a = 0; a < 3; ++a) f(c.damp[a]);
+    s += "},{"; for (int a = 0; a < 3; ++a) f(c.qlo[a]);
+    s += "},{"; for (int a = 0; a < 3; ++a) f(c.qhi[a]);
+    s += "},{"; for (int a = 0; a < 3; ++a) f(c.qdmax[a]);
+    s += "},"; f(c.kps); f(c.pe_k2s); f(c.inv_pe_den); f(c.fv_c1l); f(c.fv_c2l); f(c.fv_c2s); f(c.fv_k); f(c.h);
+    s += std::to_string(c.nsub) + "," + std::to_string(c.simple) + "," + std::to_string(c.nt) + "}";
+    return s;
+}
+
+// directory of this shared library (the kernel headers travel next to it)
+inline std::string library_dir() {
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<const void *>(&library_dir), &info) || !info.dli_fname) return ".";
+    std::string p = info.dli_fname;
+    const size_t k = p.rfind('/');
+    return k == std::string::npos ? "." : p.substr(0, k);
+}
+
+inline bool enabled() {
+    const char *e = std::getenv("ROBOY_SIM_JIT");
+    return !(e && e[0] == '0');
+}
+
+// compile and load; false (with a message) if anything along the way is not available
+inline bool build(const rb::MsjConst<float, 8> &c, Module &out, std::string &why) {
+    const Rtc &r = rtc();
+    if (!r.ok) { why = "hiprtc is not available"; return false; }
+    const std::string src = "#define RB_JIT_TABLE " + table_text(c) + "\n#include \"msj_kernels.hpp\"\n";
+    hiprtcProgram prog = nullptr;
+    if (r.create(&prog, src.c_str(), "roboy_msj_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { why = "hiprtcCreateProgram failed"; return false; }
+    constexpr int NK = 6;
+    const char *names[NK] = {"rbk::msj_step_env_per_lane<0, 256, 4, true>", "rbk::msj_step_env_per_lane<1, 256, 4, true>",
+                             "rbk::msj_env_step_kernel<0, 256, 4, rbk::Const8, true>",
+                             "rbk::msj_env_step_kernel<1, 256, 4, rbk::Const8, true>",
+                             "rbk::msj_rollout_fused<0, 256, 4, true>", "rbk::msj_rollout_fused<1, 256, 4, true>"};
+    for (const char *n : names) r.add_name(prog, n);
+    const std::string inc = "-I" + library_dir();
+    int dev = 0;
+    hipDeviceProp_t prop;
+    std::string arch = "--offload-arch=gfx950";
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.gcnArchName[0]) {
+        std::string a = prop.gcnArchName;                 // "gfx950:sramecc+:xnack-"
+        arch = "--offload-arch=" + a.substr(0, a.find(':'));
+    }
+    const char *opts[] = {arch.c_str(), "-O3", "-std=c++17", "-fno-slp-vectorize", inc.c_str()};
+    const hiprtcResult rc = r.compile(prog, 5, opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        r.log_size(prog, &n);
+        std::string log(n, '\0');
+        if (n) r.log(prog, &log[0]);
+        why = "hiprtc compilation failed: " + log.substr(0, 600);
+        r.destroy(&prog);
+        return false;
+    }
+    size_t n = 0;
+    r.code_size(prog, &n);
+    std::string code(n, '\0');
+    r.code(prog, &code[0]);
+    std::string lowered[NK];
+    for (int k = 0; k < NK; ++k) {
+        const char *low = nullptr;
+        if (r.lowered(prog, names[k], &low) != HIPRTC_SUCCESS || !low) { why = "hiprtcGetLoweredName failed"; r.destroy(&prog); return false; }
+        lowered[k] = low;
+    }
+    r.destroy(&prog);
+    if (hipModuleLoadData(&out.mod, code.data()) != hipSuccess) { why = "hipModuleLoadData failed"; out.mod = nullptr; return false; }
+    hipFunction_t *slots[NK] = {&out.step[0], &out.step[1], &out.env[0], &out.env[1], &out.rollout[0], &out.rollout[1]};
+    for (int k = 0; k < NK; ++k)
+        if (hipModuleGetFunction(slots[k], out.mod, lowered[k].c_str()) != hipSuccess) {
+            why = "hipModuleGetFunction failed for " + lowered[k];
+            (void)hipModuleUnload(out.mod);
+            out = Module();
+            return false;
+        }
+    return true;
+}
+
+inline void unload(Module &m) {
+    if (m.mod) (void)hipModuleUnload(m.mod);
+    m = Module();
+}
+
+}  // namespace rbj

@@ -27,12 +27,9 @@
 // compiled by hipcc for the kernels and by g++ in tests/ (host double/float)
 // to check the derivation without a GPU.
 #pragma once
-#include <cmath>
-#include <cstdint>
-#include <type_traits>
+#include "rtc_compat.hpp"
 
 #if defined(__HIPCC__)
-#include <hip/hip_runtime.h>
 #define RB_HD __host__ __device__ __forceinline__
 #else
 #define RB_HD inline

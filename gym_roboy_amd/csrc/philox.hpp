@@ -10,10 +10,9 @@
 // and is checked bit-for-bit, including against the Random123 known-answer
 // vectors.
 #pragma once
-#include <cstdint>
+#include "rtc_compat.hpp"
 
 #if defined(__HIPCC__)
-#include <hip/hip_runtime.h>
 #define RB_PHILOX_HD __host__ __device__ __forceinline__
 #else
 #define RB_PHILOX_HD inline

@@ -63,6 +63,10 @@ class HipBatchSimulation:
         nat.check(self._lib.rb_info(self._h, ctypes.byref(info)))
         return {name: getattr(info, name) for name, _ in nat.SimInfo._fields_}
 
+    def specialization(self) -> str:
+        """'kernarg', 'table' (MsjRobot's ahead-of-time instances) or 'jit' (hiprtc instances on this robot's constants)."""
+        return {0: "kernarg", 1: "table", 2: "jit"}[self._lib.rb_specialization(self._h)]
+
     def select_kernel(self, kernel: int):
         nat.check(self._lib.rb_select_kernel(self._h, int(kernel)))
 

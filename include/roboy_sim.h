@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define RB_ABI_VERSION 2
+#define RB_ABI_VERSION 3
 
 enum rb_status {
     RB_OK = 0,
@@ -135,6 +135,14 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator,
 void rb_destroy(rb_sim *sim);
 int rb_info(const rb_sim *sim, rb_sim_info *info);
 int rb_select_kernel(rb_sim *sim, int kernel);
+/* How the env-per-lane kernels of this handle get the robot's constants: RB_SPEC_NONE = through the kernarg
+ * (scalar loads); RB_SPEC_TABLE = instances compiled ahead of time on the reference's MsjRobot (the handle's
+ * constants equal that table bit for bit); RB_SPEC_JIT = instances compiled with hiprtc on this robot's own
+ * constants (8-tendon ball-joint robots, batches above 65 536 envs; built by the first call that needs them, or
+ * by this one; ROBOY_SIM_JIT=0 disables it).  All three are the same source and pass the same parity tests;
+ * the specialised ones run ~6 % faster.  Returns -1 for a null handle; after RB_SPEC_NONE rb_last_error() says why. */
+enum { RB_SPEC_NONE = 0, RB_SPEC_TABLE = 1, RB_SPEC_JIT = 2 };
+int rb_specialization(rb_sim *sim);
 /* The stream every launch, copy and synchronisation of this handle uses.  NULL = the
  * handle's own (non-blocking) stream; RB_STREAM_DEVICE_DEFAULT = the device's default
  * (null) stream, which is what a framework's "current stream" is unless the caller made

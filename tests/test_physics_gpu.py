@@ -489,3 +489,78 @@ def test_long_rollout_with_extreme_actions_stays_finite_and_inside_the_boxes(msj
     assert np.all(np.abs(qd) <= np.float32(desc.qd_max) + 1e-7)
     assert q.std() > 0.01
     sim.close()
+
+
+@pytest.mark.parametrize("integrator", ["euler", "rk4"])
+def test_run_time_specialised_kernels_for_another_ball_joint_robot(msj_robot, integrator):
+    """An 8-tendon ball-joint robot that is not MsjRobot (random geometry, general inertia): above 65 536 envs its
+    env-per-lane kernels are compiled with hiprtc on the robot's own constants (rb_specialization = jit).  They must
+    match the oracle, and the kernarg instances of the same source (ROBOY_SIM_JIT = 0) to rounding; MsjRobot itself
+    reports the ahead-of-time table."""
+    import os
+    from oracle.c_oracle import COracle
+    robot = _ball_joint_robot(msj_robot, 8, 77)
+    desc = robot.get_description()
+    n = 70001
+    q, qd, sp = random_states(desc, n, 5)
+    idx = np.arange(0, n, 97)
+    qo, qdo, fo = COracle(desc, "f64").step(q[idx], qd[idx], sp[idx], integrator=0 if integrator == "euler" else 1)
+
+    def run():
+        sim = _sim(robot, n, integrator=integrator)
+        spec = sim.specialization()
+        sim.set_state(q, qd)
+        out = sim.forward_step_command(sp)
+        # the graph path must replay the module kernels as well
+        d = sim.malloc(4 * n * 8)
+        sim.fill_actions_dev(d, 0)
+        sim.rollout_dev(d, 1, 12, 0.3, use_graph=True)
+        sim.synchronize()
+        assert np.isfinite(sim.read_state()[0]).all()
+        sim.close()
+        return spec, out
+    spec, (q1, qd1, f1) = run()
+    assert spec == "jit", spec
+    assert np.abs(q1[idx] - qo).max() < 2e-5 and np.abs(qd1[idx] - qdo).max() < 2e-5
+    os.environ["ROBOY_SIM_JIT"] = "0"
+    try:
+        spec0, (q0, qd0, f0) = run()
+    finally:
+        del os.environ["ROBOY_SIM_JIT"]
+    assert spec0 == "kernarg"
+    assert np.abs(q1 - q0).max() < 2e-6 and np.abs(qd1 - qd0).max() < 2e-6 and np.mean(f1 == f0) > 0.9999
+    small = _sim(robot, 1000, integrator=integrator)
+    assert small.specialization() == "kernarg"            # small batches keep the latency-oriented kernarg form
+    small.close()
+    msj = _sim(msj_robot, 70001, integrator=integrator)
+    assert msj.specialization() == "table"
+    msj.close()
+
+
+def test_run_time_specialised_fused_env_kernel(msj_robot):
+    """RoboyVecEnv over a non-MsjRobot 8-tendon ball-joint robot at a large batch: the fused env kernel comes out of
+    the hiprtc module; same host replay as for MsjRobot (states / goals bit for bit against the plain step kernel,
+    which runs out of the same module)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from host_env_model import HipStepper, HostEnvModel
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    robot = _ball_joint_robot(msj_robot, 8, 78)
+    n, seed, max_len = 66001, 4, 7
+    vec = RoboyVecEnv(robot, n, seed=seed, max_episode_length=max_len, joint_vel_penalty=True)
+    host = HostEnvModel(robot, HipStepper(robot, n, seed), n, seed, max_len, True, True, True)
+    assert vec.sim.specialization() == "jit" and host.stepper.sim.specialization() == "jit"
+    obs0 = vec.reset()
+    host.goal = host.draw(np.ones(n, bool))
+    assert np.array_equal(obs0[:, 6:], host.goal)
+    rng = np.random.default_rng(9)
+    for t in range(10):
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        obs, rew, done, _ = vec.step(a)
+        h_obs, h_rew, h_done, margin = host.step(a)
+        same = done == h_done
+        assert same.all() or (margin[~same] < 1e-5).all()
+        assert np.array_equal(obs[same], h_obs[same].astype(np.float32))
+        np.testing.assert_allclose(rew[same], h_rew[same], rtol=2e-5, atol=2e-4)
+        assert same.all()
+    vec.close(); host.stepper.close()
