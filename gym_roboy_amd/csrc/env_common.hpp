@@ -1,5 +1,5 @@
 // env_common.hpp - definitions shared by the fused env-layer kernels of both
-// robot classes (roboy_sim.hip: ball-joint robots; tree_kernels.hpp: joint trees).
+// robot classes (msj_kernels.hpp: ball-joint robots; tree_aba.hpp: joint trees).
 #pragma once
 #include "rtc_compat.hpp"
 #include "philox.hpp"

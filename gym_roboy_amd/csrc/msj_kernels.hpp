@@ -30,20 +30,16 @@ constexpr int NTX = 16;
 using ConstX = rb::MsjConst<float, NTX>;
 
 
-// One env per lane.  Loads: q, qd planes (dword per lane, 256 B contiguous per
-// wave and plane) and the env's 32-byte action record (two dwordx4).  Stores:
-// q', qd' planes and the feasibility word.  84 algorithmic bytes per env step.
-// Set-points of one env staged as an LDS column: the rolled tendon loop reads
-// sp(k) with one ds_read_b32 instead of selecting among 8 registers with a
-// runtime index (7 v_cndmask + 14 SALU per trip before).  [NT8][BLOCK] floats,
-// lane-contiguous rows: conflict-free.
-// robot constants of a kernel instance: the kernarg copy, or (BK) MsjRobot's compile-time table, which the
-// compiler folds into the instruction stream
+// robot constants of a kernel instance: the kernarg copy, or (BK) the compile-time table (MsjRobot's, or the
+// handle's own when hiprtc compiles this header), which the compiler folds into the instruction stream
 template <bool BK, typename CONST>
 __device__ __forceinline__ const CONST &robot_consts(const CONST &kernarg) {
     if constexpr (BK) return rbk::BAKED; else return kernarg;
 }
 
+// Set-points of one env staged as an LDS column: the rolled tendon loop reads sp(k) with one ds_read_b32
+// instead of selecting among 8 registers with a runtime index (7 v_cndmask + 14 SALU per trip before).
+// [NT8][BLOCK] floats, lane-contiguous rows: conflict-free.
 struct SpLds {
     const float *col;   // &lds[0][threadIdx.x]
     int stride;         // BLOCK
@@ -54,6 +50,9 @@ struct SpLds {
 // (on the device the product of two kernarg scalars costs a v_mov and a v_mul per lane and tendon)
 struct Scale8 { float v[NT8]; };
 
+// One env per lane.  Loads: q, qd planes (dword per lane, 256 B contiguous per wave and plane) and the env's
+// 32-byte action record (two dwordx4).  Stores: q', qd' planes and the feasibility word.  84 algorithmic
+// bytes per env step.
 template <int INTEG, int BLOCK, int UNROLL, bool BK = false>
 __global__ void __launch_bounds__(BLOCK)
 msj_step_env_per_lane(const Const8 c_arg, float *__restrict__ q, float *__restrict__ qd,

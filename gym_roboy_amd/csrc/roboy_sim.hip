@@ -2,12 +2,14 @@
 //
 // Replaces the per-step ROS round-trip of the reference's RosSimulationClient
 // (gym_roboy/envs/simulations/ros_simulation_client.py:32-81) by kernels that
-// advance N independent environments in lock-step.  State is struct-of-arrays
-// in HBM, one env per lane (or one tendon per lane for small batches, or one env
-// per wave for generic joint trees, tree_aba.hpp), robot constants are
-// wave-uniform and arrive through the kernarg (scalar loads -> SGPRs); LDS holds
-// only what is indexed at run time (the set-points of the rolled tendon loop).
-// DESIGN.md §4-§5.
+// advance N independent environments in lock-step.  Ball-joint robots: state
+// struct-of-arrays in HBM, one env per lane (msj_kernels.hpp; one tendon per lane
+// for small batches, below), robot constants wave-uniform - through the kernarg
+// (scalar loads -> SGPRs), or folded into the code: MsjRobot's table ahead of time
+// (msj_baked.hpp), any other 8-tendon robot's by hiprtc at run time (msj_jit.hpp);
+// LDS holds only what is indexed at run time (the set-points of the rolled tendon
+// loop).  Generic joint trees: two envs per wave, eight lanes per link, working
+// set in LDS (tree_aba.hpp).  DESIGN.md §4-§5.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
