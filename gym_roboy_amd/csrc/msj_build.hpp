@@ -69,21 +69,21 @@ int msj_build(const rb_robot_desc *d, double step_size, int nsub, MsjConst<T, NT
         if (moving0 < 1e-6) { err = "degenerate tendon segment"; return RB_EINVAL; }
         const double l0 = lc + moving0;
         MsjTendon<T> &t = c.ten[k];
-        for (int a = 0; a < 3; ++a) { t.A[a] = T(d->vp_pos[3 * va + a]); t.B[a] = T(d->vp_pos[3 * vb + a]); }
+        const double vl0 = d->v_max * l0;
+        for (int a = 0; a < 3; ++a) { t.A[a] = T(d->vp_pos[3 * va + a]); t.Bv[a] = T(d->vp_pos[3 * vb + a] / vl0); }
         double ab2 = 0.0;
         for (int a = 0; a < 3; ++a) ab2 += d->vp_pos[3 * va + a] * d->vp_pos[3 * va + a] + d->vp_pos[3 * vb + a] * d->vp_pos[3 * vb + a];
         for (int a = 0; a < 3; ++a) t.B2[a] = T(-2.0 * d->vp_pos[3 * vb + a]);
         t.ab2 = T(ab2); t.il0s = T(sc / l0); t.elcs = T(sc * (lc / l0 - 1.0)); t.ksg = T(d->kp * d->setpoint_scale / l0);
-        t.fmax = T(d->f_max[k]);
-        t.inv_vl0 = T(1.0 / (d->v_max * l0));
-        t.pad = T(0);
+        t.fmaxv = T(d->f_max[k] * vl0);
+        t.pad[0] = t.pad[1] = T(0);
     }
     for (int k = d->n_t; k < NT; ++k) {       // unused records: a well-formed tendon that never pulls
         MsjTendon<T> &t = c.ten[k];
-        t.A[0] = T(1); t.A[1] = T(0); t.A[2] = T(0); t.B[0] = T(0); t.B[1] = T(0); t.B[2] = T(1);
+        t.A[0] = T(1); t.A[1] = T(0); t.A[2] = T(0); t.Bv[0] = T(0); t.Bv[1] = T(0); t.Bv[2] = T(1);
         t.B2[0] = T(0); t.B2[1] = T(0); t.B2[2] = T(-2);
-        t.ab2 = T(2); t.il0s = T(sc); t.elcs = T(-sc); t.ksg = T(0); t.fmax = T(0); t.inv_vl0 = T(1);
-        t.pad = T(0);
+        t.ab2 = T(2); t.il0s = T(sc); t.elcs = T(-sc); t.ksg = T(0); t.fmaxv = T(0);
+        t.pad[0] = t.pad[1] = T(0);
     }
     c.nt = d->n_t;
     const double m = d->mass[2];

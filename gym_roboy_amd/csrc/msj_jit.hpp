@@ -64,9 +64,9 @@ inline std::string table_text(const rb::MsjConst<float, 8> &c) {
     auto f = [&](float v) { std::snprintf(buf, sizeof buf, "%af,", double(v)); s += buf; };
     for (int k = 0; k < 8; ++k) {
         const auto &t = c.ten[k];
-        s += "{{"; f(t.A[0]); f(t.A[1]); f(t.A[2]); s += "},{"; f(t.B[0]); f(t.B[1]); f(t.B[2]); s += "},{";
+        s += "{{"; f(t.A[0]); f(t.A[1]); f(t.A[2]); s += "},{"; f(t.Bv[0]); f(t.Bv[1]); f(t.Bv[2]); s += "},{";
         f(t.B2[0]); f(t.B2[1]); f(t.B2[2]); s += "},";
-        f(t.ab2); f(t.il0s); f(t.elcs); f(t.ksg); f(t.fmax); f(t.inv_vl0); f(t.pad); s += "},";
+        f(t.ab2); f(t.il0s); f(t.elcs); f(t.ksg); f(t.fmaxv); s += "{0.0f,0.0f}},";
     }
     s += "},{"; for (int a = 0; a < 6; ++a) f(c.IO[a]);
     s += "},{"; for (int a = 0; a < 3; ++a) f(c.mc[a]);

@@ -115,15 +115,15 @@ template <typename T> RB_HD T tclamp(T x, T lo, T hi) {
 template <typename T>
 struct alignas(64) MsjTendon {
     T A[3];        // last base via-point, world = base frame
-    T B[3];        // first body via-point, body frame
+    T Bv[3];       // first body via-point B (body frame) / (v_max * rest length): a x Bv is the torque arm
+                   // times |d| in units that make (w . (a x Bv)) / |d| the normalised lengthening rate v
     T B2[3];       // -2 B  (|B - a|^2 = ab2 + a . B2)
     T ab2;         // |A|^2 + |B|^2
     T il0s;        // s / rest length
     T elcs;        // s (lc / l0 - 1)  (lc = summed length of the segments that do not move)
     T ksg;         // kp * setpoint_scale / rest length: set-point -> activation offset u = ksg * setpoint
-    T fmax;        // maximum isometric force
-    T inv_vl0;     // 1 / (v_max * rest length)
-    T pad;
+    T fmaxv;       // maximum isometric force * (v_max * rest length)  (undoes the scale of Bv in the torque)
+    T pad[2];
 };
 
 template <typename T, int NT>
@@ -190,12 +190,19 @@ struct MsjModel {
         const T ay = f.r01 * t.A[0] + f.r11 * t.A[1] + f.r21 * t.A[2];
         const T az = f.r02 * t.A[0] + f.r12 * t.A[1] + f.r22 * t.A[2];
         const T d2 = ax * t.B2[0] + (ay * t.B2[1] + (az * t.B2[2] + t.ab2));
+        // m = (a x B)/(v_max l0); the torque arm is m/|d| up to that scale, which fmaxv undoes
+        const T mx = ay * t.Bv[2] - az * t.Bv[1];
+        const T my = az * t.Bv[0] - ax * t.Bv[2];
+        const T mz = ax * t.Bv[1] - ay * t.Bv[0];
+        tendon_force(c, f, t, u, d2, mx, my, mz, tx, ty, tz);
+    }
+
+    // the tendon behind its routing: from d2 = |B - a|^2 and m = (a x B)/(v_max l0) to the Hill-type force and
+    // the torque about the joint centre
+    static RB_HD void tendon_force(const C &c, const Frame &f, const MsjTendon<T> &t, T u, T d2, T mx, T my, T mz,
+                                   T &tx, T &ty, T &tz) {
         const T inv = Fast<T>::rsqrt(d2);
-        // cr = a x B;  w = cr * inv
-        const T mx = ay * t.B[2] - az * t.B[1];
-        const T my = az * t.B[0] - ax * t.B[2];
-        const T mz = ax * t.B[1] - ay * t.B[0];
-        const T ldot = (f.wx * mx + f.wy * my + f.wz * mz) * inv;
+        const T v = (f.wx * mx + f.wy * my + f.wz * mz) * inv;      // (dl/dt) / (v_max l0)
         // Hill-type muscle on the scaled strain es = s (l/l0 - 1) = s |d|/l0 + s (lc/l0 - 1):
         // activation = clamp(kp (e - (sigma/l0) setpoint), 0, 1) = clamp((kp/s) es - u, 0, 1)
         const T es = (d2 * inv) * t.il0s + t.elcs;
@@ -203,13 +210,12 @@ struct MsjModel {
         const T fl = Fast<T>::exp2(-(es * es));
         // f_V = (1 + c1 v)/(1 + c2 v) per branch, written branch-free with v+ = max(v,0) and
         // p = 1 + clamp(v,-1,0) = clamp(1 + v, 0, 1)  (v+ = 0 or p = 1)
-        const T v = ldot * t.inv_vl0;
         const T vp = tmax(v, T(0)), p = tclamp(v + T(1), T(0), T(1));
         const T num = c.fv_c1l * vp + p;
         const T den = c.fv_c2l * vp + (c.fv_c2s * p + c.fv_k);
         const T rden = Fast<T>::rcp(den);              // den >= 1
         const T fpe = tmax(Fast<T>::exp2(c.pe_k2s * es) * c.inv_pe_den - c.inv_pe_den, T(0));
-        const T Fs = (t.fmax * inv) * ((act * fl) * num * rden + fpe);     // tension / |d|
+        const T Fs = (t.fmaxv * inv) * ((act * fl) * num * rden + fpe);     // tension (v_max l0) / |d|
         tx -= Fs * mx; ty -= Fs * my; tz -= Fs * mz;
     }
 
