@@ -621,6 +621,38 @@ int rb_info(const rb_sim *s, rb_sim_info *info) {
     return RB_OK;
 }
 
+#ifdef RB_TREE_DEBUG
+// debug builds only: arm a dump of the LDS working set of the wave that owns `env` (joint-tree robots; filled by
+// the next rb_step*), then fetch it.  Layout: TREE_E blocks of dev.ES floats (tree_build.hpp); *dev_out gets the
+// table offsets.
+int rb_debug_tree_arm(rb_sim *s, long env) {
+    if (!s || !s->tree) return fail(RB_EINVAL, "not a joint-tree handle");
+    RB_HIP(hipSetDevice(s->device));
+    float *buf = nullptr;
+    const size_t nf = size_t(rbt::TREE_E) * s->tree_host.dev.ES;
+    RB_HIP(hipMalloc(&buf, nf * sizeof(float)));
+    RB_HIP(hipMemset(buf, 0, nf * sizeof(float)));
+    RB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rbt::rb_tree_dbg_out), &buf, sizeof(buf)));
+    RB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rbt::rb_tree_dbg_env), &env, sizeof(env)));
+    return RB_OK;
+}
+int rb_debug_tree_fetch(rb_sim *s, float *out, int n_floats, rbt::TreeDev *dev_out) {
+    if (!s || !s->tree) return fail(RB_EINVAL, "not a joint-tree handle");
+    RB_HIP(hipSetDevice(s->device));
+    RB_HIP(hipStreamSynchronize(s->stream));
+    float *buf = nullptr;
+    RB_HIP(hipMemcpyFromSymbol(&buf, HIP_SYMBOL(rbt::rb_tree_dbg_out), sizeof(buf)));
+    if (!buf) return fail(RB_EINVAL, "not armed");
+    const int nf = rbt::TREE_E * s->tree_host.dev.ES;
+    RB_HIP(hipMemcpy(out, buf, sizeof(float) * size_t(n_floats < nf ? n_floats : nf), hipMemcpyDeviceToHost));
+    if (dev_out) *dev_out = s->tree_host.dev;
+    float *none = nullptr;
+    RB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rbt::rb_tree_dbg_out), &none, sizeof(none)));
+    (void)hipFree(buf);
+    return RB_OK;
+}
+#endif
+
 int rb_specialization(rb_sim *s) {
     if (check(s)) return -1;
     if (s->baked) return RB_SPEC_TABLE;

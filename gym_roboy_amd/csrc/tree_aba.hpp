@@ -99,9 +99,12 @@ template <int CTRL>
 __device__ __forceinline__ float dpp(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
-// lanes 0,1,2 of a quad hold components 0,1,2 of a vector: component (r+1)%3 and (r+2)%3 of the own lane r
-__device__ __forceinline__ float rot1(float v) { return dpp<0xC9>(v); }   // quad_perm [1,2,0,3]
-__device__ __forceinline__ float rot2(float v) { return dpp<0xD2>(v); }   // quad_perm [2,0,1,3]
+// lanes 0,1,2 of a quad hold components 0,1,2 of a vector: component (r+1)%3 and (r+2)%3 of the own lane r.
+// Lane 3 (idle, shadows component 2) reads what lane 2 reads, so that it stays an exact copy of lane 2 through
+// every level: left to rotate onto itself its rows drift, grow from level to level of a long chain and reach
+// inf after ~15 levels - and 0 * inf in an octet sum poisons the env (found by tests/test_random_robots_gpu.py).
+__device__ __forceinline__ float rot1(float v) { return dpp<0x09>(v); }   // quad_perm [1,2,0,0]
+__device__ __forceinline__ float rot2(float v) { return dpp<0x52>(v); }   // quad_perm [2,0,1,1]
 // sum over the 8 lanes of an octet, result in every lane: quad_perm(1,0,3,2), quad_perm(2,3,0,1), row_half_mirror
 __device__ __forceinline__ float sum8(float v) {
     v += dpp<0xB1>(v);
@@ -354,9 +357,9 @@ __device__ __forceinline__ void p5_body(const Ctx &c, int e, const OctLane &o, c
     if (lr.n_ext > 3) add_ext(lr.ext[3]);
     for (int q = 4; q < lr.n_ext; ++q) add_ext(c.ti(t.o_ext_list + lr.es + q));
     const float U = rO[0] * sO[0] + rO[1] * sO[1] + rO[2] * sO[2] + rX[0] * sX[0] + rX[1] * sX[1] + rX[2] * sX[2];
-    const float sr = o.act ? sO[0] : 0.0f;                 // s_row6 (idle lanes add nothing to the sums)
-    const float D = sum8(sr * U) + lc.arm;
-    const float T = sum8(sr * pa);
+    // s_row6 U_row6 and s_row6 p^a_row6; idle lanes add exact zeros to the sums (a select, not a product with 0)
+    const float D = sum8(o.act ? sO[0] * U : 0.0f) + lc.arm;
+    const float T = sum8(o.act ? sO[0] * pa : 0.0f);
     const float invD = __builtin_amdgcn_rcpf(D);
     const float u = -lc.damp * qdi - T;
     // U of the whole octet, in this lane's column order
@@ -390,7 +393,7 @@ struct Data6 { float cr, sr, U, invD, u; };
 __device__ __forceinline__ Data6 load_data6(const Ctx &c, int e, const OctLane &o, int i) {
     const float *me = c.link(e, i);
     Data6 d;
-    d.cr = me[O_C + o.row6]; d.sr = me[O_S + o.row6]; d.U = o.act ? me[O_U + o.row6] : 0.0f; d.invD = me[O_D]; d.u = me[O_D + 1];
+    d.cr = me[O_C + o.row6]; d.sr = me[O_S + o.row6]; d.U = me[O_U + o.row6]; d.invD = me[O_D]; d.u = me[O_D + 1];
     return d;
 }
 __device__ __forceinline__ void p6_body(const Ctx &c, int e, const OctLane &o, const Rec1 &lr, const Data6 &d, float a0, float &a) {
@@ -398,7 +401,7 @@ __device__ __forceinline__ void p6_body(const Ctx &c, int e, const OctLane &o, c
     float ap = a;
     if (!(lr.flags & F_INH)) ap = lr.par >= 0 ? c.link(e, lr.par)[O_A + o.row6] : a0;
     ap += d.cr;
-    const float qdd = (d.u - sum8(d.U * ap)) * d.invD;
+    const float qdd = (d.u - sum8(o.act ? d.U * ap : 0.0f)) * d.invD;     // idle lanes add exact zeros
     a = ap + d.sr * qdd;
     if ((lr.flags & F_ASTORE) && o.act) me[O_A + o.row6] = a;
     if (o.act && o.row6 == 0) me[O_D + 2] = qdd;
@@ -641,6 +644,14 @@ __device__ __forceinline__ bool env_all_ok(const Ctx &c, const bool *ok, int e_q
     return all;
 }
 
+#ifdef RB_TREE_DEBUG
+// debug builds only (make ... FLAGS+=-DRB_TREE_DEBUG; rb_debug_tree_arm / rb_debug_tree_fetch in roboy_sim.hip):
+// the wave that owns env rb_tree_dbg_env copies its LDS working set (E blocks of ES floats, as the last
+// acceleration evaluation left them) to rb_tree_dbg_out
+__device__ float *rb_tree_dbg_out = nullptr;
+__device__ long rb_tree_dbg_env = -1;
+#endif
+
 template <int INTEG, int E, bool SP>
 __global__ void __launch_bounds__(512, RB_TREE_MIN_WAVES)
 tree_step_aba(const TreeDev tg, float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
@@ -672,6 +683,10 @@ tree_step_aba(const TreeDev tg, float *__restrict__ q, float *__restrict__ qd, u
         (c.env(e) + tg.o_SPU)[k] = act[env * tg.n_t + k] * (act_scale * c.tf(tg.o_tendon + k * TENDON_REC + 2));
     }
     tree_integrate<INTEG, E, SP>(c, qj, vj, ok);
+#ifdef RB_TREE_DEBUG
+    if (rb_tree_dbg_out && rb_tree_dbg_env >= env0 && rb_tree_dbg_env < env0 + E)
+        for (int k = lane; k < E * tg.ES; k += 64) rb_tree_dbg_out[k] = c.ws[k];
+#endif
     const bool all_ok = env_all_ok<E>(c, ok, lane < E ? lane : -1);
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
