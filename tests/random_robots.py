@@ -60,12 +60,54 @@ def random_tree_spec(seed, n_q=None, n_t=None, shape=None, p_massless=0.25):
                        "fv_a": 0.25, "fv_n": 1.5}}
 
 
-def random_tree_robot(seed, **kw):
-    """(robot object, description) of random_tree_spec(seed)."""
+def random_ball_joint_spec(seed, n_t=8):
+    """One rigid body on an x-y-z ball joint at the base origin (the class msj_math.hpp closes in closed form) with
+    everything else random: tendon routing (1-3 base via-points, 1-2 body via-points), inertia with products,
+    centre of mass off the axis, tilted gravity, asymmetric limits, muscle parameters."""
+    from gym_roboy_amd.envs.robots.description import FORMAT_TAG
+    rng = np.random.default_rng(5000 + seed)
+
+    def joint(name, parent, axis, **kw):
+        lim = float(rng.uniform(0.3, 0.6))
+        j = {"name": name, "parent": parent, "axis": axis, "origin": [0.0, 0.0, 0.0], "mass": 0.0, "com": [0.0, 0.0, 0.0],
+             "inertia": [0.0] * 6, "armature": float(rng.uniform(0.1, 0.3)), "damping": float(rng.uniform(0.3, 1.0)),
+             "limit": [-lim * float(rng.uniform(0.6, 1.0)), lim], "max_velocity": float(rng.uniform(math.pi / 8, math.pi / 4))}
+        j.update(kw)
+        return j
+    simple = seed % 3 == 0                                  # every third robot takes the principal-axis fast path
+    mass = float(rng.uniform(0.1, 0.5))
+    a = rng.normal(size=(3, 3)) * 0.02
+    m = a @ a.T * mass + np.eye(3) * 3e-4
+    inertia = [m[0, 0], m[1, 1], m[2, 2], 0.0, 0.0, 0.0] if simple else [m[0, 0], m[1, 1], m[2, 2], m[0, 1], m[0, 2], m[1, 2]]
+    com = [0.0, 0.0, float(rng.uniform(0.03, 0.08))] if simple else [float(x) for x in rng.uniform(-0.03, 0.06, 3)]
+    gravity = [0.0, 0.0, -9.81] if simple else [float(x) for x in rng.normal(size=3) * 3.0 + np.array([0.0, 0.0, -9.0])]
+    tendons = []
+    for k in range(n_t):
+        ang = rng.uniform(0, 2 * math.pi)
+        pts = []
+        for v in range(int(rng.integers(1, 4))):            # base side, from the motor towards the joint
+            r, z = 0.13 - 0.02 * v + rng.uniform(-0.01, 0.01), -0.10 + 0.04 * v + rng.uniform(-0.01, 0.01)
+            pts.append({"link": -1, "pos": [float(r * math.cos(ang)), float(r * math.sin(ang)), float(z)]})
+        ang2 = ang + rng.uniform(-0.6, 0.6)
+        for v in range(int(rng.integers(1, 3))):            # body side
+            r, z = 0.07 - 0.02 * v + rng.uniform(-0.01, 0.01), 0.08 + 0.03 * v + rng.uniform(-0.01, 0.01)
+            pts.append({"link": 2, "pos": [float(r * math.cos(ang2)), float(r * math.sin(ang2)), float(z)]})
+        tendons.append({"name": "t%d" % k, "f_max": float(rng.uniform(4.0, 30.0)), "via_points": pts})
+    return {"format": FORMAT_TAG, "name": "ball%d" % seed, "gravity": gravity,
+            "joints": [joint("x", -1, [1.0, 0.0, 0.0]), joint("y", 0, [0.0, 1.0, 0.0]),
+                       joint("z", 1, [0.0, 0.0, 1.0], mass=mass, com=com, inertia=[float(x) for x in inertia])],
+            "tendons": tendons,
+            "muscle": {"kp": float(rng.uniform(5.0, 15.0)), "setpoint_scale": float(rng.uniform(0.05, 0.15)),
+                       "v_max": float(rng.uniform(4.0, 10.0)), "fl_width": float(rng.uniform(0.3, 0.6)),
+                       "kpe": float(rng.uniform(3.0, 5.0)), "e0": float(rng.uniform(0.4, 0.8)),
+                       "fv_a": float(rng.uniform(0.2, 0.35)), "fv_n": float(rng.uniform(1.3, 1.8))}}
+
+
+def _robot_of(spec):
     from gym_roboy_amd._gymcompat import spaces
     from gym_roboy_amd.envs.robots import RobotDescription
     from gym_roboy_amd.envs.robots.roboy_robot import RoboyRobot
-    desc = RobotDescription(random_tree_spec(seed, **kw))
+    desc = RobotDescription(spec)
 
     class Random(RoboyRobot):
         _DIM_JOINT_ANGLE, _DIM_ACTION = desc.n_q, desc.n_t
@@ -77,3 +119,13 @@ def random_tree_robot(seed, **kw):
         def get_description(cls):
             return desc
     return Random(), desc
+
+
+def random_ball_joint_robot(seed, n_t=8):
+    """(robot object, description) of random_ball_joint_spec(seed, n_t)."""
+    return _robot_of(random_ball_joint_spec(seed, n_t))
+
+
+def random_tree_robot(seed, **kw):
+    """(robot object, description) of random_tree_spec(seed)."""
+    return _robot_of(random_tree_spec(seed, **kw))

@@ -76,3 +76,62 @@ def test_random_robot_fused_env_layer_runs_and_matches_plain_step():
     assert np.abs(obs[:, :desc.n_q] - q1).max() < 1e-6 and np.abs(obs[:, desc.n_q:2 * desc.n_q] - qd1).max() < 1e-6
     assert np.all(np.isfinite(np.asarray(rew.cpu() if hasattr(rew, "cpu") else rew)))
     sim.close()
+
+
+# ---- the ball-joint class (closed form, msj_math.hpp) on random robots of that class, through every kernel form ----
+def _ball_check(robot, desc, n, integrator, nsub, seed, kernel=0, sample=1):
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    from oracle.c_oracle import COracle
+    q, qd, sp = random_states(desc, n, seed)
+    sim = HipBatchSimulation(robot, n, integrator=integrator, n_substeps=nsub)
+    if kernel:
+        sim.select_kernel(kernel)
+    assert sim.info()["kernel"] in (1, 2)                      # never the joint-tree kernel
+    sim.set_state(q, qd)
+    q1, qd1, f1 = sim.forward_step_command(sp)
+    idx = np.arange(0, n, sample)
+    qo, qdo, fo = COracle(desc, "f64").step(q[idx], qd[idx], sp[idx], integrator=0 if integrator == "euler" else 1, n_substeps=nsub)
+    assert np.abs(q1[idx] - qo).max() < TOL, np.abs(q1[idx] - qo).max()
+    assert np.abs(qd1[idx] - qdo).max() < TOL, np.abs(qd1[idx] - qdo).max()
+    near = np.minimum(np.abs(qo - desc.q_lo), np.abs(qo - desc.q_hi)).min(axis=1) < 1e-5
+    assert not np.any((f1[idx] != fo) & ~near)
+    spec = sim.specialization()
+    sim.close()
+    return spec
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_ball_joint_robot_small_batches(seed):
+    """8 tendons: tendon-per-lane (AUTO below 8 192 envs) and env-per-lane forms; both integrators; 1-3 substeps."""
+    from random_robots import random_ball_joint_robot
+    robot, desc = random_ball_joint_robot(seed, 8)
+    integrator = "rk4" if seed % 2 else "euler"
+    nsub = 1 + seed % 3
+    _ball_check(robot, desc, 257, integrator, nsub, seed)                 # AUTO: tendon per lane
+    _ball_check(robot, desc, 257, integrator, nsub, seed, kernel=1)       # env per lane, one wave per workgroup
+    _ball_check(robot, desc, 9000, integrator, nsub, seed, sample=7)
+
+
+@pytest.mark.parametrize("n_t", [1, 2, 5, 7, 9, 13, 16])
+def test_random_ball_joint_robot_other_tendon_counts(n_t):
+    """Run-time tendon count (the NTX kernels), small and large launch configuration."""
+    from random_robots import random_ball_joint_robot
+    robot, desc = random_ball_joint_robot(20 + n_t, n_t)
+    _ball_check(robot, desc, 515, "rk4" if n_t % 2 else "euler", 1 + n_t % 2, n_t)
+    _ball_check(robot, desc, 70001, "euler" if n_t % 2 else "rk4", 1, n_t, sample=53)
+
+
+@pytest.mark.parametrize("seed", [1, 3, 6])
+def test_random_ball_joint_robot_large_batches_jit_and_kernarg(seed):
+    """Above 65 536 envs: the hiprtc instances on the robot's own constants and, with ROBOY_SIM_JIT=0, the kernarg
+    instances (seed 3 and 6: 2 and 1 substeps; seed 3 takes the principal-axis branch)."""
+    import os
+    from random_robots import random_ball_joint_robot
+    robot, desc = random_ball_joint_robot(seed, 8)
+    integrator = "rk4" if seed % 2 else "euler"
+    assert _ball_check(robot, desc, 70001, integrator, 1 + seed % 2, seed, sample=41) == "jit"
+    os.environ["ROBOY_SIM_JIT"] = "0"
+    try:
+        assert _ball_check(robot, desc, 70001, integrator, 1 + seed % 2, seed, sample=41) == "kernarg"
+    finally:
+        del os.environ["ROBOY_SIM_JIT"]
