@@ -161,6 +161,7 @@ __device__ __forceinline__ float swap_half(float v) { return dpp<0x1B>(dpp<0x141
 // lane r of an octet
 struct OctLane {
     int half, kk, n1, n2, row6;    // half: 0 angular / 1 linear; kk: own component (idle lanes shadow 2); n1, n2: the next two, cyclically
+    float sgn;                     // -1 angular / +1 linear
     bool act;                      // owns a row
     __device__ __forceinline__ explicit OctLane(int r) {
         half = r >> 2;
@@ -169,6 +170,7 @@ struct OctLane {
         kk = act ? k : 2;
         n1 = kk == 2 ? 0 : kk + 1; n2 = kk == 0 ? 2 : kk - 1;
         row6 = 3 * half + kk;
+        sgn = half ? 1.0f : -1.0f;
     }
 };
 
@@ -306,37 +308,43 @@ __device__ __forceinline__ void p5_body(const Ctx &c, int e, const OctLane &o, c
     float *me = c.link(e, lr.i);
     const Rec5c lc = load_rec5c(c, lr.q);
     const int k = o.kk, n1 = o.n1, n2 = o.n2, hO = 3 * o.half, hX = 3 - hO;
-    // own link's data, component order (k, n1, n2) by lane-dependent addresses
-    const float sO[3] = {me[O_S + hO + k], me[O_S + hO + n1], me[O_S + hO + n2]};
-    const float sX[3] = {me[O_S + hX + k], me[O_S + hX + n1], me[O_S + hX + n2]};
-    const float cO[3] = {me[O_C + hO + k], me[O_C + hO + n1], me[O_C + hO + n2]};
-    const float cX[3] = {me[O_C + hX + k], me[O_C + hX + n1], me[O_C + hX + n2]};
-    const float pT = me[O_PT + o.row6];
+    // own link's data in component order (k, n1, n2): the lane loads component k (three lane-dependent bases, the
+    // fields at immediate offsets) and takes the other two from its quad by DPP rotations, the other half's
+    // through a half swap - 11 LDS loads per link and lane instead of 33, each of which cost an address add
+    const float *mO = me + hO + k, *mX = me + hX + k, *mk = me + k;
+    const float sO0 = mO[O_S], sX0 = mX[O_S], cO0 = mO[O_C], cX0 = mX[O_C];
+    const float sO[3] = {sO0, rot1(sO0), rot2(sO0)}, sX[3] = {sX0, rot1(sX0), rot2(sX0)};
+    const float cO[3] = {cO0, rot1(cO0), rot2(cO0)}, cX[3] = {cX0, rot1(cX0), rot2(cX0)};
+    const float pT = mO[O_PT];
     const float qdi = (c.env(e) + t.o_SQD)[lr.i];
     float rO[3] = {0.0f, 0.0f, 0.0f}, rX[3] = {0.0f, 0.0f, 0.0f};
     float pa = pT;                                         // the tendon wrenches on the link
     if (!(lr.flags & F_MASSLESS)) {                        // (whole levels of massless links take this uniformly)
-        const V3 Rk = ld3(me + O_RP + 3 * k), R1 = ld3(me + O_RP + 3 * n1), R2 = ld3(me + O_RP + 3 * n2);
-        const float pk = me[O_RP + 9 + k], p1 = me[O_RP + 9 + n1], p2 = me[O_RP + 9 + n2];
-        const float wk = me[O_V + k], w1 = me[O_V + n1], w2 = me[O_V + n2];
-        const float vk = me[O_V + 3 + k], v1 = me[O_V + 3 + n1], v2 = me[O_V + 3 + n2];
+        const V3 Rk = ld3(me + O_RP + 3 * k);
+        const V3 R1 = {rot1(Rk.x), rot1(Rk.y), rot1(Rk.z)}, R2 = {rot2(Rk.x), rot2(Rk.y), rot2(Rk.z)};
+        const float pk = mk[O_RP + 9];
+        // spatial velocity in (own half, other half) order: for the angular lanes that is (w, vO), for the linear (vO, w)
+        const float vO0 = mO[O_V], vX0 = mX[O_V];
+        const float vO1 = rot1(vO0), vO2 = rot2(vO0), vX1 = rot1(vX0), vX2 = rot2(vX0);
         // spatial inertia of the link about the world origin, row row6
         const V3 com = {lc.com[0], lc.com[1], lc.com[2]};
         const float m = lc.m;
-        const float ck = pk + dot(Rk, com), c1 = p1 + dot(R1, com), c2 = p2 + dot(R2, com);     // world COM, rotated order
+        const float ck = pk + dot(Rk, com), c1 = rot1(ck), c2 = rot2(ck);                        // world COM, rotated order
         const float hk = m * ck, h1 = m * c1, h2 = m * c2;
         const V3 tt = symmul(lc.I6, Rk);                   // I R_k^T  (I symmetric)
         const float Ikk = dot(tt, Rk) + m * (c1 * c1 + c2 * c2);
         const float Ik1 = dot(tt, R1) - hk * c1, Ik2 = dot(tt, R2) - hk * c2;
         // angular row k: [ Ibar row | [h]x row ] ;  linear row k: [ m e_k | -[h]x row ] ;  [h]x row k = (0, -h2, h1) in rotated order
         rO[0] = o.half ? m : Ikk; rO[1] = o.half ? 0.0f : Ik1; rO[2] = o.half ? 0.0f : Ik2;
-        rX[1] = o.half ? h2 : -h2; rX[2] = o.half ? -h1 : h1;
-        // I v:  angular (Ibar w + h x vO)[k],  linear (m vO - h x w)[k]
-        const float X = o.half ? (m * vk - (h1 * w2 - h2 * w1)) : (Ikk * wk + Ik1 * w1 + Ik2 * w2 + (h1 * v2 - h2 * v1));
+        rX[1] = o.sgn * h2; rX[2] = -o.sgn * h1;
+        // I v, row row6: the row times the velocity in the same (own, other) order - angular (Ibar w + h x vO)[k],
+        // linear (m vO - h x w)[k] - without a branch on the half
+        const float X = rO[0] * vO0 + rO[1] * vO1 + rO[2] * vO2 + rX[1] * vX1 + rX[2] * vX2;
         const float X1 = rot1(X), X2 = rot2(X);
         const float Y = swap_half(X), Y1 = rot1(Y), Y2 = rot2(Y);
         // bias force v x* (I v):  angular (w x Iv_a + vO x Iv_l)[k],  linear (w x Iv_l)[k]
-        pa += (w1 * X2 - w2 * X1) + (o.half ? 0.0f : (v1 * Y2 - v2 * Y1));
+        const float w1 = o.half ? vX1 : vO1, w2 = o.half ? vX2 : vO2;
+        pa += (w1 * X2 - w2 * X1) + (o.half ? 0.0f : (vX1 * Y2 - vX2 * Y1));
     }
     // children: the one below in the same octet (registers), the others through their exchange slots
     if (lr.flags & F_REGCHILD) {
@@ -351,11 +359,13 @@ __device__ __forceinline__ void p5_body(const Ctx &c, int e, const OctLane &o, c
         rX[0] += row[hX + k]; rX[1] += row[hX + n1]; rX[2] += row[hX + n2];
         pa += X0[__mul24(xs, XSLOT) + 36 + o.row6];
     };
-    if (lr.n_ext > 0) add_ext(lr.ext[0]);
-    if (lr.n_ext > 1) add_ext(lr.ext[1]);
-    if (lr.n_ext > 2) add_ext(lr.ext[2]);
-    if (lr.n_ext > 3) add_ext(lr.ext[3]);
-    for (int q = 4; q < lr.n_ext; ++q) add_ext(c.ti(t.o_ext_list + lr.es + q));
+    if (lr.n_ext > 0) {                                    // branch points only: one test on the chains
+        add_ext(lr.ext[0]);
+        if (lr.n_ext > 1) add_ext(lr.ext[1]);
+        if (lr.n_ext > 2) add_ext(lr.ext[2]);
+        if (lr.n_ext > 3) add_ext(lr.ext[3]);
+        for (int q = 4; q < lr.n_ext; ++q) add_ext(c.ti(t.o_ext_list + lr.es + q));
+    }
     const float U = rO[0] * sO[0] + rO[1] * sO[1] + rO[2] * sO[2] + rX[0] * sX[0] + rX[1] * sX[1] + rX[2] * sX[2];
     // s_row6 U_row6 and s_row6 p^a_row6; idle lanes add exact zeros to the sums (a select, not a product with 0)
     const float D = sum8(o.act ? sO[0] * U : 0.0f) + lc.arm;
@@ -413,6 +423,9 @@ __device__ __forceinline__ void p6_body(const Ctx &c, int e, const OctLane &o, c
 // registers hand data from level to level.  Robots so wide that a level needs several passes
 // (E * lw * 8 > 64) have no inheriting links (tree_build), so their extra passes carry nothing; SP (single
 // pass) instantiations leave those loops out (fewer instructions and registers: 35.7 -> 33.1 us on the upper body).
+// The level loops are unrolled by two over a pair of record variables (A: even trips, B: odd trips), each fetched
+// one level ahead of its use: written as "cur = nxt" at the end of a trip the hand-over cost ~22 register copies
+// per level and sweep (a third of P1's vector instructions).
 template <int E, bool SP>
 __device__ __forceinline__ void sweep_p1(const Ctx &c) {
     const TreeDev &t = c.t;
@@ -422,16 +435,15 @@ __device__ __forceinline__ void sweep_p1(const Ctx &c) {
     const bool first = c.lane < n_slots;
     const float *sq = c.env(first ? e0 : 0) + t.o_W, *sqd = c.env(first ? e0 : 0) + t.o_SQD;
     Carry1 cy = {{0.0f, 0.0f, 0.0f}, 0.0f, 0.0f, 0.0f};
-    Rec1 cur = load_rec1(c, 0, x0);
-    float qi = cur.i >= 0 ? sq[cur.i] : 0.0f, qdi = cur.i >= 0 ? sqd[cur.i] : 0.0f;
-    for (int L = 0; L < t.n_levels; ++L) {
-        Rec1 nxt = cur;
-        float nqi = 0.0f, nqdi = 0.0f;
-        if (L + 1 < t.n_levels) {
-            nxt = load_rec1(c, L + 1, x0);
-            nqi = nxt.i >= 0 ? sq[nxt.i] : 0.0f; nqdi = nxt.i >= 0 ? sqd[nxt.i] : 0.0f;
-        }
-        if (first && cur.i >= 0) p1_body(c, e0, o, cur, qi, qdi, cy);
+    struct Lv { Rec1 r; float q, qd; };
+    auto fetch = [&](int L) {
+        Lv v;
+        v.r = load_rec1(c, L, x0);
+        v.q = v.r.i >= 0 ? sq[v.r.i] : 0.0f; v.qd = v.r.i >= 0 ? sqd[v.r.i] : 0.0f;
+        return v;
+    };
+    auto work = [&](int L, const Lv &v) {
+        if (first && v.r.i >= 0) p1_body(c, e0, o, v.r, v.q, v.qd, cy);
         for (int slot = c.lane + 64; !SP && slot < n_slots; slot += 64) {
             const int oc = slot >> 3, e = oc >> t.lw_shift;
             const Rec1 lr = load_rec1(c, L, oc & (lw - 1));
@@ -439,7 +451,15 @@ __device__ __forceinline__ void sweep_p1(const Ctx &c) {
             if (lr.i >= 0) p1_body(c, e, o, lr, (c.env(e) + t.o_W)[lr.i], (c.env(e) + t.o_SQD)[lr.i], none);
         }
         wave_sync();
-        cur = nxt; qi = nqi; qdi = nqdi;
+    };
+    const int n = t.n_levels;
+    Lv A = fetch(0), B = A;
+    for (int L = 0; L < n; L += 2) {
+        if (L + 1 < n) B = fetch(L + 1);
+        work(L, A);
+        if (L + 1 >= n) break;
+        if (L + 2 < n) A = fetch(L + 2);
+        work(L + 1, B);
     }
 }
 
@@ -451,11 +471,8 @@ __device__ __forceinline__ void sweep_p5(const Ctx &c) {
     const int e0 = (c.lane >> 3) >> t.lw_shift, x0 = (c.lane >> 3) & (lw - 1);
     const bool first = c.lane < n_slots;
     Carry5 cy = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, 0.0f};
-    Rec5 cur = load_rec5(c, t.n_levels - 1, x0);
-    for (int L = t.n_levels - 1; L >= 0; --L) {
-        Rec5 nxt = cur;
-        if (L > 0) nxt = load_rec5(c, L - 1, x0);
-        if (first && cur.i >= 0) p5_body(c, e0, o, cur, cy);
+    auto work = [&](int L, const Rec5 &r) {
+        if (first && r.i >= 0) p5_body(c, e0, o, r, cy);
         for (int slot = c.lane + 64; !SP && slot < n_slots; slot += 64) {
             const int oc = slot >> 3, e = oc >> t.lw_shift;
             const Rec5 lr = load_rec5(c, L, oc & (lw - 1));
@@ -463,7 +480,14 @@ __device__ __forceinline__ void sweep_p5(const Ctx &c) {
             if (lr.i >= 0) p5_body(c, e, o, lr, none);
         }
         wave_sync();
-        cur = nxt;
+    };
+    Rec5 A = load_rec5(c, t.n_levels - 1, x0), B = A;
+    for (int L = t.n_levels - 1; L >= 0; L -= 2) {
+        if (L >= 1) B = load_rec5(c, L - 1, x0);
+        work(L, A);
+        if (L < 1) break;
+        if (L >= 2) A = load_rec5(c, L - 2, x0);
+        work(L - 1, B);
     }
 }
 
@@ -477,16 +501,15 @@ __device__ __forceinline__ void sweep_p6(const Ctx &c) {
     const float g0 = t.g[0], g1 = t.g[1], g2 = t.g[2];   // scalars first: a lane-indexed t.g[] becomes a global load from the kernarg
     const float a0 = o.half ? -(o.kk == 0 ? g0 : (o.kk == 1 ? g1 : g2)) : 0.0f;    // base: fictitious acceleration -g
     float a = 0.0f;
-    Rec1 cur = load_rec1(c, 0, x0);
-    Data6 d = load_data6(c, first ? e0 : 0, o, cur.i >= 0 ? cur.i : 0);
-    for (int L = 0; L < t.n_levels; ++L) {
-        Rec1 nxt = cur;
-        Data6 nd = d;
-        if (L + 1 < t.n_levels) {
-            nxt = load_rec1(c, L + 1, x0);
-            nd = load_data6(c, first ? e0 : 0, o, nxt.i >= 0 ? nxt.i : 0);
-        }
-        if (first && cur.i >= 0) p6_body(c, e0, o, cur, d, a0, a);
+    struct Lv { Rec1 r; Data6 d; };
+    auto fetch = [&](int L) {
+        Lv v;
+        v.r = load_rec1(c, L, x0);
+        v.d = load_data6(c, first ? e0 : 0, o, v.r.i >= 0 ? v.r.i : 0);
+        return v;
+    };
+    auto work = [&](int L, const Lv &v) {
+        if (first && v.r.i >= 0) p6_body(c, e0, o, v.r, v.d, a0, a);
         for (int slot = c.lane + 64; !SP && slot < n_slots; slot += 64) {
             const int oc = slot >> 3, e = oc >> t.lw_shift;
             const Rec1 lr = load_rec1(c, L, oc & (lw - 1));
@@ -494,7 +517,15 @@ __device__ __forceinline__ void sweep_p6(const Ctx &c) {
             if (lr.i >= 0) p6_body(c, e, o, lr, load_data6(c, e, o, lr.i), a0, none);
         }
         wave_sync();
-        cur = nxt; d = nd;
+    };
+    const int n = t.n_levels;
+    Lv A = fetch(0), B = A;
+    for (int L = 0; L < n; L += 2) {
+        if (L + 1 < n) B = fetch(L + 1);
+        work(L, A);
+        if (L + 1 >= n) break;
+        if (L + 2 < n) A = fetch(L + 2);
+        work(L + 1, B);
     }
 }
 
