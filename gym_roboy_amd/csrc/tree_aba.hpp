@@ -212,7 +212,24 @@ __device__ __forceinline__ Rec5c load_rec5c(const Ctx &c, int q) {
 //      alike, so the quad rotations work in each); the angular half stores R, p, z, c_ang, the linear
 //      half w, vO, sl, c_lin.  `cy` carries (row of R, p, w, vO) down the chain. ----
 struct Carry1 { V3 Rrow; float p, w, vo; };
-__device__ __forceinline__ void p1_body(const Ctx &c, int e, const OctLane &o, const Rec1 &lr, float qi, float qdi, Carry1 &cy) {
+// the joint's own rotation exp(q [axis]x) by columns: evaluated once per joint by the joint's lane (tree_accel), not
+// by the eight lanes of its octet inside the level loop (a sincos and ~25 vector instructions per level there)
+struct Rot { V3 c0, c1, c2; };
+__device__ __forceinline__ Rot rodrigues(V3 ax, float q) {
+    float sn, cs;
+    __sincosf(q, &sn, &cs);
+    const float oc = 1.0f - cs;        // I + sin K + (1 - cos) K^2
+    Rot r;
+    r.c0 = {1.0f - oc * (ax.y * ax.y + ax.z * ax.z), sn * ax.z + oc * ax.x * ax.y, -sn * ax.y + oc * ax.x * ax.z};
+    r.c1 = {-sn * ax.z + oc * ax.x * ax.y, 1.0f - oc * (ax.x * ax.x + ax.z * ax.z), sn * ax.x + oc * ax.y * ax.z};
+    r.c2 = {sn * ax.y + oc * ax.x * ax.z, -sn * ax.x + oc * ax.y * ax.z, 1.0f - oc * (ax.x * ax.x + ax.y * ax.y)};
+    return r;
+}
+__device__ __forceinline__ Rot load_rot(const Ctx &c, int e, int i) {
+    const float *p = c.env(e) + c.t.o_W + c.t.n_q + __mul24(i, ROT);
+    return {ld3(p), ld3(p + 3), ld3(p + 6)};
+}
+__device__ __forceinline__ void p1_body(const Ctx &c, int e, const OctLane &o, const Rec1 &lr, const Rot &rot, float qdi, Carry1 &cy) {
     float *me = c.link(e, lr.i);
     V3 Rrow = cy.Rrow;
     float pp = cy.p, wp0 = cy.w, wp1 = rot1(cy.w), wp2 = rot2(cy.w), vop = cy.vo;
@@ -226,13 +243,7 @@ __device__ __forceinline__ void p1_body(const Ctx &c, int e, const OctLane &o, c
         }
     }
     const V3 ax = {lr.ax[0], lr.ax[1], lr.ax[2]}, org = {lr.org[0], lr.org[1], lr.org[2]};
-    float sn, cs;
-    __sincosf(qi, &sn, &cs);
-    // Rodrigues: I + sin K + (1 - cos) K^2, by columns
-    const float oc = 1.0f - cs;
-    const V3 c0 = {1.0f - oc * (ax.y * ax.y + ax.z * ax.z), sn * ax.z + oc * ax.x * ax.y, -sn * ax.y + oc * ax.x * ax.z};
-    const V3 c1 = {-sn * ax.z + oc * ax.x * ax.y, 1.0f - oc * (ax.x * ax.x + ax.z * ax.z), sn * ax.x + oc * ax.y * ax.z};
-    const V3 c2 = {sn * ax.y + oc * ax.x * ax.z, -sn * ax.x + oc * ax.y * ax.z, 1.0f - oc * (ax.x * ax.x + ax.y * ax.y)};
+    const V3 c0 = rot.c0, c1 = rot.c1, c2 = rot.c2;
     const V3 Ri = {dot(Rrow, c0), dot(Rrow, c1), dot(Rrow, c2)};      // row kk of R_p rot
     const float p = pp + dot(Rrow, org);                              // component kk of p_i
     const float z = dot(Rrow, ax);                                    // ... of the joint axis
@@ -433,22 +444,24 @@ __device__ __forceinline__ void sweep_p1(const Ctx &c) {
     const OctLane o(c.lane & 7);
     const int e0 = (c.lane >> 3) >> t.lw_shift, x0 = (c.lane >> 3) & (lw - 1);
     const bool first = c.lane < n_slots;
-    const float *sq = c.env(first ? e0 : 0) + t.o_W, *sqd = c.env(first ? e0 : 0) + t.o_SQD;
+    const float *sqd = c.env(first ? e0 : 0) + t.o_SQD;
     Carry1 cy = {{0.0f, 0.0f, 0.0f}, 0.0f, 0.0f, 0.0f};
-    struct Lv { Rec1 r; float q, qd; };
+    struct Lv { Rec1 r; Rot rot; float qd; };
     auto fetch = [&](int L) {
         Lv v;
         v.r = load_rec1(c, L, x0);
-        v.q = v.r.i >= 0 ? sq[v.r.i] : 0.0f; v.qd = v.r.i >= 0 ? sqd[v.r.i] : 0.0f;
+        const int i = v.r.i >= 0 ? v.r.i : 0;
+        v.rot = load_rot(c, first ? e0 : 0, i);
+        v.qd = sqd[i];
         return v;
     };
     auto work = [&](int L, const Lv &v) {
-        if (first && v.r.i >= 0) p1_body(c, e0, o, v.r, v.q, v.qd, cy);
+        if (first && v.r.i >= 0) p1_body(c, e0, o, v.r, v.rot, v.qd, cy);
         for (int slot = c.lane + 64; !SP && slot < n_slots; slot += 64) {
             const int oc = slot >> 3, e = oc >> t.lw_shift;
             const Rec1 lr = load_rec1(c, L, oc & (lw - 1));
             Carry1 none = {{0.0f, 0.0f, 0.0f}, 0.0f, 0.0f, 0.0f};
-            if (lr.i >= 0) p1_body(c, e, o, lr, (c.env(e) + t.o_W)[lr.i], (c.env(e) + t.o_SQD)[lr.i], none);
+            if (lr.i >= 0) p1_body(c, e, o, lr, load_rot(c, e, lr.i), (c.env(e) + t.o_SQD)[lr.i], none);
         }
         wave_sync();
     };
@@ -549,13 +562,21 @@ __device__ __forceinline__ void tree_accel(const Ctx &c, const float *qj, const 
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         int e, j;
-        if (joint_slot<E>(t, lane, p, e, j)) { (c.env(e) + t.o_W)[j] = qj[p]; (c.env(e) + t.o_SQD)[j] = vj[p]; }
+        if (joint_slot<E>(t, lane, p, e, j)) {
+            // the joint's velocity and its rotation matrix (behind SQ at the start of W, dead before P2 writes W)
+            const float *jr = c.tab + t.o_joint + __mul24(j, JOINT_REC);
+            const Rot r = rodrigues({jr[4], jr[5], jr[6]}, qj[p]);
+            float *dst = c.env(e) + t.o_W + t.n_q + __mul24(j, ROT);
+            st3(dst, r.c0); st3(dst + 3, r.c1); st3(dst + 6, r.c2);
+            (c.env(e) + t.o_SQD)[j] = vj[p];
+        }
     }
-    // the zero slot behind W that pads P4's lists (the exchange slots of P5 may have covered it)
-    if (lane < 6 * E) (c.env(lane / 6) + t.o_W + t.zoff)[lane % 6] = 0.0f;
     wave_sync();
     // ---- P1: forward kinematics, one tree level at a time ----
     if (!(RB_TREE_SKIP & 1)) sweep_p1<E, SP>(c);
+    // the zero slot behind W that pads P4's lists (the rotation matrices or P5's exchange slots may have covered it;
+    // P2 writes below it)
+    if (lane < 6 * E) (c.env(lane / 6) + t.o_W + t.zoff)[lane % 6] = 0.0f;
     // ---- P2: tendons (SQ is dead: W overwrites it) ----
     for (int it = lane; it < ((RB_TREE_SKIP & 2) ? 0 : E * t.n_t); it += 64) {
         int e, k;
@@ -607,7 +628,7 @@ __device__ __forceinline__ void tree_integrate(const Ctx &c, float *qj, float *v
     for (int p = 0; p < NP; ++p) {
         int e, j;
         joint[p] = joint_slot<E>(t, c.lane, p, e, j);
-        const float *rec = c.tab + t.o_joint + (joint[p] ? j : 0) * 4;
+        const float *rec = c.tab + t.o_joint + (joint[p] ? j : 0) * JOINT_REC;
         vmax[p] = joint[p] ? rec[2] : 0.0f; lo[p] = joint[p] ? rec[0] : 0.0f; hi[p] = joint[p] ? rec[1] : 0.0f;
         ok[p] = true;
     }

@@ -38,7 +38,8 @@ constexpr int TREE_E = RB_TREE_E;   // envs per wave
 constexpr int LS = 37;      // floats per link in an env's working set (layout below); odd: lanes that hold
                             // different links of an env hit different LDS banks (strides of 64 / 48 floats
                             // cost 20- / 10-way conflicts in the per-link phases)
-constexpr int TENDON_REC = 8, CROSS_REC = 8, REC1 = 12, REC5 = 24, XSLOT = 42;
+constexpr int TENDON_REC = 8, CROSS_REC = 8, REC1 = 12, REC5 = 24, XSLOT = 42, JOINT_REC = 8;
+constexpr int ROT = 9;      // floats of a joint's rotation matrix (by columns) in the env block during P1, behind SQ
 
 // Link block (LS floats), by phase:
 //   [ 0.. 8]  R (row-major)     [ 9..11]  p      [12..14]  w      [15..17]  vO       P1 -> P5
@@ -236,8 +237,10 @@ inline int tree_build(const rb_robot_desc *d, double step_size, int nsub, TreeHo
         w.push_back(f2w(used ? d->armature[i] : 1.0)); w.push_back(f2w(used ? d->damping[i] : 0.0));
     }
     pad4(); t.o_joint = int(w.size());
-    for (int i = 0; i < nq; ++i) {                  // limits: qlo, qhi, qdmax, 0
+    for (int i = 0; i < nq; ++i) {                  // per joint: qlo, qhi, qdmax, 0, axis 3, 0
         w.push_back(f2w(d->q_lo[i])); w.push_back(f2w(d->q_hi[i])); w.push_back(f2w(d->qd_max[i])); w.push_back(0u);
+        for (int a = 0; a < 3; ++a) w.push_back(f2w(d->axis[3 * i + a]));
+        w.push_back(0u);
     }
     pad4(); t.o_tendon = int(w.size());
     for (double x : t_rec) w.push_back(f2w(x));
@@ -255,10 +258,11 @@ inline int tree_build(const rb_robot_desc *d, double step_size, int nsub, TreeHo
     t.single_pass = chain_ok ? 1 : 0;
     int qw = 1; t.q_shift = 0;
     while (qw < nq) { qw <<= 1; ++t.q_shift; }
-    // env block: links | W (6 per crossing, then a zero slot of 6; SQ aliases the start during P1, the
-    // exchange slots alias it during P5) | SQD | SPU
+    // env block: links | W (6 per crossing, then a zero slot of 6; SQ and the joints' rotation matrices alias the
+    // start during P1, the exchange slots alias it during P5) | SQD | SPU
     int wsz = zoff + 6;
     if (XSLOT * n_x > wsz) wsz = XSLOT * n_x;
+    if ((1 + ROT) * nq > wsz) wsz = (1 + ROT) * nq;   // P1: SQ (nq) and behind it the joints' rotation matrices
     t.zoff = zoff;
     t.o_W = nq * LS;
     t.o_SQD = t.o_W + wsz;
