@@ -61,6 +61,10 @@ MAX_REPEATS = 256
 HBM_PEAK = 8.0e12          # B/s, spec (MI355X_MICROARCH.md "HBM3E peak BW")
 HBM_COPY = 6.29e12         # B/s, measured float4 copy (same table)
 VALU_PEAK = 157.3e12       # flop/s, fp32 vector peak (MI355X_MICROARCH.md "Peak FP32 (vector)")
+# measured rate of independent v_fma_f32 on this chip: 1.20 ns per wave-instruction and SIMD at 8 waves per SIMD
+# (profiles/r1_b/microbench_valu.log; v_pk_fma_f32 takes twice as long, i.e. the same flop rate): 64 lanes x 2 flop
+# x 1024 SIMDs / 1.20 ns.  The spec peak is the roof `frac` is quoted against; this is what an all-FMA stream reaches.
+VALU_FMA_MEASURED = 64 * 2 * 1024 / 1.20e-9
 KERNEL_NAMES = {1: "msj_step_env_per_lane", 2: "msj_step_tendon_per_lane", 3: "tree_step_aba"}
 PROFILE_DIRS = ("r2_a", "r1_b")   # newest first: where the committed rocprofv3 PMC passes live
 
@@ -104,6 +108,7 @@ def roofline(robot_name, integrator, substeps, n_envs, bytes_per_env_step, launc
     if flops is not None:
         tf = flops * n_envs / launch_s / 1e12
         valu = {"achieved": tf, "peak": VALU_PEAK / 1e12, "unit": "TFLOP/s", "frac": tf * 1e12 / VALU_PEAK,
+                "frac_of_measured_fma_rate_109TFLOPs": tf * 1e12 / VALU_FMA_MEASURED,
                 "flops_per_env_step": flops, "flops_per_launch": flops * n_envs,
                 "source": "profiles/flops_per_env_step.json (instrumented restatement, oracle/flop_count.cpp)"}
     top = valu if (valu is not None and valu["frac"] > hbm["frac"]) else hbm
