@@ -71,6 +71,51 @@ def gae(rewards, values, dones, last_value, gamma, lam):
     return adv, adv + values
 
 
+class FusedPolicyStep:
+    """``MlpPolicy.act`` as one kernel on the matrix cores (include/roboy_policy.h, csrc/mlp_policy.hip): observation
+    -> action sample, log-probability, value, written straight into the rollout buffers.  The parameters stay torch
+    tensors (the optimiser updates them in place); ``pack()`` is one device-side gather into the operand order the
+    kernel reads (the gather map depends on the dimensions only and is built once on the host).  Exploration noise is
+    the library's Philox stream keyed (seed; sample, step), not torch's generator."""
+
+    def __init__(self, policy, seed=0):
+        import ctypes
+        from . import _policy_native as pn
+        self._pn, self._ct, self._lib = pn, ctypes, pn.load()
+        self.policy = policy
+        self.obs_dim, self.act_dim = policy.pi[0].in_features, policy.pi[-1].out_features
+        if policy.pi[0].out_features != 64 or len(policy.pi) != 5:
+            raise ValueError("the fused policy step is built for MlpPolicy's two hidden layers of 64 units")
+        dev = policy.log_std.device
+        m, total = pn.gather_map(self.obs_dim, self.act_dim)
+        self._map = torch.from_numpy(m).to(dev)
+        self._zero = torch.zeros(1, device=dev)
+        self.seed = int(seed)
+
+    def _params(self):
+        pi, vf = self.policy.pi, self.policy.vf
+        return [pi[0].weight, pi[0].bias, pi[2].weight, pi[2].bias, pi[4].weight, pi[4].bias,
+                vf[0].weight, vf[0].bias, vf[2].weight, vf[2].bias, vf[4].weight, vf[4].bias, self.policy.log_std]
+
+    @torch.no_grad()
+    def pack(self):
+        flat = torch.cat([p.detach().reshape(-1) for p in self._params()] + [self._zero])
+        return flat[self._map]
+
+    @torch.no_grad()
+    def act_into(self, obs, act, logp, val, step=0, packed=None, mean=None, sample_offset=0, deterministic=False,
+                 step_base=None):
+        """obs [n, obs_dim] (contiguous, fp32, cuda) -> act [n, act_dim], logp [n], val [n] (preallocated)."""
+        c = self._ct
+        packed = self.pack() if packed is None else packed
+        ptr = lambda t: c.c_void_p(t.data_ptr()) if t is not None else None
+        self._pn.check(self._lib.rp_act_dev(
+            ptr(packed), ptr(obs), ptr(act), ptr(logp), ptr(val), ptr(mean), int(obs.shape[0]), self.obs_dim, self.act_dim,
+            self.seed, int(sample_offset), int(step), ptr(step_base), int(bool(deterministic)),
+            c.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)))
+        return packed
+
+
 def average_gradients(module, dist=None):
     if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return
@@ -89,7 +134,7 @@ def average_gradients(module, dist=None):
 class PPO:
     def __init__(self, env, policy=None, n_steps=128, nminibatches=4, noptepochs=4, gamma=0.99, lam=0.95,
                  learning_rate=2.5e-4, cliprange=0.2, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5,
-                 device="cuda", dist=None, reward_scale=1.0, seed=0, use_graphs=False):
+                 device="cuda", dist=None, reward_scale=1.0, seed=0, use_graphs=False, fused_policy=False):
         self.env, self.dist, self.device = env, dist, torch.device(device)
         torch.manual_seed(seed)
         obs_dim = env.observation_space.shape[0]
@@ -105,6 +150,14 @@ class PPO:
         self.use_graphs = bool(use_graphs) and self.device.type == "cuda" and hasattr(env, "step_dev") and not multi_rank
         self.opt = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5)
         self._rollout_graph = None
+        # fused_policy: the rollout's policy step runs as one MFMA kernel (FusedPolicyStep) instead of ~30 torch kernels
+        self._fused = None
+        if fused_policy:
+            if self.device.type != "cuda":
+                raise ValueError("fused_policy needs a GPU")
+            rank = dist.get_rank() if multi_rank else 0
+            self._fused = FusedPolicyStep(self.policy, seed=seed + 7919 * rank)
+            self._step_base = torch.zeros(1, dtype=torch.int32, device=self.device)    # rollout steps taken so far
         self.n_steps, self.nminibatches, self.noptepochs = n_steps, nminibatches, noptepochs
         self.gamma, self.lam, self.cliprange = gamma, lam, cliprange
         self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
@@ -119,12 +172,22 @@ class PPO:
     def _rollout_body(self, b):
         env, T = self.env, self.n_steps
         b["obs"][0].copy_(b["carry"])
+        packed = self._fused.pack() if self._fused is not None else None     # (inside the graph: re-gathered on every replay)
         for t in range(T):
+            if self._fused is not None:
+                # straight into the rollout buffers; the env kernel clamps the action to its box itself
+                self._fused.act_into(b["obs"][t], b["act"][t], b["logp"][t], b["val"][t], step=t, packed=packed,
+                                     step_base=self._step_base)
+                env.step_dev(b["act"][t].data_ptr(), b["obs"][t + 1].data_ptr(), b["rew_raw"][t].data_ptr(),
+                             b["done_i"][t].data_ptr())
+                continue
             a, logp, v = self.policy.act(b["obs"][t])
             b["act"][t].copy_(a); b["logp"][t].copy_(logp); b["val"][t].copy_(v)
             clipped = a.clamp(-1.0, 1.0).contiguous()
             env.step_dev(clipped.data_ptr(), b["obs"][t + 1].data_ptr(), b["rew_raw"][t].data_ptr(),
                          b["done_i"][t].data_ptr())
+        if self._fused is not None:
+            self._step_base += T                                             # fresh noise on the next replay
         b["rew"].copy_(b["rew_raw"] * self.reward_scale)
         b["done"].copy_(b["done_i"].to(torch.float32))
         with torch.no_grad():
@@ -148,6 +211,8 @@ class PPO:
         with torch.cuda.stream(side), torch.no_grad():
             # first use of the GEMM library for these shapes (handle, workspace) must not fall into the capture
             self.policy.act(b["carry"]); self.policy.value(b["carry"])
+            if self._fused is not None:       # its one-time launch configuration must not fall into the capture either
+                self._fused.act_into(b["carry"], b["act"][0], b["logp"][0], b["val"][0], deterministic=True)
         side.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
@@ -179,14 +244,23 @@ class PPO:
             self._obs = self._to_tensor(env.reset())
         N = self._obs.shape[0]
         buf = {k: [] for k in ("obs", "act", "logp", "val", "rew", "done")}
-        for _ in range(T):
-            a, logp, v = self.policy.act(self._obs)
+        packed = self._fused.pack() if self._fused is not None else None
+        for t in range(T):
+            if self._fused is not None:
+                o = self._obs.contiguous()
+                a = torch.empty(N, self._fused.act_dim, device=self.device)
+                logp, v = torch.empty(N, device=self.device), torch.empty(N, device=self.device)
+                self._fused.act_into(o, a, logp, v, step=t, packed=packed, step_base=self._step_base)
+            else:
+                a, logp, v = self.policy.act(self._obs)
             clipped = a.clamp(-1.0, 1.0).contiguous()        # the env's action box (roboy_env.py:31)
             obs, rew, done, _ = env.step(clipped if self.device.type == "cuda" else clipped.cpu().numpy())
             buf["obs"].append(self._obs); buf["act"].append(a); buf["logp"].append(logp); buf["val"].append(v)
             buf["rew"].append(self._to_tensor(rew) * self.reward_scale)
             buf["done"].append(self._to_tensor(done))
             self._obs = self._to_tensor(obs)
+        if self._fused is not None:
+            self._step_base += T
         roll = {k: torch.stack(v) for k, v in buf.items()}
         with torch.no_grad():
             last_value = self.policy.value(self._obs)
