@@ -21,6 +21,12 @@ SIGNATURES = {
     "rp_last_error": (ctypes.c_char_p, []),
     "rp_packed_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),
     "rp_pack": (ctypes.c_int, [ctypes.POINTER(MlpParams), ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "rp_train_packed_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),
+    "rp_pack_train": (ctypes.c_int, [ctypes.POINTER(MlpParams), ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "rp_grad_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),
+    "rp_ppo_workspace_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
+    "rp_ppo_grad_dev": (ctypes.c_int, [ctypes.c_void_p] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                       ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rp_act_dev": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
                                   ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
 }
@@ -60,21 +66,38 @@ def param_shapes(obs_dim, act_dim, hidden=64):
             "vf_w2": (hidden, hidden), "vf_b2": (hidden,), "vf_w3": (1, hidden), "vf_b3": (1,), "log_std": (act_dim,)}
 
 
-def pack(params, obs_dim, act_dim):
-    """params: {name: float32 array in torch layout} -> the packed blob (numpy float32)."""
+def pack(params, obs_dim, act_dim, train=False):
+    """params: {name: float32 array in torch layout} -> the packed blob (numpy float32); train: the PPO-gradient
+    blob (the rollout blob followed by the transposed weights)."""
     lib = load()
-    n = lib.rp_packed_floats(obs_dim, act_dim)
+    n = (lib.rp_train_packed_floats if train else lib.rp_packed_floats)(obs_dim, act_dim)
     if n < 0:
         check(int(n))
     shapes = param_shapes(obs_dim, act_dim)
     keep = [np.ascontiguousarray(params[k], dtype=np.float32).reshape(shapes[k]) for k in PARAM_ORDER]
     st = MlpParams(*[a.ctypes.data_as(ctypes.c_void_p) for a in keep])
     out = np.zeros(n, np.float32)
-    check(lib.rp_pack(ctypes.byref(st), obs_dim, act_dim, out.ctypes.data_as(ctypes.c_void_p)))
+    check((lib.rp_pack_train if train else lib.rp_pack)(ctypes.byref(st), obs_dim, act_dim, out.ctypes.data_as(ctypes.c_void_p)))
     return out
 
 
-def gather_map(obs_dim, act_dim):
+def grad_layout(obs_dim, act_dim):
+    """{parameter name: (offset, shape)} inside the gradient vector of rp_ppo_grad_dev, plus "pi_loss" / "vf_loss"."""
+    gs = int(load().rp_grad_floats(obs_dim, act_dim)) // 2
+    out = {}
+    for net, n_out, base in (("pi", act_dim, 0), ("vf", 1, gs)):
+        o = base
+        for name, shape in (("w1", (64, obs_dim)), ("b1", (64,)), ("w2", (64, 64)), ("b2", (64,)), ("w3", (n_out, 64)), ("b3", (n_out,))):
+            out["%s_%s" % (net, name)] = (o, shape)
+            o += int(np.prod(shape))
+        if net == "pi":
+            out["log_std"] = (o, (act_dim,))
+        o += n_out
+        out["%s_loss" % net] = (o, ())
+    return out, 2 * gs
+
+
+def gather_map(obs_dim, act_dim, train=False):
     """Index map m (int64, length rp_packed_floats) with packed = concat(params in PARAM_ORDER, [0.0])[m]: the
     order depends on the dimensions only, so the device-side packing of changing parameters is one gather."""
     shapes = param_shapes(obs_dim, act_dim)
@@ -84,6 +107,6 @@ def gather_map(obs_dim, act_dim):
         params[k] = (np.arange(off, off + size, dtype=np.float32) + 1.0).reshape(shapes[k])     # index + 1; 0 marks padding
         off += size
     assert off < (1 << 24)                     # exact in float32
-    m = pack(params, obs_dim, act_dim).astype(np.int64) - 1
+    m = pack(params, obs_dim, act_dim, train).astype(np.int64) - 1
     m[m < 0] = off                             # the appended zero
     return m, off

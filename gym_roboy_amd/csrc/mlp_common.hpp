@@ -1,0 +1,77 @@
+// mlp_common.hpp - shared by the policy kernels (mlp_policy.hip: rollout step, mlp_train.hip: PPO gradient):
+// operand layout of the packed parameter blob, MFMA / half-wave helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/roboy_policy.h"
+
+namespace rpd {
+
+extern thread_local std::string g_err;
+int fail(int code, const std::string &msg);
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int H = RP_HIDDEN, HT = H / 32;            // hidden units, row tiles of a hidden layer
+constexpr int STREAM_POLICY = 2;                     // Philox stream of the exploration noise (0: actions, 1: goals)
+
+// unit of D register r within a 32-row tile, lower half-wave (upper: + 4)
+constexpr int unit_of(int r) { return (r & 3) + 8 * (r >> 2); }
+
+struct Layout {                  // offsets (floats) into the packed blob
+    int k1s;                     // K-steps of layer 1: ceil((obs_dim + 1) / 2)
+    int ot_pi;                   // row tiles of the action mean: ceil(act_dim / 32)
+    int o_l1;                    // [4 row tiles: pi 0, pi 1, vf 0, vf 1][k1s][64]
+    int o_l2[2], o_b2[2];        // per net: [HT out][HT in][16][64], bias [HT][64]
+    int o_l3[2], o_b3[2];        // per net: [ot][HT][16][64], bias [ot][64]
+    int o_logstd;                // [64]
+    int total;                   // floats of the rollout blob (rp_pack)
+    // the PPO-gradient blob (rp_pack_train) continues with the TRANSPOSED weights as A operands:
+    int k3s[2];                  // per net: K-steps over the outputs, ceil(n_out / 2)
+    int o_l3t[2];                // per net: W3^T  [HT unit tiles][k3s][64]: row = unit, k = output 2 s + (l >> 5)
+    int o_l2t[2];                // per net: W2^T  [HT in tiles][HT out tiles][16][64]: row = in unit, k = out unit U(r) + 4 (l >> 5)
+    int total_train;
+};
+__host__ __device__ inline Layout layout_of(int obs_dim, int act_dim) {
+    Layout L;
+    L.k1s = (obs_dim + 2) / 2;
+    L.ot_pi = (act_dim + 31) / 32;
+    int o = 0;
+    L.o_l1 = o; o += 4 * L.k1s * 64;
+    for (int n = 0; n < 2; ++n) {
+        L.o_l2[n] = o; o += HT * HT * 16 * 64;
+        L.o_b2[n] = o; o += HT * 64;
+        const int ot = n == 0 ? L.ot_pi : 1;
+        L.o_l3[n] = o; o += ot * HT * 16 * 64;
+        L.o_b3[n] = o; o += ot * 64;
+    }
+    L.o_logstd = o; o += 64;
+    L.total = (o + 3) & ~3;
+    o = L.total;
+    for (int n = 0; n < 2; ++n) {
+        L.k3s[n] = ((n == 0 ? act_dim : 1) + 1) / 2;
+        L.o_l3t[n] = o; o += HT * L.k3s[n] * 64;
+        L.o_l2t[n] = o; o += HT * HT * 16 * 64;
+    }
+    L.total_train = (o + 3) & ~3;
+    return L;
+}
+
+__device__ __forceinline__ void half_swap(float &a, float &b) {      // a.hi <-> b.lo
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float tanh_fast(float x) {                 // 1 - 2 / (exp(2x) + 1): v_exp_f32 + v_rcp_f32
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+__device__ __forceinline__ void tanh_tile(f32x16 &d) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[r] = tanh_fast(d[r]);
+}
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+
+}  // namespace rpd

@@ -1,0 +1,511 @@
+// mlp_train.hip - the PPO minibatch gradient of MlpPolicy as one kernel per network on the matrix cores
+// (include/roboy_policy.h: rp_ppo_grad_dev; gym_roboy_amd/ppo.py: _minibatch_loss is the torch statement of it).
+//
+// For a minibatch (obs, act, normalised advantage, old log-probability, old value, return), one launch per net
+// (NET 0: action mean + log-std, the clipped surrogate; NET 1: value, the clipped value loss) runs, per 64-sample
+// tile of a wave:  forward (as mlp_policy.hip; the activations stay in registers)  ->  per-sample loss derivative
+// delta3 (one sample per lane)  ->  delta2 = (W3^T delta3) (1 - h2^2),  delta1 = (W2^T delta2) (1 - h1^2)  with
+// the same "a layer's result registers are the next layer's B operands" chaining (the transposed weights are
+// packed as A operands by rp_pack_train)  ->  the weight gradients  dW3 += delta3 h2^T, dW2 += delta2 h1^T,
+// dW1 += delta1 [obs | 1]^T.  Those contract over SAMPLES, which sit on the lanes of every activation register,
+// so both factors go through a 32x32 transpose in LDS (33-float rows: conflict-free both ways) into the layout
+// "units on the lanes, samples in the registers"; there register r of the two factors is directly an A / B operand
+// pair whose K pair is the samples (U(r), U(r) + 4) of the column tile.  The gradient accumulators (64 + 32 + 32
+// registers of 32x32 tiles) live across all tiles of a wave; bias and log-std gradients are per-lane sums reduced
+// once at the end.  Each wave writes its partial gradient (torch parameter order); a second kernel sums the waves.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "../../include/roboy_policy.h"
+#include "mlp_common.hpp"
+
+namespace {
+using namespace rpd;
+
+__device__ __forceinline__ void wave_fence() {         // orders this wave's LDS traffic (in-order per wave)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 32x32 transpose of an accumulator tile through the wave's LDS scratch T (32 rows of 33 floats):
+// in: lane (column n = l & 31, half h), register r <-> row U(r) + 4 h;  out: the same with rows and columns exchanged
+__device__ __forceinline__ f32x16 transpose_tile(const f32x16 &d, float *T, int col, int half) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) T[(unit_of(r) + 4 * half) * 33 + col] = d[r];
+    wave_fence();
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = T[col * 33 + unit_of(r) + 4 * half];
+    wave_fence();
+    return o;
+}
+
+struct TrainArgs {
+    const float *packed;                                  // rp_pack_train blob
+    const float *obs, *act, *adv, *logp_old, *val_old, *ret;
+    float *partials;                                      // [waves][gstride]
+    long B;
+    int obs_dim, act_dim, gstride;
+    float cliprange, vf_coef, inv_B;
+};
+
+// offsets of one net's parameters inside its gradient vector (torch layout)
+struct GOff { int w1, b1, w2, b2, w3, b3, ls, loss; };
+__host__ __device__ inline GOff goff_of(int obs_dim, int n_out) {
+    GOff g;
+    int o = 0;
+    g.w1 = o; o += H * obs_dim;
+    g.b1 = o; o += H;
+    g.w2 = o; o += H * H;
+    g.b2 = o; o += H;
+    g.w3 = o; o += n_out * H;
+    g.b3 = o; o += n_out;
+    g.ls = o; o += n_out;          // log-std gradient (action net only; zero for the value net)
+    g.loss = o; o += 4;            // [sum of the per-sample loss terms / B, ...]
+    return g;
+}
+__host__ __device__ inline int gstride_of(int obs_dim, int act_dim) {
+    const int a = goff_of(obs_dim, act_dim).loss + 4;
+    return (a + 3) & ~3;
+}
+
+// KX: 32-column tiles of [obs | 1] (obs_dim + 1 <= 32 KX);  NJ: compile-time bound of the outputs (n_out <= NJ,
+// a multiple of 8): the per-sample arrays of the loss derivative are NJ registers each
+template <int NET, int KX, int NJ>
+__global__ void __launch_bounds__(256, 1)
+mlp_grad_kernel(const TrainArgs a) {
+    constexpr int OT = (NJ + 31) / 32;                     // 32-row tiles of the outputs
+    extern __shared__ float4 lds4[];
+    float *lds = reinterpret_cast<float *>(lds4);
+    const int obs_dim = a.obs_dim, act_dim = a.act_dim, n_out = NET == 0 ? a.act_dim : 1;
+    // LDS holds THIS net's operand blocks only (offsets of the blob rebased), then per-wave scratch
+    const Layout G = layout_of(obs_dim, act_dim);
+    Layout L = G;
+    const int ot_net = NET == 0 ? G.ot_pi : 1;
+    int o = 0;
+    auto stage = [&](int src, int n_floats) {              // blob block -> LDS at o; all blocks are multiples of 4 floats
+        const float4 *s4 = reinterpret_cast<const float4 *>(a.packed + src);
+        for (int k = threadIdx.x; k < n_floats / 4; k += blockDim.x) lds4[o / 4 + k] = s4[k];
+        const int at = o;
+        o += n_floats;
+        return at;
+    };
+    L.o_l1 = stage(G.o_l1 + (NET == 0 ? 0 : HT) * G.k1s * 64, HT * G.k1s * 64) - 0;
+    L.o_l2[NET] = stage(G.o_l2[NET], HT * HT * 16 * 64);
+    L.o_b2[NET] = stage(G.o_b2[NET], HT * 64);
+    L.o_l3[NET] = stage(G.o_l3[NET], ot_net * HT * 16 * 64);
+    L.o_b3[NET] = stage(G.o_b3[NET], ot_net * 64);
+    L.o_logstd = stage(G.o_logstd, 64);
+    L.o_l3t[NET] = stage(G.o_l3t[NET], HT * G.k3s[NET] * 64);
+    L.o_l2t[NET] = stage(G.o_l2t[NET], HT * HT * 16 * 64);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    constexpr int S3S = NJ + 1;                            // row stride of the delta3 staging (odd)
+    float *T = lds + o + wave * (32 * 33 + 64 * S3S);      // transpose scratch, then the delta3 staging [64][S3S]
+    float *S3 = T + 32 * 33;
+    const float onehot = half ? 0.0f : 1.0f;
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const long B = a.B, n_tiles = (B + 63) / 64;
+    const int mrow = 0;                                     // (the staged layer-1 block holds this net's two row tiles)
+    const int k3s = L.k3s[NET];
+
+    // gradient accumulators, alive across the wave's tiles
+    f32x16 G1[HT][KX], G2[HT][HT], G3[OT][HT], db2[HT];
+    float db3[NJ], gls[NJ];
+    float loss_sum = 0.0f;
+#pragma unroll
+    for (int o = 0; o < HT; ++o) {
+        db2[o] = zero;
+#pragma unroll
+        for (int k = 0; k < KX; ++k) G1[o][k] = zero;
+#pragma unroll
+        for (int m = 0; m < HT; ++m) G2[o][m] = zero;
+    }
+#pragma unroll
+    for (int q = 0; q < OT; ++q)
+#pragma unroll
+        for (int m = 0; m < HT; ++m) G3[q][m] = zero;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { db3[j] = 0.0f; gls[j] = 0.0f; }
+
+    for (long tile = long(blockIdx.x) * nw + wave; tile < n_tiles; tile += long(gridDim.x) * nw) {
+        // ================= forward =================
+        long s0 = tile * 64 + col, s1 = s0 + 32;
+        s0 = s0 < B ? s0 : B - 1; s1 = s1 < B ? s1 : B - 1;
+        const float *x0 = a.obs + s0 * obs_dim, *x1 = a.obs + s1 * obs_dim;
+        f32x16 h1[HT][2], h2[HT][2];
+#pragma unroll
+        for (int m = 0; m < HT; ++m) { h1[m][0] = zero; h1[m][1] = zero; }
+        const float *w1 = lds + L.o_l1 + lane;
+        for (int s = 0; s < L.k1s; ++s) {
+            const int k = 2 * s + half;
+            const float b0 = k < obs_dim ? x0[k] : (k == obs_dim ? 1.0f : 0.0f);
+            const float b1 = k < obs_dim ? x1[k] : (k == obs_dim ? 1.0f : 0.0f);
+#pragma unroll
+            for (int m = 0; m < HT; ++m) {
+                const float w = w1[((mrow + m) * L.k1s + s) * 64];
+                h1[m][0] = mfma(w, b0, h1[m][0]);
+                h1[m][1] = mfma(w, b1, h1[m][1]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < HT; ++m) { tanh_tile(h1[m][0]); tanh_tile(h1[m][1]); }
+#pragma unroll
+        for (int o = 0; o < HT; ++o) {
+            h2[o][0] = zero; h2[o][1] = zero;
+            const float *w = lds + L.o_l2[NET] + o * (HT * 16 * 64) + lane;
+#pragma unroll
+            for (int m = 0; m < HT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float ww = w[(m * 16 + r) * 64];
+                    h2[o][0] = mfma(ww, h1[m][0][r], h2[o][0]);
+                    h2[o][1] = mfma(ww, h1[m][1][r], h2[o][1]);
+                }
+            const float b = lds[L.o_b2[NET] + o * 64 + lane];
+            h2[o][0] = mfma(b, onehot, h2[o][0]);
+            h2[o][1] = mfma(b, onehot, h2[o][1]);
+            tanh_tile(h2[o][0]); tanh_tile(h2[o][1]);
+        }
+        float out[NJ];                                      // this lane's sample: output row j
+#pragma unroll
+        for (int q = 0; q < OT; ++q) {
+            f32x16 y0 = zero, y1 = zero;
+            const float *w = lds + L.o_l3[NET] + q * (HT * 16 * 64) + lane;
+#pragma unroll
+            for (int m = 0; m < HT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float ww = w[(m * 16 + r) * 64];
+                    y0 = mfma(ww, h2[m][0][r], y0);
+                    y1 = mfma(ww, h2[m][1][r], y1);
+                }
+            const float b = lds[L.o_b3[NET] + q * 64 + lane];
+            y0 = mfma(b, onehot, y0);
+            y1 = mfma(b, onehot, y1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {                  // one sample per lane: rows 32 q + U(r) and + 4
+                float lo = y0[r], hi = y1[r];
+                half_swap(lo, hi);
+                if (32 * q + unit_of(r) < NJ) out[32 * q + unit_of(r)] = lo;
+                if (32 * q + unit_of(r) + 4 < NJ) out[32 * q + unit_of(r) + 4] = hi;
+            }
+        }
+        // ================= loss derivative of this lane's sample =================
+        const long i = tile * 64 + lane;
+        const bool live = i < B;
+        const long ii = live ? i : B - 1;
+        float d3[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) d3[j] = 0.0f;
+        if (NET == 0) {
+            float lp = -0.91893853320467274f * float(act_dim);
+            float z[NJ], iv[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                z[j] = 0.0f; iv[j] = 0.0f;
+                if (j < act_dim) {
+                    const float ls = lds[L.o_logstd + j];
+                    iv[j] = __expf(-2.0f * ls);
+                    z[j] = a.act[ii * act_dim + j] - out[j];
+                    lp -= 0.5f * z[j] * z[j] * iv[j] + ls;
+                }
+            }
+            const float A = a.adv[ii], ratio = __expf(lp - a.logp_old[ii]);
+            const float rc = __builtin_amdgcn_fmed3f(ratio, 1.0f - a.cliprange, 1.0f + a.cliprange);
+            const float t1 = -A * ratio, t2 = -A * rc;
+            const float g = live ? (t1 >= t2 ? -A : 0.0f) * ratio * a.inv_B : 0.0f;      // dL / dlogp
+            if (live) loss_sum += fmaxf(t1, t2) * a.inv_B;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (j < act_dim) {
+                    d3[j] = g * z[j] * iv[j];
+                    gls[j] += g * (z[j] * z[j] * iv[j] - 1.0f);
+                }
+        } else {
+            const float v = out[0], vo = a.val_old[ii], R = a.ret[ii];
+            const float dv = v - vo, vc = vo + __builtin_amdgcn_fmed3f(dv, -a.cliprange, a.cliprange);
+            const float e1 = (v - R) * (v - R), e2 = (vc - R) * (vc - R);
+            const float dvl = e1 >= e2 ? (v - R) : (fabsf(dv) < a.cliprange ? (vc - R) : 0.0f);
+            d3[0] = live ? a.vf_coef * a.inv_B * dvl : 0.0f;
+            if (live) loss_sum += 0.5f * fmaxf(e1, e2) * a.inv_B;
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) db3[j] += d3[j];
+        // delta3 staged [sample][row] for the transposed (row-on-lane) reads of dW3
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (j < n_out) S3[lane * S3S + j] = d3[j];
+        // ================= delta2 = (W3^T delta3) (1 - h2^2) =================
+        f32x16 d2[HT][2];
+#pragma unroll
+        for (int m = 0; m < HT; ++m) { d2[m][0] = zero; d2[m][1] = zero; }
+#pragma unroll
+        for (int s = 0; s < NJ / 2; ++s)
+            if (s < k3s) {                                   // K pair = outputs (2 s, 2 s + 1)
+                float b0 = d3[2 * s], b1 = d3[2 * s + 1];
+                half_swap(b0, b1);                           // b0: column tile 0, b1: column tile 1
+#pragma unroll
+                for (int m = 0; m < HT; ++m) {
+                    const float w = lds[L.o_l3t[NET] + (m * k3s + s) * 64 + lane];
+                    d2[m][0] = mfma(w, b0, d2[m][0]);
+                    d2[m][1] = mfma(w, b1, d2[m][1]);
+                }
+            }
+#pragma unroll
+        for (int m = 0; m < HT; ++m)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d2[m][t][r] *= 1.0f - h2[m][t][r] * h2[m][t][r];
+        wave_fence();                                        // S3 written above is read below
+        // ================= dW3 += delta3 h2^T, per column tile =================
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x16 h2T[HT];
+#pragma unroll
+            for (int m = 0; m < HT; ++m) h2T[m] = transpose_tile(h2[m][t], T, col, half);
+#pragma unroll
+            for (int q = 0; q < OT; ++q) {
+                const int j = 32 * q + col;                  // row on this lane
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d3t = j < n_out ? S3[(32 * t + unit_of(r) + 4 * half) * S3S + j] : 0.0f;
+#pragma unroll
+                    for (int m = 0; m < HT; ++m) G3[q][m] = mfma(d3t, h2T[m][r], G3[q][m]);
+                }
+            }
+        }
+        // ================= delta1 = (W2^T delta2) (1 - h1^2) =================
+        f32x16 d1[HT][2];
+#pragma unroll
+        for (int ip = 0; ip < HT; ++ip) {
+            d1[ip][0] = zero; d1[ip][1] = zero;
+            const float *w = lds + L.o_l2t[NET] + ip * (HT * 16 * 64) + lane;
+#pragma unroll
+            for (int o = 0; o < HT; ++o)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float ww = w[(o * 16 + r) * 64];
+                    d1[ip][0] = mfma(ww, d2[o][0][r], d1[ip][0]);
+                    d1[ip][1] = mfma(ww, d2[o][1][r], d1[ip][1]);
+                }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d1[ip][t][r] *= 1.0f - h1[ip][t][r] * h1[ip][t][r];
+        }
+        // ================= dW2 += delta2 h1^T, db2, dW1 += delta1 [obs | 1]^T =================
+#pragma unroll
+        for (int o = 0; o < HT; ++o) db2[o] += d2[o][0] + d2[o][1];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x16 h1T[HT], dT[HT];
+#pragma unroll
+            for (int m = 0; m < HT; ++m) { h1T[m] = transpose_tile(h1[m][t], T, col, half); dT[m] = transpose_tile(d2[m][t], T, col, half); }
+#pragma unroll
+            for (int o = 0; o < HT; ++o)
+#pragma unroll
+                for (int m = 0; m < HT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) G2[o][m] = mfma(dT[o][r], h1T[m][r], G2[o][m]);
+#pragma unroll
+            for (int m = 0; m < HT; ++m) dT[m] = transpose_tile(d1[m][t], T, col, half);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                long sn = tile * 64 + 32 * t + unit_of(r) + 4 * half;          // sample of this K slot
+                sn = sn < B ? sn : B - 1;
+#pragma unroll
+                for (int kx = 0; kx < KX; ++kx) {
+                    const int k = 32 * kx + col;
+                    const float xv = k < obs_dim ? a.obs[sn * obs_dim + k] : (k == obs_dim ? 1.0f : 0.0f);
+#pragma unroll
+                    for (int o = 0; o < HT; ++o) G1[o][kx] = mfma(dT[o][r], xv, G1[o][kx]);
+                }
+            }
+        }
+    }
+    // ================= this wave's partial gradient, torch parameter order =================
+    const GOff g = goff_of(obs_dim, n_out);
+    float *P = a.partials + (long(blockIdx.x) * nw + wave) * a.gstride;
+    for (int k = lane; k < a.gstride; k += 64) P[k] = 0.0f;
+    wave_fence();
+    __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+    for (int o = 0; o < HT; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * o + unit_of(r) + 4 * half;              // out unit
+#pragma unroll
+            for (int m = 0; m < HT; ++m) P[g.w2 + row * H + 32 * m + col] = G2[o][m][r];
+#pragma unroll
+            for (int kx = 0; kx < KX; ++kx) {
+                const int k = 32 * kx + col;
+                if (k < obs_dim) P[g.w1 + row * obs_dim + k] = G1[o][kx][r];
+                else if (k == obs_dim) P[g.b1 + row] = G1[o][kx][r];
+            }
+            // bias 2: sum of this register over the 32 lanes of the half-wave (all hold different samples)
+            float v = db2[o][r];
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (col == 0) P[g.b2 + row] = v;
+        }
+#pragma unroll
+    for (int q = 0; q < OT; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * q + unit_of(r) + 4 * half;              // output
+            if (row < n_out) {
+#pragma unroll
+                for (int m = 0; m < HT; ++m) P[g.w3 + row * H + 32 * m + col] = G3[q][m][r];
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        if (j < n_out) {
+            float v = db3[j], w = gls[j];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); w += __shfl_xor(w, off, 64); }
+            if (lane == 0) { P[g.b3 + j] = v; P[g.ls + j] = NET == 0 ? w : 0.0f; }
+        }
+    float ls = loss_sum;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ls += __shfl_xor(ls, off, 64);
+    if (lane == 0) P[g.loss] = ls;
+}
+
+// out[k] = sum over the waves' partials
+__global__ void reduce_partials_kernel(const float *__restrict__ partials, int n_waves, int gstride, int n, float *__restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int w = 0;
+    for (; w + 3 < n_waves; w += 4) {
+        s0 += partials[long(w) * gstride + k]; s1 += partials[long(w + 1) * gstride + k];
+        s2 += partials[long(w + 2) * gstride + k]; s3 += partials[long(w + 3) * gstride + k];
+    }
+    for (; w < n_waves; ++w) s0 += partials[long(w) * gstride + k];
+    out[k] = (s0 + s1) + (s2 + s3);
+}
+
+constexpr int WAVES_PER_BLOCK = 4;
+int n_cus() {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n;
+}
+long grad_blocks(long B) {
+    const long tiles = (B + 63) / 64;
+    long blocks = (tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    const long cap = n_cus();
+    return blocks < cap ? blocks : cap;
+}
+
+template <int NET, int KX, int NJ>
+int launch_grad(const TrainArgs &a, long blocks, size_t lds, hipStream_t stream) {
+    static size_t allowed = 64 * 1024;
+    if (lds > allowed) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_grad_kernel<NET, KX, NJ>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return fail(RP_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        allowed = lds;
+    }
+    hipLaunchKernelGGL((mlp_grad_kernel<NET, KX, NJ>), dim3(unsigned(blocks)), dim3(64 * WAVES_PER_BLOCK), lds, stream, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RP_EHIP, std::string("mlp_grad_kernel: ") + hipGetErrorString(e));
+    return RP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t rp_train_packed_floats(int obs_dim, int act_dim) {
+    if (rp_packed_floats(obs_dim, act_dim) < 0) return RP_EUNSUPPORTED;
+    if (obs_dim + 1 > 64) return fail(RP_EUNSUPPORTED, "the gradient kernel supports obs_dim <= 63");
+    return layout_of(obs_dim, act_dim).total_train;
+}
+
+int rp_pack_train(const rp_mlp_params *p, int obs_dim, int act_dim, float *out) {
+    if (rp_train_packed_floats(obs_dim, act_dim) < 0) return RP_EUNSUPPORTED;
+    const int rc = rp_pack(p, obs_dim, act_dim, out);
+    if (rc) return rc;
+    const Layout L = layout_of(obs_dim, act_dim);
+    std::memset(out + L.total, 0, sizeof(float) * size_t(L.total_train - L.total));
+    const float *w2[2] = {p->pi_w2, p->vf_w2}, *w3[2] = {p->pi_w3, p->vf_w3};
+    for (int net = 0; net < 2; ++net) {
+        const int n_out = net == 0 ? act_dim : 1;
+        for (int m = 0; m < HT; ++m)
+            for (int s = 0; s < L.k3s[net]; ++s)
+                for (int l = 0; l < 64; ++l) {
+                    const int unit = 32 * m + (l & 31), j = 2 * s + (l >> 5);
+                    out[L.o_l3t[net] + (m * L.k3s[net] + s) * 64 + l] = j < n_out ? w3[net][j * H + unit] : 0.0f;
+                }
+        for (int ip = 0; ip < HT; ++ip)
+            for (int o = 0; o < HT; ++o)
+                for (int r = 0; r < 16; ++r)
+                    for (int l = 0; l < 64; ++l) {
+                        const int in = 32 * ip + (l & 31), outu = 32 * o + unit_of(r) + 4 * (l >> 5);
+                        out[L.o_l2t[net] + ((ip * HT + o) * 16 + r) * 64 + l] = w2[net][outu * H + in];
+                    }
+    }
+    return RP_OK;
+}
+
+int64_t rp_grad_floats(int obs_dim, int act_dim) {
+    if (rp_train_packed_floats(obs_dim, act_dim) < 0) return RP_EUNSUPPORTED;
+    return 2 * int64_t(gstride_of(obs_dim, act_dim));
+}
+
+int64_t rp_ppo_workspace_floats(int obs_dim, int act_dim, int64_t batch) {
+    if (rp_train_packed_floats(obs_dim, act_dim) < 0 || batch < 1) return RP_EUNSUPPORTED;
+    return 2 * grad_blocks(batch) * WAVES_PER_BLOCK * int64_t(gstride_of(obs_dim, act_dim));
+}
+
+int rp_ppo_grad_dev(const float *d_packed_train, const float *d_obs, const float *d_act, const float *d_adv,
+                    const float *d_logp_old, const float *d_val_old, const float *d_ret, int64_t batch, int obs_dim,
+                    int act_dim, float cliprange, float vf_coef, float *d_grad, float *d_workspace, void *stream) {
+    if (!d_packed_train || !d_obs || !d_act || !d_adv || !d_logp_old || !d_val_old || !d_ret || !d_grad || !d_workspace)
+        return fail(RP_EINVAL, "null argument");
+    if (batch < 1) return fail(RP_EINVAL, "batch must be >= 1");
+    if (rp_train_packed_floats(obs_dim, act_dim) < 0) return RP_EUNSUPPORTED;
+    const Layout L = layout_of(obs_dim, act_dim);
+    const int gs = gstride_of(obs_dim, act_dim);
+    const long blocks = grad_blocks(batch), waves = blocks * WAVES_PER_BLOCK;
+    auto lds_of = [&](int net, int nj) {                      // the staged blocks of one net + per-wave scratch
+        const int ot = net == 0 ? L.ot_pi : 1;
+        const size_t w = size_t(HT) * L.k1s * 64 + 2 * size_t(HT * HT * 16 * 64) + HT * 64 + size_t(ot) * (HT * 16 * 64 + 64) + 64 +
+                         size_t(HT) * L.k3s[net] * 64;
+        return sizeof(float) * (w + WAVES_PER_BLOCK * (32 * 33 + 64 * (nj + 1)));
+    };
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    TrainArgs a;
+    a.packed = d_packed_train; a.obs = d_obs; a.act = d_act; a.adv = d_adv; a.logp_old = d_logp_old; a.val_old = d_val_old;
+    a.ret = d_ret; a.B = batch; a.obs_dim = obs_dim; a.act_dim = act_dim; a.gstride = gs; a.cliprange = cliprange;
+    a.vf_coef = vf_coef; a.inv_B = 1.0f / float(batch);
+    const int kx = (obs_dim + 1 + 31) / 32;
+    int rc;
+    a.partials = d_workspace;
+    // instances: the reference's robot class (obs <= 31, up to 8 actions) and the general one (obs <= 63, 64 actions)
+    const bool small = kx == 1 && act_dim <= 8;
+    if (lds_of(0, small ? 8 : 64) > 160 * 1024) return fail(RP_EUNSUPPORTED, "policy too large for the LDS-resident form");
+    if (small) rc = launch_grad<0, 1, 8>(a, blocks, lds_of(0, 8), st);
+    else rc = launch_grad<0, 2, 64>(a, blocks, lds_of(0, 64), st);
+    if (rc) return rc;
+    a.partials = d_workspace + waves * gs;
+    if (kx == 1) rc = launch_grad<1, 1, 8>(a, blocks, lds_of(1, 8), st);
+    else rc = launch_grad<1, 2, 8>(a, blocks, lds_of(1, 8), st);
+    if (rc) return rc;
+    for (int net = 0; net < 2; ++net) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((gs + 255) / 256), dim3(256), 0, st, d_workspace + net * waves * gs,
+                           int(waves), gs, gs, d_grad + net * gs);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RP_EHIP, std::string("reduce_partials_kernel: ") + hipGetErrorString(e));
+    return RP_OK;
+}
+
+}  // extern "C"

@@ -116,6 +116,58 @@ class FusedPolicyStep:
         return packed
 
 
+class FusedPolicyGrad:
+    """The PPO minibatch gradient of an ``MlpPolicy`` as MFMA kernels (include/roboy_policy.h: rp_ppo_grad_dev,
+    csrc/mlp_train.hip): forward, clipped-surrogate / clipped-value loss derivative, back-propagation and the weight
+    gradients of both networks without materialising an activation in memory.  ``run()`` fills ``p.grad`` of every
+    parameter (views of one flat buffer) and returns the two loss terms; optimiser, gradient clipping and the
+    cross-rank average stay torch's."""
+
+    def __init__(self, policy):
+        import ctypes
+        from . import _policy_native as pn
+        self._pn, self._ct, self._lib = pn, ctypes, pn.load()
+        self.policy = policy
+        self.obs_dim, self.act_dim = policy.pi[0].in_features, policy.pi[-1].out_features
+        dev = policy.log_std.device
+        m, _ = pn.gather_map(self.obs_dim, self.act_dim, train=True)
+        self._map = torch.from_numpy(m).to(dev)
+        self._zero = torch.zeros(1, device=dev)
+        layout, n = pn.grad_layout(self.obs_dim, self.act_dim)
+        self._g = torch.zeros(n, device=dev)
+        self._layout = layout
+        pi, vf = policy.pi, policy.vf
+        self._named = {"pi_w1": pi[0].weight, "pi_b1": pi[0].bias, "pi_w2": pi[2].weight, "pi_b2": pi[2].bias,
+                       "pi_w3": pi[4].weight, "pi_b3": pi[4].bias, "vf_w1": vf[0].weight, "vf_b1": vf[0].bias,
+                       "vf_w2": vf[2].weight, "vf_b2": vf[2].bias, "vf_w3": vf[4].weight, "vf_b3": vf[4].bias,
+                       "log_std": policy.log_std}
+        self._views = {}
+        for name, p in self._named.items():
+            off, shape = layout[name]
+            self._views[name] = self._g[off:off + p.numel()].view(shape)
+        self._ws = None
+
+    @torch.no_grad()
+    def run(self, obs, act, adv, logp_old, val_old, ret, cliprange, vf_coef, ent_coef):
+        c, B = self._ct, int(obs.shape[0])
+        flat = torch.cat([self._named[k].detach().reshape(-1) for k in self._pn.PARAM_ORDER] + [self._zero])
+        packed = flat[self._map]
+        need = int(self._lib.rp_ppo_workspace_floats(self.obs_dim, self.act_dim, B))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, device=obs.device)
+        ptr = lambda t: c.c_void_p(t.data_ptr())
+        self._pn.check(self._lib.rp_ppo_grad_dev(
+            ptr(packed), ptr(obs), ptr(act), ptr(adv), ptr(logp_old), ptr(val_old), ptr(ret), B, self.obs_dim, self.act_dim,
+            float(cliprange), float(vf_coef), ptr(self._g), ptr(self._ws),
+            c.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)))
+        self._views["log_std"] -= ent_coef            # entropy bonus of a state-independent log-std
+        for name, p in self._named.items():
+            p.grad = self._views[name]
+        pg = self._g[self._layout["pi_loss"][0]]
+        vf = self._g[self._layout["vf_loss"][0]]
+        return pg, vf
+
+
 def average_gradients(module, dist=None):
     if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return
@@ -134,7 +186,8 @@ def average_gradients(module, dist=None):
 class PPO:
     def __init__(self, env, policy=None, n_steps=128, nminibatches=4, noptepochs=4, gamma=0.99, lam=0.95,
                  learning_rate=2.5e-4, cliprange=0.2, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5,
-                 device="cuda", dist=None, reward_scale=1.0, seed=0, use_graphs=False, fused_policy=False):
+                 device="cuda", dist=None, reward_scale=1.0, seed=0, use_graphs=False, fused_policy=False,
+                 fused_update=False):
         self.env, self.dist, self.device = env, dist, torch.device(device)
         torch.manual_seed(seed)
         obs_dim = env.observation_space.shape[0]
@@ -158,6 +211,12 @@ class PPO:
             rank = dist.get_rank() if multi_rank else 0
             self._fused = FusedPolicyStep(self.policy, seed=seed + 7919 * rank)
             self._step_base = torch.zeros(1, dtype=torch.int32, device=self.device)    # rollout steps taken so far
+        # fused_update: the minibatch gradient comes from the MFMA kernels (FusedPolicyGrad) instead of torch autograd
+        self._fgrad = None
+        if fused_update:
+            if self.device.type != "cuda":
+                raise ValueError("fused_update needs a GPU")
+            self._fgrad = FusedPolicyGrad(self.policy)
         self.n_steps, self.nminibatches, self.noptepochs = n_steps, nminibatches, noptepochs
         self.gamma, self.lam, self.cliprange = gamma, lam, cliprange
         self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
@@ -282,7 +341,21 @@ class PPO:
         ent = d.entropy().sum(-1).mean()
         return pg - self.ent_coef * ent + self.vf_coef * vf, pg, vf, ent
 
+    def _minibatch_step_fused(self, flat, idx):
+        adv = flat["adv"][idx]
+        adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).contiguous()
+        pg, vf = self._fgrad.run(flat["obs"][idx].contiguous(), flat["act"][idx].contiguous(), adv, flat["logp"][idx].contiguous(),
+                                 flat["val"][idx].contiguous(), flat["ret"][idx].contiguous(), self.cliprange, self.vf_coef,
+                                 self.ent_coef)
+        ent = (0.5 + 0.5 * math.log(2 * math.pi) + self.policy.log_std.detach()).sum()
+        average_gradients(self.policy, self.dist)
+        nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+        self.opt.step()
+        return pg - self.ent_coef * ent + self.vf_coef * vf, pg, vf, ent
+
     def _minibatch_step(self, flat, idx):
+        if self._fgrad is not None:
+            return self._minibatch_step_fused(flat, idx)
         loss, pg, vf, ent = self._minibatch_loss(flat, idx)
         self.opt.zero_grad(set_to_none=True)
         loss.backward()

@@ -55,6 +55,29 @@ int rp_act_dev(const float *d_packed, const float *d_obs, float *d_act, float *d
                int64_t n, int obs_dim, int act_dim, uint64_t seed, uint64_t sample_offset, uint32_t step,
                const uint32_t *d_step_base, int deterministic, void *stream);
 
+/* ---- the PPO minibatch gradient (gym_roboy_amd/ppo.py: _minibatch_loss is the torch statement) ----
+ * Loss = mean_i max(-A_i r_i, -A_i clip(r_i, 1 -+ c)) + vf_coef * mean_i 1/2 max((v_i - R_i)^2, (vclip_i - R_i)^2),
+ * r_i = exp(logp(act_i | obs_i) - logp_old_i), vclip_i = v_old_i + clip(v_i - v_old_i, -+c); A_i is the caller's
+ * (already normalised) advantage.  The entropy bonus of a state-independent log-std has the constant gradient
+ * -ent_coef per log-std component and is left to the caller. */
+
+/* floats of the blob rp_pack_train() writes: the rp_pack() blob followed by the transposed weights */
+int64_t rp_train_packed_floats(int obs_dim, int act_dim);
+int rp_pack_train(const rp_mlp_params *host_params, int obs_dim, int act_dim, float *packed_host);
+
+/* The gradient vector d_grad: two blocks of rp_grad_floats() / 2 floats, action net then value net, each in torch
+ * layout  [w1 (64 x obs), b1 (64), w2 (64 x 64), b2 (64), w3 (out x 64), b3 (out), log_std (out; zero for the value
+ * net), loss term, 3 spare]  padded to a multiple of 4 (out = act_dim / 1). */
+int64_t rp_grad_floats(int obs_dim, int act_dim);
+int64_t rp_ppo_workspace_floats(int obs_dim, int act_dim, int64_t batch);
+
+/* Device pointers: obs [batch][obs_dim], act [batch][act_dim], adv / logp_old / val_old / ret [batch]; d_grad
+ * rp_grad_floats() floats (overwritten), d_workspace rp_ppo_workspace_floats() floats.  Three launches on `stream`
+ * (one per net, one reduction); asynchronous. */
+int rp_ppo_grad_dev(const float *d_packed_train, const float *d_obs, const float *d_act, const float *d_adv,
+                    const float *d_logp_old, const float *d_val_old, const float *d_ret, int64_t batch, int obs_dim,
+                    int act_dim, float cliprange, float vf_coef, float *d_grad, float *d_workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

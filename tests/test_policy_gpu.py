@@ -105,3 +105,83 @@ def test_ppo_rollout_with_the_fused_policy_step_trains():
         lp2 = agent.policy.dist(roll2["obs"]).log_prob(roll2["act"]).sum(-1)
     assert (lp2 - roll2["logp"]).abs().max() < 1e-3
     env.close()
+
+
+# ---- the PPO minibatch gradient (csrc/mlp_train.hip) against torch autograd in float64 ----
+def _minibatch(policy64, obs_dim, act_dim, B, seed, cliprange):
+    """A minibatch in which every branch of the two clipped losses occurs: actions around the policy's mean, old
+    log-probabilities off by up to +-0.5 (ratios on both sides of the clip range), old values near and far."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.rand(B, obs_dim, generator=g, dtype=torch.float64) * 4 - 2
+    with torch.no_grad():
+        d = policy64.dist(obs)
+        act = d.mean + d.stddev * torch.randn(B, act_dim, generator=g, dtype=torch.float64)
+        logp = d.log_prob(act).sum(-1)
+        v = policy64.value(obs)
+    logp_old = logp + (torch.rand(B, generator=g, dtype=torch.float64) - 0.5)
+    adv = torch.randn(B, generator=g, dtype=torch.float64)
+    val_old = v + (torch.rand(B, generator=g, dtype=torch.float64) - 0.5) * 6 * cliprange
+    ret = v + torch.randn(B, generator=g, dtype=torch.float64)
+    return obs, act, adv, logp_old, val_old, ret
+
+
+def _torch_loss(policy, obs, act, adv, logp_old, val_old, ret, cliprange, vf_coef, ent_coef):
+    import torch
+    d = policy.dist(obs)
+    logp = d.log_prob(act).sum(-1)
+    ratio = (logp - logp_old).exp()
+    pg = torch.max(-adv * ratio, -adv * ratio.clamp(1 - cliprange, 1 + cliprange)).mean()
+    v = policy.value(obs)
+    v_clip = val_old + (v - val_old).clamp(-cliprange, cliprange)
+    vf = 0.5 * torch.max((v - ret) ** 2, (v_clip - ret) ** 2).mean()
+    ent = d.entropy().sum(-1).mean()
+    return pg - ent_coef * ent + vf_coef * vf, pg, vf
+
+
+@pytest.mark.parametrize("obs_dim,act_dim,B", [(9, 8, 1000), (9, 8, 64), (9, 8, 37), (9, 8, 20000), (60, 38, 777), (3, 1, 200), (30, 8, 129)])
+def test_ppo_minibatch_gradient_matches_torch_autograd(obs_dim, act_dim, B):
+    import torch
+    from gym_roboy_amd.ppo import FusedPolicyGrad
+    cliprange, vf_coef, ent_coef = 0.2, 0.5, 0.1
+    policy = _policy(obs_dim, act_dim, 11 + obs_dim)
+    ref = _policy(obs_dim, act_dim, 11 + obs_dim).double()
+    mb = _minibatch(ref, obs_dim, act_dim, B, B, cliprange)
+    loss, pg_ref, vf_ref = _torch_loss(ref, *mb, cliprange, vf_coef, ent_coef)
+    loss.backward()
+    policy = policy.cuda()
+    fg = FusedPolicyGrad(policy)
+    dev = [t.float().cuda().contiguous() for t in mb]
+    pg, vf = fg.run(*dev, cliprange, vf_coef, ent_coef)
+    torch.cuda.synchronize()
+    assert abs(pg.item() - pg_ref.item()) < 1e-4 * max(1.0, abs(pg_ref.item()))
+    assert abs(vf.item() - vf_ref.item()) < 1e-4 * max(1.0, abs(vf_ref.item()))
+    worst = 0.0
+    for (name, p), (_, q) in zip(policy.named_parameters(), ref.named_parameters()):
+        got, want = p.grad.detach().cpu().double(), q.grad
+        scale = max(want.abs().max().item(), 1e-6)
+        err = (got - want).abs().max().item() / scale
+        worst = max(worst, err)
+        assert err < 5e-4, (name, err, scale)
+    assert worst < 5e-4
+
+
+def test_ppo_with_fused_rollout_and_fused_update_learns_like_the_torch_path():
+    """Same seed, same env: PPO(fused_policy, fused_update) and the all-torch PPO see different noise streams, so they
+    are compared statistically - both must improve the mean reward on the toy horizon - and the fused update must
+    reproduce torch's update when both are fed the SAME rollout."""
+    import copy
+    import torch
+    from gym_roboy_amd.envs.robots import MsjRobot
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    from gym_roboy_amd.ppo import PPO
+    env = RoboyVecEnv(MsjRobot(), 512, seed=1)
+    a = PPO(env, n_steps=16, seed=4, reward_scale=0.01, fused_update=True)
+    b = PPO(env, n_steps=16, seed=4, reward_scale=0.01)
+    b.policy.load_state_dict(copy.deepcopy(a.policy.state_dict()))
+    roll = a.collect()
+    torch.manual_seed(9); a.update({k: v.clone() for k, v in roll.items()})
+    torch.manual_seed(9); b.update({k: v.clone() for k, v in roll.items()})       # same minibatch permutations
+    for (n, p), (_, q) in zip(a.policy.named_parameters(), b.policy.named_parameters()):
+        assert (p - q).abs().max().item() < 2e-4, n            # 16 Adam steps apart by rounding only
+    env.close()

@@ -37,15 +37,17 @@ for n in [int(a) for a in sys.argv[1:]] or [4096, 65536, 262144, 2097152]:
           % (n, t_f, flops * n / t_f / 1e6, t_p, t_t), flush=True)
 
 for n in (65536, 262144):
-    for fused_policy in (False, True):
+    for fused in (False, True):
         env = RoboyVecEnv(MsjRobot(), n)
-        agent = PPO(env, ent_coef=0.1, device="cuda", reward_scale=0.01, use_graphs=True, fused_policy=fused_policy)
-        roll = agent.collect(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            roll = agent.collect()
-        torch.cuda.synchronize()
-        tc = (time.perf_counter() - t0) / 5
-        print("PPO rollout, N=%d, graphs, %s: %.1f ms per 128-step rollout = %.1f us per vectorised step"
-              % (n, "fused policy step" if fused_policy else "torch policy step", tc * 1e3, tc / agent.n_steps * 1e6), flush=True)
+        agent = PPO(env, ent_coef=0.1, device="cuda", reward_scale=0.01, use_graphs=True, fused_policy=fused, fused_update=fused)
+        roll = agent.collect(); agent.update(roll); torch.cuda.synchronize()
+        tc = tu = 0.0
+        iters = 3
+        for _ in range(iters):
+            t0 = time.perf_counter(); roll = agent.collect(); torch.cuda.synchronize(); t1 = time.perf_counter()
+            agent.update(roll); torch.cuda.synchronize(); t2 = time.perf_counter()
+            tc += t1 - t0; tu += t2 - t1
+        print("PPO iteration, N=%d, graphs, %s: rollout %.1f ms (%.1f us per vectorised step), update %.1f ms; %.3g timesteps/s end to end"
+              % (n, "fused policy step + fused gradient" if fused else "torch policy + autograd", tc / iters * 1e3,
+                 tc / iters / agent.n_steps * 1e6, tu / iters * 1e3, iters * agent.n_steps * n / (tc + tu)), flush=True)
         env.close()
