@@ -25,7 +25,7 @@ SIGNATURES = {
     "rp_pack_train": (ctypes.c_int, [ctypes.POINTER(MlpParams), ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "rp_grad_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),
     "rp_ppo_workspace_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
-    "rp_ppo_grad_dev": (ctypes.c_int, [ctypes.c_void_p] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+    "rp_ppo_grad_dev": (ctypes.c_int, [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                        ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rp_act_dev": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
                                   ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),

@@ -45,6 +45,7 @@ __device__ __forceinline__ f32x16 transpose_tile(const f32x16 &d, float *T, int 
 struct TrainArgs {
     const float *packed;                                  // rp_pack_train blob
     const float *obs, *act, *adv, *logp_old, *val_old, *ret;
+    const long long *index;                               // row of sample i in obs / act / logp_old / val_old / ret (NULL: i); adv is direct
     float *partials;                                      // [waves][gstride]
     long B;
     int obs_dim, act_dim, gstride;
@@ -135,6 +136,7 @@ mlp_grad_kernel(const TrainArgs a) {
         // ================= forward =================
         long s0 = tile * 64 + col, s1 = s0 + 32;
         s0 = s0 < B ? s0 : B - 1; s1 = s1 < B ? s1 : B - 1;
+        if (a.index) { s0 = a.index[s0]; s1 = a.index[s1]; }
         const float *x0 = a.obs + s0 * obs_dim, *x1 = a.obs + s1 * obs_dim;
         f32x16 h1[HT][2], h2[HT][2];
 #pragma unroll
@@ -197,7 +199,8 @@ mlp_grad_kernel(const TrainArgs a) {
         // ================= loss derivative of this lane's sample =================
         const long i = tile * 64 + lane;
         const bool live = i < B;
-        const long ii = live ? i : B - 1;
+        const long im = live ? i : B - 1;                    // position in the minibatch
+        const long ii = a.index ? long(a.index[im]) : im;     // row in the rollout tensors
         float d3[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) d3[j] = 0.0f;
@@ -214,7 +217,7 @@ mlp_grad_kernel(const TrainArgs a) {
                     lp -= 0.5f * z[j] * z[j] * iv[j] + ls;
                 }
             }
-            const float A = a.adv[ii], ratio = __expf(lp - a.logp_old[ii]);
+            const float A = a.adv[im], ratio = __expf(lp - a.logp_old[ii]);
             const float rc = __builtin_amdgcn_fmed3f(ratio, 1.0f - a.cliprange, 1.0f + a.cliprange);
             const float t1 = -A * ratio, t2 = -A * rc;
             const float g = live ? (t1 >= t2 ? -A : 0.0f) * ratio * a.inv_B : 0.0f;      // dL / dlogp
@@ -318,6 +321,7 @@ mlp_grad_kernel(const TrainArgs a) {
             for (int r = 0; r < 16; ++r) {
                 long sn = tile * 64 + 32 * t + unit_of(r) + 4 * half;          // sample of this K slot
                 sn = sn < B ? sn : B - 1;
+                if (a.index) sn = a.index[sn];
 #pragma unroll
                 for (int kx = 0; kx < KX; ++kx) {
                     const int k = 32 * kx + col;
@@ -466,8 +470,9 @@ int64_t rp_ppo_workspace_floats(int obs_dim, int act_dim, int64_t batch) {
 }
 
 int rp_ppo_grad_dev(const float *d_packed_train, const float *d_obs, const float *d_act, const float *d_adv,
-                    const float *d_logp_old, const float *d_val_old, const float *d_ret, int64_t batch, int obs_dim,
-                    int act_dim, float cliprange, float vf_coef, float *d_grad, float *d_workspace, void *stream) {
+                    const float *d_logp_old, const float *d_val_old, const float *d_ret, const int64_t *d_index,
+                    int64_t batch, int obs_dim, int act_dim, float cliprange, float vf_coef, float *d_grad,
+                    float *d_workspace, void *stream) {
     if (!d_packed_train || !d_obs || !d_act || !d_adv || !d_logp_old || !d_val_old || !d_ret || !d_grad || !d_workspace)
         return fail(RP_EINVAL, "null argument");
     if (batch < 1) return fail(RP_EINVAL, "batch must be >= 1");
@@ -484,11 +489,12 @@ int rp_ppo_grad_dev(const float *d_packed_train, const float *d_obs, const float
     hipStream_t st = static_cast<hipStream_t>(stream);
     TrainArgs a;
     a.packed = d_packed_train; a.obs = d_obs; a.act = d_act; a.adv = d_adv; a.logp_old = d_logp_old; a.val_old = d_val_old;
-    a.ret = d_ret; a.B = batch; a.obs_dim = obs_dim; a.act_dim = act_dim; a.gstride = gs; a.cliprange = cliprange;
+    a.ret = d_ret; a.index = reinterpret_cast<const long long *>(d_index); a.B = batch; a.obs_dim = obs_dim; a.act_dim = act_dim; a.gstride = gs; a.cliprange = cliprange;
     a.vf_coef = vf_coef; a.inv_B = 1.0f / float(batch);
     const int kx = (obs_dim + 1 + 31) / 32;
     int rc;
     a.partials = d_workspace;
+    // instances: the reference's robot class (obs <= 31, up to 8 actions) and the general one (obs <= 63, 64 actions)
     // instances: the reference's robot class (obs <= 31, up to 8 actions) and the general one (obs <= 63, 64 actions)
     const bool small = kx == 1 && act_dim <= 8;
     if (lds_of(0, small ? 8 : 64) > 160 * 1024) return fail(RP_EUNSUPPORTED, "policy too large for the LDS-resident form");
@@ -496,7 +502,7 @@ int rp_ppo_grad_dev(const float *d_packed_train, const float *d_obs, const float
     else rc = launch_grad<0, 2, 64>(a, blocks, lds_of(0, 64), st);
     if (rc) return rc;
     a.partials = d_workspace + waves * gs;
-    if (kx == 1) rc = launch_grad<1, 1, 8>(a, blocks, lds_of(1, 8), st);
+    if (small) rc = launch_grad<1, 1, 8>(a, blocks, lds_of(1, 8), st);
     else rc = launch_grad<1, 2, 8>(a, blocks, lds_of(1, 8), st);
     if (rc) return rc;
     for (int net = 0; net < 2; ++net) {

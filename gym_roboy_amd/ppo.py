@@ -148,16 +148,18 @@ class FusedPolicyGrad:
         self._ws = None
 
     @torch.no_grad()
-    def run(self, obs, act, adv, logp_old, val_old, ret, cliprange, vf_coef, ent_coef):
-        c, B = self._ct, int(obs.shape[0])
+    def run(self, obs, act, adv, logp_old, val_old, ret, cliprange, vf_coef, ent_coef, index=None):
+        """index (int64 [B], optional): minibatch sample i is row index[i] of obs / act / logp_old / val_old / ret
+        (the whole rollout's tensors, no gathered copies); adv is always in minibatch order."""
+        c, B = self._ct, int(adv.shape[0])
         flat = torch.cat([self._named[k].detach().reshape(-1) for k in self._pn.PARAM_ORDER] + [self._zero])
         packed = flat[self._map]
         need = int(self._lib.rp_ppo_workspace_floats(self.obs_dim, self.act_dim, B))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, device=obs.device)
-        ptr = lambda t: c.c_void_p(t.data_ptr())
+        ptr = lambda t: c.c_void_p(t.data_ptr()) if t is not None else None
         self._pn.check(self._lib.rp_ppo_grad_dev(
-            ptr(packed), ptr(obs), ptr(act), ptr(adv), ptr(logp_old), ptr(val_old), ptr(ret), B, self.obs_dim, self.act_dim,
+            ptr(packed), ptr(obs), ptr(act), ptr(adv), ptr(logp_old), ptr(val_old), ptr(ret), ptr(index), B, self.obs_dim, self.act_dim,
             float(cliprange), float(vf_coef), ptr(self._g), ptr(self._ws),
             c.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)))
         self._views["log_std"] -= ent_coef            # entropy bonus of a state-independent log-std
@@ -344,9 +346,9 @@ class PPO:
     def _minibatch_step_fused(self, flat, idx):
         adv = flat["adv"][idx]
         adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).contiguous()
-        pg, vf = self._fgrad.run(flat["obs"][idx].contiguous(), flat["act"][idx].contiguous(), adv, flat["logp"][idx].contiguous(),
-                                 flat["val"][idx].contiguous(), flat["ret"][idx].contiguous(), self.cliprange, self.vf_coef,
-                                 self.ent_coef)
+        # the rollout's own tensors + the minibatch's row indices: the kernels gather, nothing is copied
+        pg, vf = self._fgrad.run(flat["obs"], flat["act"], adv, flat["logp"], flat["val"], flat["ret"], self.cliprange,
+                                 self.vf_coef, self.ent_coef, index=idx.contiguous())
         ent = (0.5 + 0.5 * math.log(2 * math.pi) + self.policy.log_std.detach()).sum()
         average_gradients(self.policy, self.dist)
         nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
@@ -366,6 +368,8 @@ class PPO:
 
     def update(self, roll):
         flat = {k: v.reshape(-1, *v.shape[2:]) for k, v in roll.items()}
+        if self._fgrad is not None:          # the gradient kernels index the rollout tensors directly
+            flat = {k: v.contiguous() for k, v in flat.items()}
         n = flat["obs"].shape[0]
         mb = max(n // self.nminibatches, 1)
         out = None

@@ -71,12 +71,15 @@ int rp_pack_train(const rp_mlp_params *host_params, int obs_dim, int act_dim, fl
 int64_t rp_grad_floats(int obs_dim, int act_dim);
 int64_t rp_ppo_workspace_floats(int obs_dim, int act_dim, int64_t batch);
 
-/* Device pointers: obs [batch][obs_dim], act [batch][act_dim], adv / logp_old / val_old / ret [batch]; d_grad
- * rp_grad_floats() floats (overwritten), d_workspace rp_ppo_workspace_floats() floats.  Three launches on `stream`
- * (one per net, one reduction); asynchronous. */
+/* Device pointers.  d_index == NULL: obs [batch][obs_dim], act [batch][act_dim], adv / logp_old / val_old / ret
+ * [batch].  d_index != NULL (int64 [batch]): sample i of the minibatch is ROW d_index[i] of obs, act, logp_old,
+ * val_old, ret (the whole rollout's tensors - no gathered copies), while adv [batch] stays in minibatch order (it is
+ * normalised per minibatch by the caller).  d_grad: rp_grad_floats() floats (overwritten), d_workspace:
+ * rp_ppo_workspace_floats() floats.  Four launches on `stream` (one per net, two reductions); asynchronous. */
 int rp_ppo_grad_dev(const float *d_packed_train, const float *d_obs, const float *d_act, const float *d_adv,
-                    const float *d_logp_old, const float *d_val_old, const float *d_ret, int64_t batch, int obs_dim,
-                    int act_dim, float cliprange, float vf_coef, float *d_grad, float *d_workspace, void *stream);
+                    const float *d_logp_old, const float *d_val_old, const float *d_ret, const int64_t *d_index,
+                    int64_t batch, int obs_dim, int act_dim, float cliprange, float vf_coef, float *d_grad,
+                    float *d_workspace, void *stream);
 
 #ifdef __cplusplus
 }

@@ -164,6 +164,15 @@ def test_ppo_minibatch_gradient_matches_torch_autograd(obs_dim, act_dim, B):
         worst = max(worst, err)
         assert err < 5e-4, (name, err, scale)
     assert worst < 5e-4
+    # the same minibatch addressed through row indices into larger "rollout" tensors: bit-identical gradient
+    g_direct = fg._g.clone()
+    perm = torch.randperm(3 * B, device="cuda")[:B]
+    big = [torch.zeros(3 * B, *t.shape[1:], device="cuda") for t in dev]
+    for t_big, t in zip(big, dev):
+        t_big[perm] = t
+    fg.run(big[0], big[1], dev[2], big[3], big[4], big[5], cliprange, vf_coef, ent_coef, index=perm)
+    torch.cuda.synchronize()
+    assert torch.equal(fg._g, g_direct)
 
 
 def test_ppo_with_fused_rollout_and_fused_update_learns_like_the_torch_path():

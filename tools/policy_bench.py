@@ -36,6 +36,19 @@ for n in [int(a) for a in sys.argv[1:]] or [4096, 65536, 262144, 2097152]:
     print("n=%8d: fused kernel %8.1f us (%.1f useful TFLOP/s; weight gather %.1f us once per rollout), torch MlpPolicy.act %8.1f us (eager)"
           % (n, t_f, flops * n / t_f / 1e6, t_p, t_t), flush=True)
 
+from gym_roboy_amd.ppo import FusedPolicyGrad
+fg = FusedPolicyGrad(policy)
+for B in (2097152, 8388608):
+    mb = [torch.rand(B, obs_dim, device="cuda"), torch.randn(B, act_dim, device="cuda") * 0.5, torch.randn(B, device="cuda"),
+          torch.randn(B, device="cuda") - 8.0, torch.randn(B, device="cuda"), torch.randn(B, device="cuda")]
+    t_g = timed(lambda: fg.run(*mb, 0.2, 0.5, 0.1), 5)
+    perm = torch.randperm(B, device="cuda")
+    t_i = timed(lambda: [t[perm].contiguous() for t in mb], 5)
+    flops_fb = 3 * flops                                   # forward + two backward products per weight
+    print("minibatch of %d samples: fused gradient (3 launches) %.2f ms = %.1f useful TFLOP/s; torch gather of the minibatch tensors %.2f ms"
+          % (B, t_g / 1e3, flops_fb * B / t_g / 1e6, t_i / 1e3), flush=True)
+    del mb, perm
+
 for n in (65536, 262144):
     for fused in (False, True):
         env = RoboyVecEnv(MsjRobot(), n)
