@@ -24,6 +24,9 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-graphs", action="store_true",
                     help="launch every kernel from Python instead of replaying HIP graphs (single-rank runs use graphs)")
+    ap.add_argument("--torch-policy", action="store_true",
+                    help="policy step and minibatch gradient through torch (autograd, rocBLAS) instead of the fused "
+                         "matrix-core kernels of include/roboy_policy.h")
     args = ap.parse_args(argv)
 
     import torch
@@ -48,7 +51,8 @@ def main(argv=None):
                       env_id_offset=rank * args.num_envs)
     more_exploration = 0.1                      # train_parallel.py:30
     agent = PPO(env, ent_coef=more_exploration, device="cuda", dist=dist, seed=args.seed, reward_scale=0.01,
-                use_graphs=(world == 1 and not args.no_graphs))
+                use_graphs=(world == 1 and not args.no_graphs), fused_policy=not args.torch_policy,
+                fused_update=not args.torch_policy)
     if os.path.exists(model_file):
         agent.load(model_file)                  # resume from the last backup
     for _ in range(args.rounds):
