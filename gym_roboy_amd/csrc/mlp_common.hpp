@@ -74,4 +74,23 @@ __device__ __forceinline__ void tanh_tile(f32x16 &d) {
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
 
+// acc0 / acc1 += A_k x b0[k] / b1[k] for k = 0 .. N-1, A operands from LDS at w[k * 64] (this lane's element), with the
+// operand of step k + 2 requested before the MFMAs of step k are issued: at one wave per SIMD nothing else hides the
+// LDS latency, and without the explicit distance the compiler reloads into the register it has just consumed and
+// waits for it (25-30 % of the matrix pipe idle in these loops).
+template <int N, typename B0, typename B1>
+__device__ __forceinline__ void mfma_stream(const float *w, const B0 &b0, const B1 &b1, f32x16 &acc0, f32x16 &acc1) {
+    float a0 = w[0], a1 = N > 1 ? w[64] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float a2 = k + 2 < N ? w[(k + 2) * 64] : 0.0f;
+        acc0 = mfma(a0, b0(k), acc0);
+        acc1 = mfma(a0, b1(k), acc1);
+        a0 = a1; a1 = a2;
+        // keep that order through the machine scheduler: one LDS read, then the step's two MFMAs
+        if (k + 2 < N) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
+}
+
 }  // namespace rpd

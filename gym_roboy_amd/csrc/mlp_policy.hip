@@ -7,8 +7,7 @@
 // accumulate: bit for bit a k-ordered fmaf chain, so the result is the fp32 network, not a reduced-precision one).
 // Samples are the COLUMNS of every product (lane & 31), units the rows:
 //   * layer 1: B operand = obs read straight from HBM in operand order (lane l of K-step s reads element
-//     2s + (l >> 5) of sample l & 31; column obs_dim is the constant 1 that carries the bias); both nets' first
-//     layers (4 row tiles) run in the same K loop;
+//     2s + (l >> 5) of sample l & 31; column obs_dim is the constant 1 that carries the bias);
 //   * a layer's result registers ARE the next layer's B operands: D register r of a 32x32 tile holds, for the
 //     lane's sample, unit U(r) = (r & 3) + 8 (r >> 2) in lanes 0-31 and unit U(r) + 4 in lanes 32-63 - exactly a
 //     B operand whose K pair is (U(r), U(r) + 4).  The weights (A operands) are packed in that k order by
@@ -17,8 +16,10 @@
 //     column tiles' registers (lanes 32-63 of tile 0 <-> lanes 0-31 of tile 1), and every lane finishes its own
 //     sample: Philox + Box-Muller noise, action, log-probability, stores.
 // The A operands (weights, 56 KB for MsjRobot's 9 -> 8 policy) are staged into LDS once per workgroup and read
-// one ds_read_b32 per MFMA pair; waves are persistent over tiles.  f32 MFMA does not overlap f32 VALU work on
-// gfx950 (tools/microbench/mfma_valu_overlap.hip), so the tanh passes add to the 436 MFMAs per tile.
+// one ds_read_b32 per MFMA pair (requested two steps ahead: mlp_common.hpp); waves are persistent over tiles.  f32 MFMA
+// does not overlap f32 VALU work on gfx950 (tools/microbench/mfma_valu_overlap.hip), so the tanh passes add to the
+// 436 MFMAs per tile; the two nets run one after the other to stay within 256 registers = two waves per SIMD, which
+// is what keeps the quarter-rate instructions of tanh issuing (85 -> 78 us at 262 144 samples).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -37,24 +38,39 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 namespace {
 using namespace rpd;
 
-// hidden layer 2 and the output layer of one net on a 64-sample tile; h1: the net's tanh'ed first layer
-// ([row tile][column tile]); y[q][t]: output row tile q (only q < ot computed), column tile t
-__device__ __forceinline__ void net_tail(const float *lds, const Layout &L, int net, int ot, int lane, float onehot,
-                                         const f32x16 (*h1)[2], f32x16 (&y)[2][2]) {
+// one net on a 64-sample tile: x0 / x1: the observation rows of this lane's samples in column tile 0 / 1;
+// y[q][t]: output row tile q (only q < ot computed), column tile t, brought back to one sample per lane.
+// The two nets run one after the other so that a wave stays within 256 registers (two waves per SIMD: at one wave
+// per SIMD the tanh passes - 2 quarter-rate instructions per element - issue at less than half their rate).
+__device__ __forceinline__ void net_forward(const float *lds, const Layout &L, int net, int ot, int lane, float onehot,
+                                            const float *x0, const float *x1, int obs_dim, f32x16 (&y)[2][2]) {
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int half = lane >> 5;
+    f32x16 h1[HT][2];
+#pragma unroll
+    for (int m = 0; m < HT; ++m) { h1[m][0] = zero; h1[m][1] = zero; }
+    // layer 1: K loop over the observation, B operands straight from HBM (column obs_dim = 1 carries the bias)
+    const float *w1 = lds + L.o_l1 + (net * HT) * L.k1s * 64 + lane;
+    for (int s = 0; s < L.k1s; ++s) {
+        const int k = 2 * s + half;
+        const float b0 = k < obs_dim ? x0[k] : (k == obs_dim ? 1.0f : 0.0f);
+        const float b1 = k < obs_dim ? x1[k] : (k == obs_dim ? 1.0f : 0.0f);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            const float a = w1[(m * L.k1s + s) * 64];
+            h1[m][0] = mfma(a, b0, h1[m][0]);
+            h1[m][1] = mfma(a, b1, h1[m][1]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < HT; ++m) { tanh_tile(h1[m][0]); tanh_tile(h1[m][1]); }
     f32x16 h2[HT][2];
 #pragma unroll
     for (int o = 0; o < HT; ++o) {
         h2[o][0] = zero; h2[o][1] = zero;
         const float *w = lds + L.o_l2[net] + o * (HT * 16 * 64) + lane;
-#pragma unroll
-        for (int m = 0; m < HT; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float a = w[(m * 16 + r) * 64];
-                h2[o][0] = mfma(a, h1[m][0][r], h2[o][0]);
-                h2[o][1] = mfma(a, h1[m][1][r], h2[o][1]);
-            }
+        mfma_stream<HT * 16>(w, [&](int k) { return h1[k >> 4][0][k & 15]; }, [&](int k) { return h1[k >> 4][1][k & 15]; },
+                             h2[o][0], h2[o][1]);
         const float b = lds[L.o_b2[net] + o * 64 + lane];      // bias: K pair (1, 0)
         h2[o][0] = mfma(b, onehot, h2[o][0]);
         h2[o][1] = mfma(b, onehot, h2[o][1]);
@@ -65,14 +81,8 @@ __device__ __forceinline__ void net_tail(const float *lds, const Layout &L, int 
         y[q][0] = zero; y[q][1] = zero;
         if (q < ot) {
             const float *w = lds + L.o_l3[net] + q * (HT * 16 * 64) + lane;
-#pragma unroll
-            for (int m = 0; m < HT; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float a = w[(m * 16 + r) * 64];
-                    y[q][0] = mfma(a, h2[m][0][r], y[q][0]);
-                    y[q][1] = mfma(a, h2[m][1][r], y[q][1]);
-                }
+            mfma_stream<HT * 16>(w, [&](int k) { return h2[k >> 4][0][k & 15]; }, [&](int k) { return h2[k >> 4][1][k & 15]; },
+                                 y[q][0], y[q][1]);
             const float b = lds[L.o_b3[net] + q * 64 + lane];
             y[q][0] = mfma(b, onehot, y[q][0]);
             y[q][1] = mfma(b, onehot, y[q][1]);
@@ -87,7 +97,7 @@ __device__ __forceinline__ void net_tail(const float *lds, const Layout &L, int 
     }
 }
 
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(256, 2)
 mlp_act_kernel(const float *__restrict__ packed, const float *__restrict__ obs, float *__restrict__ act,
                float *__restrict__ logp, float *__restrict__ value, float *__restrict__ mean_out, long n, int obs_dim,
                int act_dim, uint64_t seed, uint64_t sample_offset, uint32_t step, const uint32_t *__restrict__ step_base,
@@ -101,38 +111,18 @@ mlp_act_kernel(const float *__restrict__ packed, const float *__restrict__ obs, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int col = lane & 31, half = lane >> 5;
     const float onehot = half ? 0.0f : 1.0f;
-    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const long n_tiles = (n + 63) / 64;
     for (long tile = long(blockIdx.x) * nw + wave; tile < n_tiles; tile += long(gridDim.x) * nw) {
-        // ---- layer 1 of both nets: K loop over the observation, B operands straight from HBM ----
         long s0 = tile * 64 + col, s1 = s0 + 32;                    // this lane's samples in column tile 0 / 1
         s0 = s0 < n ? s0 : n - 1; s1 = s1 < n ? s1 : n - 1;         // past the end: shadow the last sample
         const float *x0 = obs + s0 * obs_dim, *x1 = obs + s1 * obs_dim;
-        f32x16 h1[4][2];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) { h1[m][0] = zero; h1[m][1] = zero; }
-        const float *w1 = lds + L.o_l1 + lane;
-        for (int s = 0; s < L.k1s; ++s) {
-            const int k = 2 * s + half;
-            const float b0 = k < obs_dim ? x0[k] : (k == obs_dim ? 1.0f : 0.0f);
-            const float b1 = k < obs_dim ? x1[k] : (k == obs_dim ? 1.0f : 0.0f);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const float a = w1[(m * L.k1s + s) * 64];
-                h1[m][0] = mfma(a, b0, h1[m][0]);
-                h1[m][1] = mfma(a, b1, h1[m][1]);
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < 4; ++m) { tanh_tile(h1[m][0]); tanh_tile(h1[m][1]); }
-        // ---- the rest of the two nets ----
         f32x16 ypi[2][2], yvf[2][2];
-        net_tail(lds, L, 0, L.ot_pi, lane, onehot, h1, ypi);            // row tiles 0, 1: the action-mean net
-        net_tail(lds, L, 1, 1, lane, onehot, h1 + HT, yvf);             // row tiles 2, 3: the value net
+        net_forward(lds, L, 1, 1, lane, onehot, x0, x1, obs_dim, yvf);          // the value net
+        const float val = yvf[0][0][0];                                          // value = row 0 of its output tile
+        net_forward(lds, L, 0, L.ot_pi, lane, onehot, x0, x1, obs_dim, ypi);    // the action-mean net
         // ---- epilogue: this lane's sample ----
         const long i = tile * 64 + lane;
         const bool live = i < n;
-        const float val = yvf[0][0][0];                             // value = row 0 of the value net's tile
         float lp = -0.91893853320467274f * float(act_dim);          // -1/2 log(2 pi) per dimension
         float *arow = act + (live ? i : 0) * act_dim, *mrow = mean_out ? mean_out + (live ? i : 0) * act_dim : nullptr;
         const uint64_t gid = sample_offset + uint64_t(i);
@@ -246,8 +236,10 @@ int rp_act_dev(const float *d_packed, const float *d_obs, float *d_act, float *d
     int dev = 0, n_cu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     const long n_tiles = (n + 63) / 64;
-    long blocks = (n_tiles + 3) / 4;                 // 4 waves per workgroup, one workgroup per CU, persistent over tiles
-    if (blocks > n_cu) blocks = n_cu;
+    // 4 waves per workgroup (one per SIMD), two workgroups per CU, persistent over tiles; 6-wave workgroups spread
+    // unevenly over the 4 SIMDs and were slower (107 against 78 us at 262 144 samples)
+    long blocks = (n_tiles + 3) / 4;
+    if (blocks > 2 * n_cu) blocks = 2 * n_cu;
     hipLaunchKernelGGL(mlp_act_kernel, dim3(unsigned(blocks)), dim3(256), lds, static_cast<hipStream_t>(stream), d_packed,
                        d_obs, d_act, d_logp, d_value, d_mean, long(n), obs_dim, act_dim, seed, sample_offset, step,
                        d_step_base, deterministic);

@@ -159,14 +159,8 @@ mlp_grad_kernel(const TrainArgs a) {
         for (int o = 0; o < HT; ++o) {
             h2[o][0] = zero; h2[o][1] = zero;
             const float *w = lds + L.o_l2[NET] + o * (HT * 16 * 64) + lane;
-#pragma unroll
-            for (int m = 0; m < HT; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float ww = w[(m * 16 + r) * 64];
-                    h2[o][0] = mfma(ww, h1[m][0][r], h2[o][0]);
-                    h2[o][1] = mfma(ww, h1[m][1][r], h2[o][1]);
-                }
+            mfma_stream<HT * 16>(w, [&](int k) { return h1[k >> 4][0][k & 15]; }, [&](int k) { return h1[k >> 4][1][k & 15]; },
+                                 h2[o][0], h2[o][1]);
             const float b = lds[L.o_b2[NET] + o * 64 + lane];
             h2[o][0] = mfma(b, onehot, h2[o][0]);
             h2[o][1] = mfma(b, onehot, h2[o][1]);
@@ -177,14 +171,7 @@ mlp_grad_kernel(const TrainArgs a) {
         for (int q = 0; q < OT; ++q) {
             f32x16 y0 = zero, y1 = zero;
             const float *w = lds + L.o_l3[NET] + q * (HT * 16 * 64) + lane;
-#pragma unroll
-            for (int m = 0; m < HT; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float ww = w[(m * 16 + r) * 64];
-                    y0 = mfma(ww, h2[m][0][r], y0);
-                    y1 = mfma(ww, h2[m][1][r], y1);
-                }
+            mfma_stream<HT * 16>(w, [&](int k) { return h2[k >> 4][0][k & 15]; }, [&](int k) { return h2[k >> 4][1][k & 15]; }, y0, y1);
             const float b = lds[L.o_b3[NET] + q * 64 + lane];
             y0 = mfma(b, onehot, y0);
             y1 = mfma(b, onehot, y1);
@@ -288,14 +275,8 @@ mlp_grad_kernel(const TrainArgs a) {
         for (int ip = 0; ip < HT; ++ip) {
             d1[ip][0] = zero; d1[ip][1] = zero;
             const float *w = lds + L.o_l2t[NET] + ip * (HT * 16 * 64) + lane;
-#pragma unroll
-            for (int o = 0; o < HT; ++o)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float ww = w[(o * 16 + r) * 64];
-                    d1[ip][0] = mfma(ww, d2[o][0][r], d1[ip][0]);
-                    d1[ip][1] = mfma(ww, d2[o][1][r], d1[ip][1]);
-                }
+            mfma_stream<HT * 16>(w, [&](int k) { return d2[k >> 4][0][k & 15]; }, [&](int k) { return d2[k >> 4][1][k & 15]; },
+                                 d1[ip][0], d1[ip][1]);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
