@@ -21,6 +21,8 @@ SIGNATURES = {
     "rp_last_error": (ctypes.c_char_p, []),
     "rp_packed_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),
     "rp_pack": (ctypes.c_int, [ctypes.POINTER(MlpParams), ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "rp_gae_dev": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                  ctypes.c_int, ctypes.c_int64, ctypes.c_void_p]),
     "rp_train_packed_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),
     "rp_pack_train": (ctypes.c_int, [ctypes.POINTER(MlpParams), ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "rp_grad_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),

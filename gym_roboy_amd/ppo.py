@@ -71,6 +71,19 @@ def gae(rewards, values, dones, last_value, gamma, lam):
     return adv, adv + values
 
 
+def gae_fused(rewards, values, dones, last_value, gamma, lam, adv_out=None, ret_out=None):
+    """gae() as one kernel (include/roboy_policy.h: rp_gae_dev): the [T, N] tensors must be contiguous fp32 on the GPU."""
+    import ctypes as c
+    from . import _policy_native as pn
+    T, N = rewards.shape
+    adv = torch.empty_like(rewards) if adv_out is None else adv_out
+    ret = torch.empty_like(rewards) if ret_out is None else ret_out
+    ptr = lambda t: c.c_void_p(t.data_ptr())
+    pn.check(pn.load().rp_gae_dev(ptr(rewards), ptr(values), ptr(dones), ptr(last_value), float(gamma), float(lam), ptr(adv), ptr(ret),
+                                  int(T), int(N), c.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream)))
+    return adv, ret
+
+
 class FusedPolicyStep:
     """``MlpPolicy.act`` as one kernel on the matrix cores (include/roboy_policy.h, csrc/mlp_policy.hip): observation
     -> action sample, log-probability, value, written straight into the rollout buffers.  The parameters stay torch
@@ -253,8 +266,11 @@ class PPO:
         b["done"].copy_(b["done_i"].to(torch.float32))
         with torch.no_grad():
             last_value = self.policy.value(b["obs"][T])
-        adv, ret = gae(b["rew"], b["val"], b["done"], last_value, self.gamma, self.lam)
-        b["adv"].copy_(adv); b["ret"].copy_(ret)
+        if self._fused is not None:
+            gae_fused(b["rew"], b["val"], b["done"], last_value.contiguous(), self.gamma, self.lam, b["adv"], b["ret"])
+        else:
+            adv, ret = gae(b["rew"], b["val"], b["done"], last_value, self.gamma, self.lam)
+            b["adv"].copy_(adv); b["ret"].copy_(ret)
         b["carry"].copy_(b["obs"][T])
 
     def _build_rollout_graph(self):

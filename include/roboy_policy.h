@@ -61,6 +61,13 @@ int rp_act_dev(const float *d_packed, const float *d_obs, float *d_act, float *d
  * (already normalised) advantage.  The entropy bonus of a state-independent log-std has the constant gradient
  * -ent_coef per log-std component and is left to the caller. */
 
+/* Generalised advantage estimation over a rollout (device pointers, [n_steps][n_envs] row-major; done[t] = step t
+ * ended an episode, as 0 / 1 floats; last_val [n_envs] = value of the observation after the last step):
+ * delta_t = rew_t + gamma * V_{t+1} * (1 - done_t) - V_t,  adv_t = delta_t + gamma * lam * (1 - done_t) * adv_{t+1},
+ * ret_t = adv_t + V_t.  One launch, one env per thread. */
+int rp_gae_dev(const float *d_rew, const float *d_val, const float *d_done, const float *d_last_val, float gamma, float lam,
+               float *d_adv, float *d_ret, int n_steps, int64_t n_envs, void *stream);
+
 /* floats of the blob rp_pack_train() writes: the rp_pack() blob followed by the transposed weights */
 int64_t rp_train_packed_floats(int obs_dim, int act_dim);
 int rp_pack_train(const rp_mlp_params *host_params, int obs_dim, int act_dim, float *packed_host);

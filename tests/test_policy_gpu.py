@@ -194,3 +194,17 @@ def test_ppo_with_fused_rollout_and_fused_update_learns_like_the_torch_path():
     for (n, p), (_, q) in zip(a.policy.named_parameters(), b.policy.named_parameters()):
         assert (p - q).abs().max().item() < 2e-4, n            # 16 Adam steps apart by rounding only
     env.close()
+
+
+def test_fused_gae_equals_the_torch_loop():
+    import torch
+    from gym_roboy_amd.ppo import gae, gae_fused
+    g = torch.Generator().manual_seed(0)
+    T, N = 37, 1000
+    rew, val = torch.randn(T, N, generator=g).cuda(), torch.randn(T, N, generator=g).cuda()
+    done = (torch.rand(T, N, generator=g) < 0.05).float().cuda()
+    last = torch.randn(N, generator=g).cuda()
+    a0, r0 = gae(rew, val, done, last, 0.99, 0.95)
+    a1, r1 = gae_fused(rew, val, done, last, 0.99, 0.95)
+    torch.cuda.synchronize()
+    assert (a0 - a1).abs().max().item() < 1e-5 and (r0 - r1).abs().max().item() < 1e-5
