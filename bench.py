@@ -30,6 +30,7 @@ carries a ``collective`` object that audits it.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import statistics
 import subprocess
@@ -349,6 +350,32 @@ def run_fused_rollout(torch, robot, n_envs, steps_per_launch=100, launches=20):
             "finite": bool(np.isfinite(q).all() and np.isfinite(qd).all()), "feasible_frac": float(feas.mean())}
 
 
+def run_ppo_iteration(torch, n_envs, fused, iters=2):
+    """The consumer of the path: PPO iterations (128-step rollout through the fused env kernel +
+    4 epochs x 4 minibatches) on one GPU, timesteps/s end to end; fused: policy step, GAE and minibatch gradient on the
+    matrix cores (include/roboy_policy.h) instead of torch's kernels.  Not the headline metric."""
+    from gym_roboy_amd.envs.robots import MsjRobot
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    from gym_roboy_amd.ppo import PPO
+    env = RoboyVecEnv(MsjRobot(), n_envs)
+    agent = PPO(env, ent_coef=0.1, device="cuda", reward_scale=0.01, use_graphs=True, fused_policy=fused, fused_update=fused)
+    stats = agent.update(agent.collect())
+    torch.cuda.synchronize()
+    tc = tu = 0.0
+    for _ in range(iters):
+        t0 = time.perf_counter(); roll = agent.collect(); torch.cuda.synchronize(); t1 = time.perf_counter()
+        stats = agent.update(roll); torch.cuda.synchronize(); t2 = time.perf_counter()
+        tc += t1 - t0; tu += t2 - t1
+    feasible = float(env.sim.read_state()[2].mean())
+    env.close()
+    return {"workload": "ppo-%d-%s" % (n_envs, "fused" if fused else "torch"),
+            "label": "PPO iteration (128-step rollout + 16 minibatch steps), %d envs, %s" % (
+                n_envs, "policy step / GAE / gradient as MFMA kernels" if fused else "torch policy, autograd"),
+            "value": iters * agent.n_steps * n_envs / (tc + tu), "unit": "timesteps/s", "rollout_ms": tc / iters * 1e3,
+            "update_ms": tu / iters * 1e3, "steps": iters * agent.n_steps,
+            "finite": bool(all(math.isfinite(v) for v in stats.values())), "feasible_frac": feasible}
+
+
 _PY_ENV_WORKER = r"""
 import contextlib, io, sys, time
 sys.path.insert(0, %(root)r)
@@ -509,6 +536,8 @@ def main():
             also.append(brief(run_fused_env(torch, MsjRobot(), 2097152)))
             for n_fused in (4096, 2097152):
                 also.append(brief(run_fused_rollout(torch, MsjRobot(), n_fused)))
+            for fused in (True, False):                      # the consumer, end to end (timesteps/s, not env-steps/s)
+                also.append(run_ppo_iteration(torch, 65536, fused))
 
     rc = 0
     if rank == 0:

@@ -62,8 +62,10 @@ def test_bench_default_run_carries_every_config_with_sanity_fields():
     assert d["steps"] == 400 and "262 144" in d["config"]["workload"]
     names = [a["workload"] for a in d["also"]]
     for w in ("msj-4096-euler", "msj-262144-euler", "msj-2097152-euler", "upper-body-8192-euler",
-              "upper-body-8192-rk4", "fused-env-2097152"):
+              "upper-body-8192-rk4", "fused-env-2097152", "ppo-65536-fused", "ppo-65536-torch"):
         assert w in names, names
+    ppo = {a["workload"]: a for a in d["also"] if a["workload"].startswith("ppo-")}
+    assert ppo["ppo-65536-fused"]["value"] > 3 * ppo["ppo-65536-torch"]["value"]      # the consumer on the matrix cores
     for a in d["also"]:
         assert a["finite"] is True and 0.0 <= a["feasible_frac"] <= 1.0, a["workload"]
         if "roofline" in a:
