@@ -281,6 +281,9 @@ __device__ __forceinline__ void p2_tendon(const Ctx &c, int e, int k) {
     const int c0 = c.ti(t.o_t_cr_start + k), c1 = c.ti(t.o_t_cr_start + k + 1);
     float *W = c.env(e) + t.o_W;
     float len = 0.0f, ldot = 0.0f;
+    // the last crossing's unit wrench stays in registers (a tendon with one crossing - every tendon of the upper
+    // body - never reads its wrench back from LDS); earlier crossings are stored unscaled and rescaled below
+    V3 wa = {0.0f, 0.0f, 0.0f}, wu = {0.0f, 0.0f, 0.0f};
     for (int cr = c0; cr < c1; ++cr) {
         const float *rec = c.tab + t.o_cross + cr * CROSS_REC;
         const int la = __float_as_int(rec[0]), lb = __float_as_int(rec[1]);
@@ -292,7 +295,8 @@ __device__ __forceinline__ void p2_tendon(const Ctx &c, int e, int k) {
         const V3 u = d * inv;
         len += d2 * inv;
         ldot += dot(u, vb - va);
-        st3(W + 6 * cr, cross(xa, u)); st3(W + 6 * cr + 3, u);      // unit wrench; scaled by the tension below
+        wa = cross(xa, u); wu = u;                                    // unit wrench; scaled by the tension below
+        if (cr + 1 < c1) { st3(W + 6 * cr, wa); st3(W + 6 * cr + 3, wu); }
     }
     const float *tr = c.tab + t.o_tendon + k * TENDON_REC;
     const float es = len * tr[0] + tr[1];                             // scaled strain s (l/l0 - 1)
@@ -303,10 +307,11 @@ __device__ __forceinline__ void p2_tendon(const Ctx &c, int e, int k) {
     const float num = t.fv_c1l * vp + p, den = t.fv_c2l * vp + (t.fv_c2s * p + t.fv_k);
     const float fpe = fmaxf(__builtin_amdgcn_exp2f(t.pe_k2s * es) * t.inv_pe_den - t.inv_pe_den, 0.0f);
     const float F = tr[3] * ((act * fl) * num * __builtin_amdgcn_rcpf(den) + fpe);
-    for (int cr = c0; cr < c1; ++cr) {
+    for (int cr = c0; cr + 1 < c1; ++cr) {
 #pragma unroll
         for (int a = 0; a < 6; ++a) W[6 * cr + a] *= F;
     }
+    if (c1 > c0) { st3(W + 6 * (c1 - 1), wa * F); st3(W + 6 * (c1 - 1) + 3, wu * F); }
 }
 
 // ---- P5: backward pass of one link.  Lane (half, kk) owns row row6 = 3 half + kk of the link's 6x6 and
