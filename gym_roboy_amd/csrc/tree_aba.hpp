@@ -40,7 +40,7 @@
 // waves sharing one LDS copy of the robot tables (staged behind the only barrier).
 //
 // The model is DESIGN.md §2; oracle/physics_np.py (Jacobian-sum M, RNE bias, dense solve) is what
-// this is checked against; tools/proto/aba_world.py is the fp64 prototype of this formulation
+// this is checked against; tests/proto/aba_world.py is the fp64 prototype of this formulation
 // (agrees with the oracle to 3e-15).  Algorithmic HBM bytes per env step: 4 (4 n_q + n_t + 1).
 // State layout in HBM for this kernel class: env-major rows q[n][n_q], qd[n][n_q], goal[n][n_q] (a wave's
 // E envs are one contiguous run; the SoA planes of the env-per-lane kernels would cost a cache line per

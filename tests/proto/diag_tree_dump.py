@@ -1,7 +1,7 @@
 """Debug aid: dump the LDS working set of the joint-tree kernel for one env (library built with -DRB_TREE_DEBUG,
-ROBOY_SIM_LIB=gym_roboy_amd/csrc/variants/lib_dbg.so) and compare per link with the fp64 prototype (tools/proto/aba_world.py)."""
+ROBOY_SIM_LIB=gym_roboy_amd/csrc/variants/lib_dbg.so) and compare per link with the fp64 prototype (tests/proto/aba_world.py)."""
 import ctypes, sys
-sys.path.insert(0, "tests"); sys.path.insert(0, "."); sys.path.insert(0, "tools/proto")
+sys.path.insert(0, "tests"); sys.path.insert(0, "."); sys.path.insert(0, "tests/proto")
 import numpy as np
 from random_robots import random_tree_robot
 from conftest import random_states
@@ -23,7 +23,7 @@ dev = TreeDev()
 assert lib.rb_debug_tree_fetch(sim.handle, buf.ctypes.data_as(ctypes.c_void_p), len(buf), ctypes.byref(dev)) == 0
 ES, LS = dev.ES, 37
 blk = buf[(env % 2) * ES:(env % 2 + 1) * ES]
-src = open("tools/proto/aba_world.py").read().split("if __name__")[0].replace("    return qdd", "    return qdd, D, u_, U, a, s, c, fext")
+src = open("tests/proto/aba_world.py").read().split("if __name__")[0].replace("    return qdd", "    return qdd, D, u_, U, a, s, c, fext")
 ns = {}
 exec(src, ns)
 orc = TendonRobotOracle(desc)
