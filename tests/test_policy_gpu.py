@@ -208,3 +208,22 @@ def test_fused_gae_equals_the_torch_loop():
     a1, r1 = gae_fused(rew, val, done, last, 0.99, 0.95)
     torch.cuda.synchronize()
     assert (a0 - a1).abs().max().item() < 1e-5 and (r0 - r1).abs().max().item() < 1e-5
+
+
+def test_ppo_on_the_upper_body_with_the_fused_kernels():
+    """The 60 -> 38 policy of the joint-tree robot goes through the general instances of the kernels."""
+    import torch
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    from gym_roboy_amd.ppo import PPO
+    env = RoboyVecEnv(UpperBodyRobot(), 256, seed=5)
+    agent = PPO(env, n_steps=8, use_graphs=True, fused_policy=True, fused_update=True, seed=1, reward_scale=0.01)
+    roll = agent.collect()
+    with torch.no_grad():
+        lp = agent.policy.dist(roll["obs"]).log_prob(roll["act"]).sum(-1)
+    assert (lp - roll["logp"]).abs().max() < 2e-3
+    before = [p.detach().clone() for p in agent.policy.parameters()]
+    stats = agent.update(roll)
+    assert all(np.isfinite(v) for v in stats.values())
+    assert any((p.detach() - b).abs().max() > 0 for p, b in zip(agent.policy.parameters(), before))
+    env.close()
