@@ -85,12 +85,12 @@ mlp_grad_kernel(const TrainArgs a) {
     const Layout G = layout_of(obs_dim, act_dim);
     Layout L = G;
     const int ot_net = NET == 0 ? G.ot_pi : 1;
-    int o = 0;
-    auto stage = [&](int src, int n_floats) {              // blob block -> LDS at o; all blocks are multiples of 4 floats
+    int lds_used = 0;
+    auto stage = [&](int src, int n_floats) {              // blob block -> LDS at lds_used; all blocks are multiples of 4 floats
         const float4 *s4 = reinterpret_cast<const float4 *>(a.packed + src);
-        for (int k = threadIdx.x; k < n_floats / 4; k += blockDim.x) lds4[o / 4 + k] = s4[k];
-        const int at = o;
-        o += n_floats;
+        for (int k = threadIdx.x; k < n_floats / 4; k += blockDim.x) lds4[lds_used / 4 + k] = s4[k];
+        const int at = lds_used;
+        lds_used += n_floats;
         return at;
     };
     L.o_l1 = stage(G.o_l1 + (NET == 0 ? 0 : HT) * G.k1s * 64, HT * G.k1s * 64) - 0;
@@ -106,7 +106,7 @@ mlp_grad_kernel(const TrainArgs a) {
     const int col = lane & 31, half = lane >> 5;
     constexpr int S3S = NJ + 1;                            // row stride of the delta3 staging (odd)
     constexpr int XSN = KX == 1 ? 64 * 33 : 0;             // KX == 1: the tile's observations [64 samples][33], staged once
-    float *T = lds + o + wave * (32 * 33 + 64 * S3S + XSN);   // transpose scratch, the delta3 staging [64][S3S], observations
+    float *T = lds + lds_used + wave * (32 * 33 + 64 * S3S + XSN);   // transpose scratch, the delta3 staging [64][S3S], observations
     float *S3 = T + 32 * 33;
     float *XS = S3 + 64 * S3S;
     const float onehot = half ? 0.0f : 1.0f;
