@@ -139,7 +139,7 @@ def _torch_loss(policy, obs, act, adv, logp_old, val_old, ret, cliprange, vf_coe
     return pg - ent_coef * ent + vf_coef * vf, pg, vf
 
 
-@pytest.mark.parametrize("obs_dim,act_dim,B", [(9, 8, 1000), (9, 8, 64), (9, 8, 37), (9, 8, 20000), (60, 38, 777), (3, 1, 200), (30, 8, 129)])
+@pytest.mark.parametrize("obs_dim,act_dim,B", [(9, 8, 1000), (9, 8, 64), (9, 8, 37), (9, 8, 1), (9, 8, 2), (9, 8, 20000), (60, 38, 777), (3, 1, 200), (30, 8, 129)])
 def test_ppo_minibatch_gradient_matches_torch_autograd(obs_dim, act_dim, B):
     import torch
     from gym_roboy_amd.ppo import FusedPolicyGrad
