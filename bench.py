@@ -537,7 +537,11 @@ def main():
             for n_fused in (4096, 2097152):
                 also.append(brief(run_fused_rollout(torch, MsjRobot(), n_fused)))
             for fused in (True, False):                      # the consumer, end to end (timesteps/s, not env-steps/s)
-                also.append(run_ppo_iteration(torch, 65536, fused))
+                try:
+                    also.append(run_ppo_iteration(torch, 65536, fused))
+                except Exception as exc:                     # never at the expense of the headline line
+                    also.append({"workload": "ppo-65536-%s" % ("fused" if fused else "torch"), "error": repr(exc)[:300],
+                                 "finite": False, "feasible_frac": 0.0})
 
     rc = 0
     if rank == 0:
