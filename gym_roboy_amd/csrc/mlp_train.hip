@@ -431,6 +431,21 @@ long grad_blocks(long B) {
     return blocks < cap ? blocks : cap;
 }
 
+// dynamic LDS of one gradient-kernel instance: the staged operand blocks of one net + per-wave scratch
+size_t grad_lds_bytes(const Layout &L, int net, int nj, int kx_inst) {
+    const int ot = net == 0 ? L.ot_pi : 1;
+    const size_t w = size_t(HT) * L.k1s * 64 + 2 * size_t(HT * HT * 16 * 64) + HT * 64 + size_t(ot) * (HT * 16 * 64 + 64) + 64 +
+                     size_t(HT) * L.k3s[net] * 64;
+    return sizeof(float) * (w + WAVES_PER_BLOCK * (32 * 33 + 64 * (nj + 1) + (kx_inst == 1 ? 64 * 33 : 0)));
+}
+// the instance pair rp_ppo_grad_dev picks: the reference's robot class (obs <= 31, up to 8 actions) or the general
+// one (obs <= 63, up to 64 actions); false if the general instance of the action net does not fit the 160 KB of LDS
+bool grad_fits(int obs_dim, int act_dim) {
+    const Layout L = layout_of(obs_dim, act_dim);
+    const bool small = obs_dim + 1 <= 32 && act_dim <= 8;
+    return grad_lds_bytes(L, 0, small ? 8 : 64, small ? 1 : 2) <= 160 * 1024;
+}
+
 template <int NET, int KX, int NJ>
 int launch_grad(const TrainArgs &a, long blocks, size_t lds, hipStream_t stream) {
     static size_t allowed = 64 * 1024;
@@ -453,6 +468,8 @@ extern "C" {
 int64_t rp_train_packed_floats(int obs_dim, int act_dim) {
     if (rp_packed_floats(obs_dim, act_dim) < 0) return RP_EUNSUPPORTED;
     if (obs_dim + 1 > 64) return fail(RP_EUNSUPPORTED, "the gradient kernel supports obs_dim <= 63");
+    if (!grad_fits(obs_dim, act_dim))
+        return fail(RP_EUNSUPPORTED, "policy too large for the LDS-resident gradient kernel (operands + scratch > 160 KB)");
     return layout_of(obs_dim, act_dim).total_train;
 }
 
@@ -514,12 +531,7 @@ int rp_ppo_grad_dev(const float *d_packed_train, const float *d_obs, const float
     const Layout L = layout_of(obs_dim, act_dim);
     const int gs = gstride_of(obs_dim, act_dim);
     const long blocks = grad_blocks(batch), waves = blocks * WAVES_PER_BLOCK;
-    auto lds_of = [&](int net, int nj) {                      // the staged blocks of one net + per-wave scratch
-        const int ot = net == 0 ? L.ot_pi : 1;
-        const size_t w = size_t(HT) * L.k1s * 64 + 2 * size_t(HT * HT * 16 * 64) + HT * 64 + size_t(ot) * (HT * 16 * 64 + 64) + 64 +
-                         size_t(HT) * L.k3s[net] * 64;
-        return sizeof(float) * (w + WAVES_PER_BLOCK * (32 * 33 + 64 * (nj + 1) + (obs_dim + 1 <= 32 ? 64 * 33 : 0)));
-    };
+    auto lds_of = [&](int net, int nj, int kx_inst) { return grad_lds_bytes(L, net, nj, kx_inst); };
     hipStream_t st = static_cast<hipStream_t>(stream);
     TrainArgs a;
     a.packed = d_packed_train; a.obs = d_obs; a.act = d_act; a.adv = d_adv; a.logp_old = d_logp_old; a.val_old = d_val_old;
@@ -531,13 +543,12 @@ int rp_ppo_grad_dev(const float *d_packed_train, const float *d_obs, const float
     // instances: the reference's robot class (obs <= 31, up to 8 actions) and the general one (obs <= 63, 64 actions)
     // instances: the reference's robot class (obs <= 31, up to 8 actions) and the general one (obs <= 63, 64 actions)
     const bool small = kx == 1 && act_dim <= 8;
-    if (lds_of(0, small ? 8 : 64) > 160 * 1024) return fail(RP_EUNSUPPORTED, "policy too large for the LDS-resident form");
-    if (small) rc = launch_grad<0, 1, 8>(a, blocks, lds_of(0, 8), st);
-    else rc = launch_grad<0, 2, 64>(a, blocks, lds_of(0, 64), st);
+    if (small) rc = launch_grad<0, 1, 8>(a, blocks, lds_of(0, 8, 1), st);
+    else rc = launch_grad<0, 2, 64>(a, blocks, lds_of(0, 64, 2), st);
     if (rc) return rc;
     a.partials = d_workspace + waves * gs;
-    if (small) rc = launch_grad<1, 1, 8>(a, blocks, lds_of(1, 8), st);
-    else rc = launch_grad<1, 2, 8>(a, blocks, lds_of(1, 8), st);
+    if (small) rc = launch_grad<1, 1, 8>(a, blocks, lds_of(1, 8, 1), st);
+    else rc = launch_grad<1, 2, 8>(a, blocks, lds_of(1, 8, 2), st);
     if (rc) return rc;
     for (int net = 0; net < 2; ++net) {
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((gs + 255) / 256), dim3(256), 0, st, d_workspace + net * waves * gs,

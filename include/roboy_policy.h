@@ -68,7 +68,9 @@ int rp_act_dev(const float *d_packed, const float *d_obs, float *d_act, float *d
 int rp_gae_dev(const float *d_rew, const float *d_val, const float *d_done, const float *d_last_val, float gamma, float lam,
                float *d_adv, float *d_ret, int n_steps, int64_t n_envs, void *stream);
 
-/* floats of the blob rp_pack_train() writes: the rp_pack() blob followed by the transposed weights */
+/* floats of the blob rp_pack_train() writes: the rp_pack() blob followed by the transposed weights; negative if the
+ * gradient kernels do not support the dimensions: obs_dim <= 63, and the operands of the action net plus the per-wave
+ * scratch must fit the 160 KB of LDS (60 -> 38 does, 63 -> 64 does not) */
 int64_t rp_train_packed_floats(int obs_dim, int act_dim);
 int rp_pack_train(const rp_mlp_params *host_params, int obs_dim, int act_dim, float *packed_host);
 

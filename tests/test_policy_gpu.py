@@ -139,7 +139,8 @@ def _torch_loss(policy, obs, act, adv, logp_old, val_old, ret, cliprange, vf_coe
     return pg - ent_coef * ent + vf_coef * vf, pg, vf
 
 
-@pytest.mark.parametrize("obs_dim,act_dim,B", [(9, 8, 1000), (9, 8, 64), (9, 8, 37), (9, 8, 1), (9, 8, 2), (9, 8, 20000), (60, 38, 777), (3, 1, 200), (30, 8, 129)])
+@pytest.mark.parametrize("obs_dim,act_dim,B", [(9, 8, 1000), (9, 8, 64), (9, 8, 37), (9, 8, 1), (9, 8, 2), (9, 8, 20000), (60, 38, 777), (3, 1, 200), (30, 8, 129),
+                                                (31, 8, 100), (32, 8, 100), (10, 33, 100), (63, 40, 70)])
 def test_ppo_minibatch_gradient_matches_torch_autograd(obs_dim, act_dim, B):
     import torch
     from gym_roboy_amd.ppo import FusedPolicyGrad
@@ -173,6 +174,14 @@ def test_ppo_minibatch_gradient_matches_torch_autograd(obs_dim, act_dim, B):
     fg.run(big[0], big[1], dev[2], big[3], big[4], big[5], cliprange, vf_coef, ent_coef, index=perm)
     torch.cuda.synchronize()
     assert torch.equal(fg._g, g_direct)
+
+
+def test_gradient_kernel_refuses_policies_beyond_its_lds_budget_loudly():
+    from gym_roboy_amd.ppo import FusedPolicyGrad
+    with pytest.raises(RuntimeError, match="too large"):
+        FusedPolicyGrad(_policy(63, 64, 0).cuda())
+    with pytest.raises(RuntimeError, match="obs_dim <= 63"):
+        FusedPolicyGrad(_policy(64, 8, 0).cuda())
 
 
 def test_ppo_with_fused_rollout_and_fused_update_learns_like_the_torch_path():
