@@ -60,6 +60,26 @@ def test_step_large_batch_matches_oracle(msj_robot, msj_oracle, integrator):
     _check_step(msj_robot, msj_oracle, 70001, integrator, 1, seed=5)
 
 
+@pytest.mark.parametrize("n", [8192, 8193, 16384, 16385, 65536, 65537])
+def test_step_at_the_dispatch_boundaries_matches_oracle(msj_robot, n):
+    """Batch sizes on either side of every kernel-form switch of AUTO (tendon per lane up to 8 192 / 16 384 envs for
+    Euler / RK4, one-wave workgroups up to 65 536, 256-thread workgroups above): a strided sample against the C oracle,
+    the last env included."""
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    from oracle.c_oracle import COracle
+    desc = msj_robot.get_description()
+    q, qd, sp = random_states(desc, n, n)
+    idx = np.unique(np.concatenate([np.arange(0, n, 61), [n - 1]]))
+    orc = COracle(desc, "f64")
+    for integrator in ("euler", "rk4"):
+        sim = HipBatchSimulation(msj_robot, n, integrator=integrator)
+        sim.set_state(q, qd)
+        q1, qd1, f1 = sim.forward_step_command(sp)
+        qo, qdo, fo = orc.step(q[idx], qd[idx], sp[idx], integrator=0 if integrator == "euler" else 1)
+        assert np.abs(q1[idx] - qo).max() < TOL and np.abs(qd1[idx] - qdo).max() < TOL
+        sim.close()
+
+
 def test_kernel_forms_agree_with_each_other(msj_robot):
     """Same inputs through both forms: they differ only in the order the 8
     tendon torques are summed (sequential vs DPP butterfly)."""
