@@ -76,6 +76,24 @@ __device__ __forceinline__ void net_forward(const float *lds, const Layout &L, i
         h2[o][1] = mfma(b, onehot, h2[o][1]);
         tanh_tile(h2[o][0]); tanh_tile(h2[o][1]);
     }
+    if (net == 1) {
+        // the value net's ONE output row on the VALU (as a 32-row MFMA tile it would be 31/32 padding: 66 of the 436
+        // MFMAs per tile): every lane holds 32 of the 64 h2 units of its column's sample; the half swap adds the other
+        // half's partial sum and leaves one sample per lane, as the MFMA path does.  y[0][0][0] = the value.
+        float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+        for (int m = 0; m < HT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float wv = lds[L.o_l3[net] + (m * 16 + r) * 64 + 32 * half];     // row 0 of the A operand: lane 0 / 32
+                p0 += wv * h2[m][0][r];
+                p1 += wv * h2[m][1][r];
+            }
+        half_swap(p0, p1);
+        y[0][0] = zero; y[0][1] = zero; y[1][0] = zero; y[1][1] = zero;
+        y[0][0][0] = p0 + p1 + lds[L.o_b3[net]];
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         y[q][0] = zero; y[q][1] = zero;

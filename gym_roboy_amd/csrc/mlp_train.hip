@@ -118,6 +118,11 @@ mlp_grad_kernel(const TrainArgs a) {
     // gradient accumulators, alive across the wave's tiles
     f32x16 G1[HT][KX], G2[HT][HT], G3[OT][HT], db2[HT];
     float db3[NJ], gls[NJ];
+    float acc3[HT][16];                                     // value net: per-lane sums of dW3 (see the forward pass)
+#pragma unroll
+    for (int m = 0; m < HT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[m][r] = 0.0f;
     float loss_sum = 0.0f;
 #pragma unroll
     for (int o = 0; o < HT; ++o) {
@@ -191,8 +196,26 @@ mlp_grad_kernel(const TrainArgs a) {
             tanh_tile(h2[o][0]); tanh_tile(h2[o][1]);
         }
         float out[NJ];                                      // this lane's sample: output row j
+        // The value net has ONE output: as 32-row MFMA tiles its output layer, W3^T delta3 and dW3 would be 31/32
+        // padding (134 of the net's 602 MFMAs per tile).  They run on the VALU instead: every lane holds 32 of the 64
+        // h2 units of its column's sample, so the output is a 32-term dot product per half-wave plus the other half's.
+        float wv[HT][16];                                   // W3[0][unit of (m, r, this half)]
+        float bt0 = 0.0f, bt1 = 0.0f;                       // delta3 of this lane's column sample in tile 0 / 1
+        if (NET == 1) {
+            float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
-        for (int q = 0; q < OT; ++q) {
+            for (int m = 0; m < HT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    wv[m][r] = lds[L.o_l3[NET] + (m * 16 + r) * 64 + 32 * half];      // row 0 of the A operand: lane 0 / 32
+                    p0 += wv[m][r] * h2[m][0][r];
+                    p1 += wv[m][r] * h2[m][1][r];
+                }
+            half_swap(p0, p1);                               // (tile 0 | tile 1) x (lower | upper units) -> one sample per lane
+            out[0] = p0 + p1 + lds[L.o_b3[NET]];
+        }
+#pragma unroll
+        for (int q = 0; q < (NET == 1 ? 0 : OT); ++q) {
             f32x16 y0 = zero, y1 = zero;
             const float *w = lds + L.o_l3[NET] + q * (HT * 16 * 64) + lane;
             mfma_stream<HT * 16>(w, [&](int k) { return h2[k >> 4][0][k & 15]; }, [&](int k) { return h2[k >> 4][1][k & 15]; }, y0, y1);
@@ -250,15 +273,30 @@ mlp_grad_kernel(const TrainArgs a) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) db3[j] += d3[j];
         // delta3 staged [sample][row] for the transposed (row-on-lane) reads of dW3
+        if (NET == 0) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            if (j < n_out) S3[lane * S3S + j] = d3[j];
+            for (int j = 0; j < NJ; ++j)
+                if (j < n_out) S3[lane * S3S + j] = d3[j];
+        } else {
+            bt0 = d3[0]; bt1 = d3[0];
+            half_swap(bt0, bt1);                             // this lane's column sample of tile 0 / tile 1
+        }
         // ================= delta2 = (W3^T delta3) (1 - h2^2) =================
         f32x16 d2[HT][2];
 #pragma unroll
         for (int m = 0; m < HT; ++m) { d2[m][0] = zero; d2[m][1] = zero; }
+        if (NET == 1) {
 #pragma unroll
-        for (int s = 0; s < NJ / 2; ++s)
+            for (int m = 0; m < HT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    d2[m][0][r] = wv[m][r] * bt0;
+                    d2[m][1][r] = wv[m][r] * bt1;
+                    acc3[m][r] += bt0 * h2[m][0][r] + bt1 * h2[m][1][r];     // dW3, reduced over the lanes at the end
+                }
+        }
+#pragma unroll
+        for (int s = 0; s < (NET == 1 ? 0 : NJ / 2); ++s)
             if (s < k3s) {                                   // K pair = outputs (2 s, 2 s + 1)
                 float b0 = d3[2 * s], b1 = d3[2 * s + 1];
                 half_swap(b0, b1);                           // b0: column tile 0, b1: column tile 1
@@ -278,7 +316,7 @@ mlp_grad_kernel(const TrainArgs a) {
         wave_fence();                                        // S3 written above is read below
         // ================= dW3 += delta3 h2^T, per column tile =================
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < (NET == 1 ? 0 : 2); ++t) {
             f32x16 h2T[HT];
 #pragma unroll
             for (int m = 0; m < HT; ++m) h2T[m] = transpose_tile(h2[m][t], T, col, half);
@@ -363,8 +401,19 @@ mlp_grad_kernel(const TrainArgs a) {
             for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
             if (col == 0) P[g.b2 + row] = v;
         }
+    if (NET == 1) {
 #pragma unroll
-    for (int q = 0; q < OT; ++q)
+        for (int m = 0; m < HT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc3[m][r];                                    // sum over the 32 samples-lanes of the half-wave
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                if (col == 0) P[g.w3 + 32 * m + unit_of(r) + 4 * half] = v;
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < (NET == 1 ? 0 : OT); ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * q + unit_of(r) + 4 * half;              // output

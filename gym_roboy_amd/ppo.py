@@ -20,7 +20,7 @@ matrix-core kernels of ``include/roboy_policy.h`` (exact f32): the policy step a
 rollout (``FusedPolicyStep``, ``gae_fused``) and the minibatch gradient of the update
 (``FusedPolicyGrad``; optimiser, gradient clipping and the cross-rank average stay torch's).
 At 262 144 envs a PPO iteration goes from 49 ms + 1.06 s (rollout + update, torch: ~40
-memory-bound passes over [8.4 M x 64] activations per minibatch) to 12 ms + 0.14 s
+memory-bound passes over [8.4 M x 64] activations per minibatch) to 11 ms + 0.13 s
 (``tools/policy_bench.py``).  The torch path stays the default of this class and is what the
 fused kernels are tested against; ``train_parallel.py`` selects the fused ones.
 """
