@@ -311,8 +311,8 @@ def run_fused_env(torch, robot, n_envs, steps=300, warmup=30):
     finite = bool(torch.isfinite(obs).all().item() and torch.isfinite(rew).all().item())
     q, qd, feas = env.sim.read_state()
     env.close()
-    name = "fused-env-%d" % n_envs
-    return {"workload": name, "label": "fused env layer (RoboyVecEnv.step), %d envs, Euler fp32" % n_envs,
+    name = "fused-env-%d" % n_envs if type(robot).__name__ == "MsjRobot" else "fused-env-%s-%d" % (type(robot).__name__, n_envs)
+    return {"workload": name, "label": "fused env layer (RoboyVecEnv.step), %s, %d envs, Euler fp32" % (type(robot).__name__, n_envs),
             "value": n_envs * steps / wall, "ms_per_step": wall * 1e3 / steps, "launch_us_events": us, "steps": steps,
             "roofline": roofline(type(robot).__name__, "euler", 1, n_envs, bytes_per, us * 1e-6, name),
             "finite": finite and bool(np.isfinite(q).all() and np.isfinite(qd).all()), "feasible_frac": float(feas.mean())}
@@ -534,6 +534,7 @@ def main():
                     rob = UpperBodyRobot() if name.startswith("upper-body") else MsjRobot()
                     also.append(brief(run_workload(torch, rob, name, None, None, None, use_graph, rank, world, dist)))
             also.append(brief(run_fused_env(torch, MsjRobot(), 2097152)))
+            also.append(brief(run_fused_env(torch, UpperBodyRobot(), 8192)))
             for n_fused in (4096, 2097152):
                 also.append(brief(run_fused_rollout(torch, MsjRobot(), n_fused)))
             for fused in (True, False):                      # the consumer, end to end (timesteps/s, not env-steps/s)
