@@ -135,3 +135,32 @@ def test_random_ball_joint_robot_large_batches_jit_and_kernarg(seed):
         assert _ball_check(robot, desc, 70001, integrator, 1 + seed % 2, seed, sample=41) == "kernarg"
     finally:
         del os.environ["ROBOY_SIM_JIT"]
+
+
+@pytest.mark.parametrize("seed", list(range(16)) + sorted(EXTREMES))
+def test_random_tree_robots_stay_finite_and_inside_their_boxes_under_extreme_actions(seed):
+    """150 steps of bang-bang set-points from the corners of the state box (both integrators): every state stays
+    finite, inside the joint limits and the velocity box - whatever the topology (the 0 * inf of drifting idle lanes
+    showed up only on deep chains and only for some poses)."""
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    if isinstance(seed, str):
+        robot, desc = random_tree_robot(100 + sorted(EXTREMES).index(seed), **EXTREMES[seed])
+        seed = 100 + sorted(EXTREMES).index(seed)
+    else:
+        robot, desc = random_tree_robot(seed)
+    n = 64
+    rng = np.random.default_rng(seed)
+    for integrator in ("euler", "rk4"):
+        sim = HipBatchSimulation(robot, n, integrator=integrator)
+        corner = rng.integers(0, 2, (n, desc.n_q)).astype(bool)
+        q0 = np.where(corner, desc.q_hi, desc.q_lo).astype(np.float32) * 0.999
+        qd0 = np.where(rng.integers(0, 2, (n, desc.n_q)).astype(bool), desc.qd_max, -desc.qd_max).astype(np.float32)
+        sim.set_state(q0, qd0)
+        for t in range(150):
+            sp = (0.3 * np.sign(rng.normal(size=(n, desc.n_t)))).astype(np.float32)
+            q, qd, f = sim.forward_step_command(sp)
+            if t % 50 == 49 or t == 0:
+                assert np.isfinite(q).all() and np.isfinite(qd).all(), (integrator, t)
+                assert np.all(q >= desc.q_lo - 1e-6) and np.all(q <= desc.q_hi + 1e-6), (integrator, t)
+                assert np.all(np.abs(qd) <= desc.qd_max + 1e-6), (integrator, t)
+        sim.close()
