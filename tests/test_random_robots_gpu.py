@@ -164,3 +164,23 @@ def test_random_tree_robots_stay_finite_and_inside_their_boxes_under_extreme_act
                 assert np.all(q >= desc.q_lo - 1e-6) and np.all(q <= desc.q_hi + 1e-6), (integrator, t)
                 assert np.all(np.abs(qd) <= desc.qd_max + 1e-6), (integrator, t)
         sim.close()
+
+
+@pytest.mark.parametrize("seed,n_t", [(0, 8), (1, 8), (2, 8), (3, 8), (4, 1), (5, 5), (6, 13), (7, 16)])
+def test_random_ball_joint_robots_stay_finite_and_inside_their_boxes_under_extreme_actions(seed, n_t):
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    from random_robots import random_ball_joint_robot
+    robot, desc = random_ball_joint_robot(seed, n_t)
+    rng = np.random.default_rng(seed)
+    for integrator, n in (("euler", 300), ("rk4", 300), ("euler", 70001)):
+        sim = HipBatchSimulation(robot, n, integrator=integrator, n_substeps=1 + seed % 2)
+        q0 = np.where(rng.integers(0, 2, (n, 3)).astype(bool), desc.q_hi, desc.q_lo).astype(np.float32) * 0.999
+        qd0 = np.where(rng.integers(0, 2, (n, 3)).astype(bool), desc.qd_max, -desc.qd_max).astype(np.float32)
+        sim.set_state(q0, qd0)
+        for t in range(60 if n > 1000 else 150):
+            sp = (0.3 * np.sign(rng.normal(size=(n, n_t)))).astype(np.float32)
+            q, qd, f = sim.forward_step_command(sp)
+        assert np.isfinite(q).all() and np.isfinite(qd).all(), (integrator, n)
+        assert np.all(q >= desc.q_lo - 1e-6) and np.all(q <= desc.q_hi + 1e-6)
+        assert np.all(np.abs(qd) <= desc.qd_max + 1e-6)
+        sim.close()
