@@ -184,3 +184,38 @@ def test_random_ball_joint_robots_stay_finite_and_inside_their_boxes_under_extre
         assert np.all(q >= desc.q_lo - 1e-6) and np.all(q <= desc.q_hi + 1e-6)
         assert np.all(np.abs(qd) <= desc.qd_max + 1e-6)
         sim.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 6, "star32", "chain32"])
+def test_fused_env_layer_on_random_robots_matches_host_replay(seed):
+    """RoboyVecEnv over the joint-tree kernel on random robots: the replay check of tests/test_tree_robot_gpu.py
+    (states and goals bit for bit against the plain kernel + numpy Philox, reward / done against reward.py in float64,
+    episode statistics), with auto-reset and a 9-step episode horizon so that every bookkeeping path runs."""
+    from host_env_model import HipStepper, HostEnvModel
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    if isinstance(seed, str):
+        robot, desc = random_tree_robot(100 + sorted(EXTREMES).index(seed), **EXTREMES[seed])
+    else:
+        robot, desc = random_tree_robot(seed)
+    n, env_seed, max_len = 66, 3, 9
+    vec = RoboyVecEnv(robot, n, seed=env_seed, auto_reset=True, max_episode_length=max_len, joint_vel_penalty=True)
+    host = HostEnvModel(robot, HipStepper(robot, n, env_seed), n, env_seed, max_len, True, True, True)
+    obs0 = vec.reset()
+    host.goal = host.draw(np.ones(n, bool))
+    nq = desc.n_q
+    assert obs0.shape == (n, 3 * nq) and not obs0[:, :2 * nq].any() and np.array_equal(obs0[:, 2 * nq:], host.goal)
+    rng = np.random.default_rng(1)
+    n_done = 0
+    for t in range(22):
+        a = rng.uniform(-1, 1, (n, desc.n_t)).astype(np.float32)
+        obs, rew, done, _ = vec.step(a)
+        h_obs, h_rew, h_done, margin = host.step(a)
+        assert np.array_equal(done, h_done) or (margin[done != h_done] < 1e-5).all()
+        assert (done == h_done).all()
+        assert np.array_equal(obs, h_obs.astype(np.float32))
+        np.testing.assert_allclose(rew, h_rew, rtol=3e-5, atol=3e-4)
+        n_done += int(done.sum())
+    assert n_done >= 2 * n
+    st = vec.stats()
+    assert st["n_env_steps"] == 22 * n and st["n_episodes"] == n_done
+    vec.close(); host.stepper.close()
