@@ -236,3 +236,41 @@ def test_ppo_on_the_upper_body_with_the_fused_kernels():
     assert all(np.isfinite(v) for v in stats.values())
     assert any((p.detach() - b).abs().max() > 0 for p, b in zip(agent.policy.parameters(), before))
     env.close()
+
+
+def _fused_rank(rank, world, port, out_dir):
+    import os
+    import torch
+    import torch.distributed as dist
+    from gym_roboy_amd.envs.robots import MsjRobot
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    from gym_roboy_amd.ppo import PPO
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    env = RoboyVecEnv(MsjRobot(), 256, seed=0, env_id_offset=256 * rank)
+    agent = PPO(env, n_steps=8, seed=5, dist=dist, reward_scale=0.01, fused_policy=True, fused_update=True)
+    roll = agent.collect()
+    agent.update(roll)
+    torch.cuda.synchronize()
+    torch.save({"params": [p.detach().cpu() for p in agent.policy.parameters()], "act": roll["act"].cpu()},
+               os.path.join(out_dir, "r%d.pt" % rank))
+    env.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_the_fused_kernels_stay_in_step(tmp_path):
+    """Two ranks (both on the one GPU, gradients averaged over gloo) with fused_policy / fused_update: different
+    exploration noise and env shards per rank, identical parameters after the update (the gradient views of
+    FusedPolicyGrad go through average_gradients like torch's)."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    mp.spawn(_fused_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert (a["act"] - b["act"]).abs().max() > 0.1                     # own noise per rank
+    for p, q in zip(a["params"], b["params"]):
+        assert torch.equal(p, q)
+    assert all(torch.isfinite(p).all() for p in a["params"])
