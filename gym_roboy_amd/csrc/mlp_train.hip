@@ -434,9 +434,18 @@ mlp_grad_kernel(const TrainArgs a) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ls += __shfl_xor(ls, off, 64);
     if (lane == 0) P[g.loss] = ls;
+    // the workgroup's waves fold their partials into wave 0's (fixed order: bit-reproducible), so the reduction
+    // kernel reads one partial per workgroup instead of one per wave
+    __syncthreads();
+    float *P0 = a.partials + long(blockIdx.x) * nw * a.gstride;
+    for (int k = threadIdx.x; k < a.gstride; k += blockDim.x) {
+        float v = P0[k];
+        for (int w = 1; w < nw; ++w) v += P0[w * a.gstride + k];
+        P0[k] = v;
+    }
 }
 
-// out[k] = sum over the waves' partials
+// out[k] = sum over the partials (one per workgroup, `gstride` apart)
 __global__ void reduce_partials_kernel(const float *__restrict__ partials, int n_waves, int gstride, int n, float *__restrict__ out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -601,7 +610,7 @@ int rp_ppo_grad_dev(const float *d_packed_train, const float *d_obs, const float
     if (rc) return rc;
     for (int net = 0; net < 2; ++net) {
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((gs + 255) / 256), dim3(256), 0, st, d_workspace + net * waves * gs,
-                           int(waves), gs, gs, d_grad + net * gs);
+                           int(blocks), WAVES_PER_BLOCK * gs, gs, d_grad + net * gs);       // one folded partial per workgroup
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RP_EHIP, std::string("reduce_partials_kernel: ") + hipGetErrorString(e));
