@@ -130,17 +130,24 @@ mlp_act_kernel(const float *__restrict__ packed, const float *__restrict__ obs, 
     const int col = lane & 31, half = lane >> 5;
     const float onehot = half ? 0.0f : 1.0f;
     const long n_tiles = (n + 63) / 64;
-    for (long tile = long(blockIdx.x) * nw + wave; tile < n_tiles; tile += long(gridDim.x) * nw) {
+    // work item = (tile, net): the two nets of a tile share nothing but the observation, so they go to different
+    // waves - twice the items, half the dependent MFMA chain per item (what a small batch waits for: 4 096 samples are
+    // 64 tiles for 1 024 SIMDs)
+    for (long item = long(blockIdx.x) * nw + wave; item < 2 * n_tiles; item += long(gridDim.x) * nw) {
+        const long tile = item >> 1;
         long s0 = tile * 64 + col, s1 = s0 + 32;                    // this lane's samples in column tile 0 / 1
         s0 = s0 < n ? s0 : n - 1; s1 = s1 < n ? s1 : n - 1;         // past the end: shadow the last sample
         const float *x0 = obs + s0 * obs_dim, *x1 = obs + s1 * obs_dim;
-        f32x16 ypi[2][2], yvf[2][2];
-        net_forward(lds, L, 1, 1, lane, onehot, x0, x1, obs_dim, yvf);          // the value net
-        const float val = yvf[0][0][0];                                          // value = row 0 of its output tile
-        net_forward(lds, L, 0, L.ot_pi, lane, onehot, x0, x1, obs_dim, ypi);    // the action-mean net
-        // ---- epilogue: this lane's sample ----
         const long i = tile * 64 + lane;
         const bool live = i < n;
+        f32x16 ypi[2][2];
+        if (item & 1) {                                              // the value net
+            net_forward(lds, L, 1, 1, lane, onehot, x0, x1, obs_dim, ypi);
+            if (live) value[i] = ypi[0][0][0];                       // row 0 of its output tile
+            continue;
+        }
+        net_forward(lds, L, 0, L.ot_pi, lane, onehot, x0, x1, obs_dim, ypi);    // the action-mean net
+        // ---- epilogue: this lane's sample ----
         float lp = -0.91893853320467274f * float(act_dim);          // -1/2 log(2 pi) per dimension
         float *arow = act + (live ? i : 0) * act_dim, *mrow = mean_out ? mean_out + (live ? i : 0) * act_dim : nullptr;
         const uint64_t gid = sample_offset + uint64_t(i);
@@ -179,7 +186,7 @@ mlp_act_kernel(const float *__restrict__ packed, const float *__restrict__ obs, 
                         }
                     }
                 }
-        if (live) { logp[i] = lp; value[i] = val; }
+        if (live) logp[i] = lp;
     }
 }
 
@@ -256,7 +263,7 @@ int rp_act_dev(const float *d_packed, const float *d_obs, float *d_act, float *d
     const long n_tiles = (n + 63) / 64;
     // 4 waves per workgroup (one per SIMD), two workgroups per CU, persistent over tiles; 6-wave workgroups spread
     // unevenly over the 4 SIMDs and were slower (107 against 78 us at 262 144 samples)
-    long blocks = (n_tiles + 3) / 4;
+    long blocks = (2 * n_tiles + 3) / 4;             // items = (tile, net)
     if (blocks > 2 * n_cu) blocks = 2 * n_cu;
     hipLaunchKernelGGL(mlp_act_kernel, dim3(unsigned(blocks)), dim3(256), lds, static_cast<hipStream_t>(stream), d_packed,
                        d_obs, d_act, d_logp, d_value, d_mean, long(n), obs_dim, act_dim, seed, sample_offset, step,
