@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 #include "msj_math.hpp"
 
@@ -95,19 +96,17 @@ inline bool enabled() {
     return !(e && e[0] == '0');
 }
 
-// compile and load; false (with a message) if anything along the way is not available
-inline bool build(const rb::MsjConst<float, 8> &c, Module &out, std::string &why) {
+// Compile `src` with hiprtc for the current device, load the code object and look up the kernels `names`
+// (C++ name expressions, e.g. template instances); false (with a message) if anything along the way is not
+// available.  A failed compilation also prints the head of the hiprtc log to stderr, once per process: a lost
+// specialisation must not go unnoticed in a bench run.
+inline bool compile_and_load(const std::string &src, const char *file_name, const char *const *names, int nk,
+                             hipModule_t &mod, hipFunction_t **slots, std::string &why) {
     const Rtc &r = rtc();
     if (!r.ok) { why = "hiprtc is not available"; return false; }
-    const std::string src = "#define RB_JIT_TABLE " + table_text(c) + "\n#include \"msj_kernels.hpp\"\n";
     hiprtcProgram prog = nullptr;
-    if (r.create(&prog, src.c_str(), "roboy_msj_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { why = "hiprtcCreateProgram failed"; return false; }
-    constexpr int NK = 6;
-    const char *names[NK] = {"rbk::msj_step_env_per_lane<0, 256, 4, true>", "rbk::msj_step_env_per_lane<1, 256, 4, true>",
-                             "rbk::msj_env_step_kernel<0, 256, 4, rbk::Const8, true>",
-                             "rbk::msj_env_step_kernel<1, 256, 4, rbk::Const8, true>",
-                             "rbk::msj_rollout_fused<0, 256, 4, true>", "rbk::msj_rollout_fused<1, 256, 4, true>"};
-    for (const char *n : names) r.add_name(prog, n);
+    if (r.create(&prog, src.c_str(), file_name, 0, nullptr, nullptr) != HIPRTC_SUCCESS) { why = "hiprtcCreateProgram failed"; return false; }
+    for (int k = 0; k < nk; ++k) r.add_name(prog, names[k]);
     const std::string inc = "-I" + library_dir();
     int dev = 0;
     hipDeviceProp_t prop;
@@ -124,6 +123,8 @@ inline bool build(const rb::MsjConst<float, 8> &c, Module &out, std::string &why
         std::string log(n, '\0');
         if (n) r.log(prog, &log[0]);
         why = "hiprtc compilation failed: " + log.substr(0, 600);
+        static bool reported = false;
+        if (!reported) { reported = true; std::fprintf(stderr, "roboy_sim: %s: %s\n", file_name, why.c_str()); }
         r.destroy(&prog);
         return false;
     }
@@ -131,22 +132,34 @@ inline bool build(const rb::MsjConst<float, 8> &c, Module &out, std::string &why
     r.code_size(prog, &n);
     std::string code(n, '\0');
     r.code(prog, &code[0]);
-    std::string lowered[NK];
-    for (int k = 0; k < NK; ++k) {
+    std::vector<std::string> lowered(nk);
+    for (int k = 0; k < nk; ++k) {
         const char *low = nullptr;
         if (r.lowered(prog, names[k], &low) != HIPRTC_SUCCESS || !low) { why = "hiprtcGetLoweredName failed"; r.destroy(&prog); return false; }
         lowered[k] = low;
     }
     r.destroy(&prog);
-    if (hipModuleLoadData(&out.mod, code.data()) != hipSuccess) { why = "hipModuleLoadData failed"; out.mod = nullptr; return false; }
-    hipFunction_t *slots[NK] = {&out.step[0], &out.step[1], &out.env[0], &out.env[1], &out.rollout[0], &out.rollout[1]};
-    for (int k = 0; k < NK; ++k)
-        if (hipModuleGetFunction(slots[k], out.mod, lowered[k].c_str()) != hipSuccess) {
+    if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { why = "hipModuleLoadData failed"; mod = nullptr; return false; }
+    for (int k = 0; k < nk; ++k)
+        if (hipModuleGetFunction(slots[k], mod, lowered[k].c_str()) != hipSuccess) {
             why = "hipModuleGetFunction failed for " + lowered[k];
-            (void)hipModuleUnload(out.mod);
-            out = Module();
+            (void)hipModuleUnload(mod);
+            mod = nullptr;
             return false;
         }
+    return true;
+}
+
+// the env-per-lane ball-joint kernels on this robot's constants
+inline bool build(const rb::MsjConst<float, 8> &c, Module &out, std::string &why) {
+    const std::string src = "#define RB_JIT_TABLE " + table_text(c) + "\n#include \"msj_kernels.hpp\"\n";
+    constexpr int NK = 6;
+    const char *names[NK] = {"rbk::msj_step_env_per_lane<0, 256, 4, true>", "rbk::msj_step_env_per_lane<1, 256, 4, true>",
+                             "rbk::msj_env_step_kernel<0, 256, 4, rbk::Const8, true>",
+                             "rbk::msj_env_step_kernel<1, 256, 4, rbk::Const8, true>",
+                             "rbk::msj_rollout_fused<0, 256, 4, true>", "rbk::msj_rollout_fused<1, 256, 4, true>"};
+    hipFunction_t *slots[NK] = {&out.step[0], &out.step[1], &out.env[0], &out.env[1], &out.rollout[0], &out.rollout[1]};
+    if (!compile_and_load(src, "roboy_msj_jit.hip", names, NK, out.mod, slots, why)) { out = Module(); return false; }
     return true;
 }
 

@@ -8,8 +8,10 @@
 // (scalar loads -> SGPRs), or folded into the code: MsjRobot's table ahead of time
 // (msj_baked.hpp), any other 8-tendon robot's by hiprtc at run time (msj_jit.hpp);
 // LDS holds only what is indexed at run time (the set-points of the rolled tendon
-// loop).  Generic joint trees: two envs per wave, eight lanes per link, working
-// set in LDS (tree_aba.hpp).  DESIGN.md §4-§5.
+// loop).  Generic joint trees: one env per lane running straight-line code generated
+// for the robot (tree_lane_gen.hpp, tree_lane.hpp: the committed upper body ahead of
+// time, other robots by hiprtc) or, without that specialisation, two envs per wave,
+// eight lanes per link, working set in LDS (tree_aba.hpp).  DESIGN.md §4-§5.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -23,6 +25,14 @@
 #include "msj_kernels.hpp"
 #include "msj_jit.hpp"
 #include "tree_aba.hpp"
+// env-per-lane form of the joint-tree kernels: generated per robot (tree_lane_gen.hpp); the committed upper body's
+// instances are compiled here ahead of time, any other robot's by hiprtc (tree_lane_jit.hpp)
+#include "tree_lane_defs.hpp"
+#define RBL_NS rbl_baked
+#include "tree_lane_baked.hpp"
+#include "tree_lane.hpp"
+#undef RBL_NS
+#include "tree_lane_jit.hpp"
 
 namespace {
 
@@ -67,6 +77,11 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // (U = 2 / 4 / 8: RK4 16.96 / 16.63 / 16.77 us, Euler 2M 36.9 / 35.2 / 35.3 us)
 #ifndef RB_BAKED_UNROLL
 #define RB_BAKED_UNROLL 4
+#endif
+// joint-tree robots without ahead-of-time instances: AUTO builds the env-per-lane kernels with hiprtc (~10 s each)
+// from this many envs on (ROBOY_SIM_JIT=2: at any batch size, =0: never); below it the octet kernels run
+#ifndef RB_TREE_JIT_BATCH
+#define RB_TREE_JIT_BATCH 16384
 #endif
 using namespace rbk;    // the env-per-lane kernels (msj_kernels.hpp), EnvParams, GoalBox, ...
 
@@ -341,6 +356,12 @@ struct rb_sim {
     rbt::TreeHost tree_host;
     uint32_t *d_tree_words = nullptr;   // the robot tables, staged into LDS by every workgroup
     int tree_waves = 1;                 // waves per workgroup
+    // env-per-lane form of the joint-tree kernels (tree_lane.hpp): the text generated for this robot, whether it is
+    // the text the library's ahead-of-time instances were compiled from, and the hiprtc-built kernels otherwise
+    rblg::Generated lane_gen;
+    bool lane_ok = false;               // lane_gen is valid (the generator supports the robot)
+    bool lane_baked = false;
+    rblj::Kernel lane_step_k, lane_env_k;
     GoalBox box;
     hipStream_t own_stream = nullptr, stream = nullptr;
     float *d_q = nullptr, *d_qd = nullptr;
@@ -372,10 +393,56 @@ namespace {
 
 // Build the run-time specialised kernels of this robot once, outside any stream capture (hipModuleLoadData
 // is not capturable): called by the entry points before they launch or capture.
+// A stream that is being captured must not see the build: the attempt is left for a later call (the state stays
+// "not tried") and this call launches the instances it already has.
+bool capturing(rb_sim *s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return s->stream && hipStreamIsCapturing(s->stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
+int jit_level() {      // ROBOY_SIM_JIT: 0 = never, 1 (default) = from the batch thresholds on, 2 = at any batch size
+    const char *e = std::getenv("ROBOY_SIM_JIT");
+    return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
+}
+
+// does this handle run the env-per-lane form of the joint-tree kernels?  (explicit choice, or AUTO with instances at hand /
+// worth building)
+bool tree_wants_lane(const rb_sim *s) {
+    if (!s->tree || !s->lane_ok || s->kernel_choice == RB_KERNEL_ENV_PER_WAVE) return false;
+    if (s->kernel_choice == RB_KERNEL_ENV_PER_LANE || s->lane_baked) return true;
+    const int lvl = jit_level();
+    return lvl == 2 || (lvl == 1 && s->n >= RB_TREE_JIT_BATCH);
+}
+
+// kind: 0 = step, 1 = env step.  The kernel to launch, or nullptr for the ahead-of-time instances / the octet kernels.
+rblj::Kernel *lane_kernel(rb_sim *s, int kind) {
+    rblj::Kernel &k = kind == 0 ? s->lane_step_k : s->lane_env_k;
+    if (k.state == 0 && !s->lane_baked && tree_wants_lane(s) && !capturing(s) && hipSetDevice(s->device) == hipSuccess) {
+        if (!rblj::build(s->lane_gen, kind, s->integrator == RB_EULER ? 0 : 1, k)) s->jit_why = k.why;
+        else {
+            // a workgroup is one wave; more than 64 KiB of dynamic LDS (robots with many joints) has to be granted
+            const size_t lds = rblg::lane_lds_bytes_per_wave(s->lane_gen);
+            if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(k.fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) {
+                k.state = -1; s->jit_why = k.why = "LDS region of the lane kernel not granted";
+            }
+        }
+    }
+    return &k;
+}
+// true if this call runs the lane form (ahead-of-time or built instances)
+bool tree_use_lane(rb_sim *s, int kind) {
+    bool lane = tree_wants_lane(s);
+    if (lane && !s->lane_baked) lane = lane_kernel(s, kind)->state == 1;
+    s->kernel = lane ? RB_KERNEL_ENV_PER_LANE : RB_KERNEL_ENV_PER_WAVE;     // what rb_info reports
+    return lane;
+}
+
 void maybe_jit(rb_sim *s) {
+    if (s->tree) { if (tree_wants_lane(s) && !s->lane_baked) (void)lane_kernel(s, 0); return; }
     if (s->jit_state != 0) return;
+    if (s->ntx || s->baked || s->n <= RB_SMALL_BATCH || !rbj::enabled() || jit_level() == 0) { s->jit_state = -1; return; }
+    if (capturing(s)) return;                     // try again outside the capture
     s->jit_state = -1;
-    if (s->tree || s->ntx || s->baked || s->n <= RB_SMALL_BATCH || !rbj::enabled()) return;
     if (hipSetDevice(s->device) != hipSuccess) return;
     if (rbj::build(s->c8, s->jit, s->jit_why)) s->jit_state = 1;
 }
@@ -394,7 +461,27 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale) {
 #define RB_STEP_LAUNCH_BK(INTEG, B, U)                                                                \
     hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U, true>), dim3(blocks_for(n, B)), dim3(B), 0, \
                        s->stream, s->c8, s->d_q, s->d_qd, s->d_feas, d_act, us, n)
-    if (s->tree) {
+    if (s->tree && tree_use_lane(s, 0)) {
+        // one wave (64 envs) per workgroup: the LDS regions admit four per CU, one per SIMD, and a small batch spreads over the CUs
+        const unsigned waves = blocks_for(n, 64);
+        const size_t lds = rblg::lane_lds_bytes_per_wave(s->lane_gen);
+        const float h = s->tree_host.dev.h;
+        const int nsub = s->tree_host.dev.nsub;
+        if (s->lane_baked) {
+            if (s->integrator == RB_EULER)
+                hipLaunchKernelGGL(rbl_baked::tree_lane_step<0>, dim3(waves), dim3(64), lds, s->stream, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, h, nsub, n);
+            else
+                hipLaunchKernelGGL(rbl_baked::tree_lane_step<1>, dim3(waves), dim3(64), lds, s->stream, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, h, nsub, n);
+        } else {
+            float *q = s->d_q, *qd = s->d_qd;
+            uint32_t *feas = s->d_feas;
+            float hh = h;
+            int ns = nsub;
+            long nn = n;
+            void *args[] = {&q, &qd, &feas, &d_act, &act_scale, &hh, &ns, &nn};
+            RB_HIP(hipModuleLaunchKernel(s->lane_step_k.fn, waves, 1, 1, 64, 1, 1, unsigned(lds), s->stream, args, nullptr));
+        }
+    } else if (s->tree) {
         const int wv = s->tree_waves;
         const size_t lds = rbt::tree_lds_bytes(s->tree_host, wv);
         const long per_block = long(wv) * rbt::TREE_E;
@@ -518,7 +605,12 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
         // not a ball-joint robot: the generic joint-tree kernel (one env per wave)
         std::string why_tree;
         rc = rbt::tree_build(robot, step_size, n_substeps, s->tree_host, why_tree);
-        if (rc == RB_OK) s->tree = true;
+        if (rc == RB_OK) {
+            s->tree = true;
+            std::string why_gen;
+            s->lane_ok = rblg::generate(robot, true, s->lane_gen, why_gen) == RB_OK;
+            s->lane_baked = s->lane_ok && s->lane_gen.hash == RBL_TEXT_HASH && rblg::lane_lds_slots(s->lane_gen) == rbl_baked::LDS_SLOTS;
+        }
         else why = "not a ball-joint robot (" + why + ") and not a supported joint tree (" + why_tree + ")";
     }
     if (rc != RB_OK) {
@@ -605,6 +697,7 @@ void rb_destroy(rb_sim *s) {
     if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
     for (auto &kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     rbj::unload(s->jit);
+    rblj::unload(s->lane_step_k); rblj::unload(s->lane_env_k);
     (void)hipFree(s->d_q); (void)hipFree(s->d_qd); (void)hipFree(s->d_feas);
     (void)hipFree(s->d_goal_count); (void)hipFree(s->d_rows); (void)hipFree(s->d_u8); (void)hipFree(s->d_ten);
     (void)hipFree(s->d_tree_words);
@@ -659,6 +752,13 @@ int rb_debug_tree_fetch(rb_sim *s, float *out, int n_floats, rbt::TreeDev *dev_o
 
 int rb_specialization(rb_sim *s) {
     if (check(s)) return -1;
+    if (s->tree) {
+        if (!tree_wants_lane(s)) { g_err = s->lane_ok ? "the octet kernels are selected (batch below the build threshold, or by choice)" : "no generator for this robot"; return RB_SPEC_NONE; }
+        if (s->lane_baked) return RB_SPEC_TABLE;
+        if (lane_kernel(s, 0)->state == 1) return RB_SPEC_JIT;
+        g_err = s->lane_step_k.why;
+        return RB_SPEC_NONE;
+    }
     if (s->baked) return RB_SPEC_TABLE;
     if (s->jit_state == 0) maybe_jit(s);
     if (s->jit_state == 1) return RB_SPEC_JIT;
@@ -671,9 +771,21 @@ int rb_select_kernel(rb_sim *s, int kernel) {
     if (kernel < RB_KERNEL_AUTO || kernel > RB_KERNEL_ENV_PER_WAVE) return fail(RB_EINVAL, "unknown kernel variant");
     s->kernel_choice = kernel;
     if (s->tree) {
-        if (kernel != RB_KERNEL_AUTO && kernel != RB_KERNEL_ENV_PER_WAVE)
-            return fail(RB_EUNSUPPORTED, "joint-tree robots only have the env-per-wave kernel");
-        s->kernel = RB_KERNEL_ENV_PER_WAVE;
+        if (kernel == RB_KERNEL_TENDON_PER_LANE) return fail(RB_EUNSUPPORTED, "joint-tree robots have no tendon-per-lane kernel");
+        if (kernel == RB_KERNEL_ENV_PER_LANE && !s->lane_ok) return fail(RB_EUNSUPPORTED, "no env-per-lane kernel can be generated for this robot");
+        if (!s->graphs.empty()) { RB_HIP(hipSetDevice(s->device)); RB_HIP(hipStreamSynchronize(s->stream)); }
+        for (auto &kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
+        s->graphs.clear();
+        s->kernel_choice = kernel;
+        if (kernel == RB_KERNEL_ENV_PER_LANE && !s->lane_baked) {
+            // an explicit choice builds the step kernel now (and fails loudly if that is not possible)
+            if (capturing(s)) return fail(RB_EINVAL, "the env-per-lane kernels cannot be built during a stream capture");
+            if (lane_kernel(s, 0)->state != 1) {
+                s->kernel_choice = RB_KERNEL_AUTO;
+                return fail(RB_EUNSUPPORTED, "env-per-lane kernel not available: " + s->lane_step_k.why);
+            }
+        }
+        s->kernel = tree_wants_lane(s) ? RB_KERNEL_ENV_PER_LANE : RB_KERNEL_ENV_PER_WAVE;
         return RB_OK;
     }
     if (kernel == RB_KERNEL_ENV_PER_WAVE) return fail(RB_EUNSUPPORTED, "ball-joint robots have no env-per-wave kernel");
@@ -929,6 +1041,9 @@ int rb_env_configure(rb_sim *s, const rb_env_config *cfg) {
     RB_HIP(hipMemsetAsync(s->d_infeas_n, 0, sizeof(uint32_t) * size_t(s->n), s->stream));
     s->env_steps = 0.0;
     s->env_ready = true;
+    // the run-time specialised kernels are built here, outside any capture a caller may wrap around its first step
+    maybe_jit(s);
+    if (s->tree && tree_wants_lane(s) && !s->lane_baked) (void)lane_kernel(s, 1);
     return rb_env_reset_dev(s, nullptr);
 }
 
@@ -968,6 +1083,32 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
     if (!s->env_ready) return fail(RB_EINVAL, "rb_env_configure has not been called");
     if (!s->tree && reinterpret_cast<uintptr_t>(d_act) % 16) return fail(RB_EINVAL, "action slab must be 16-byte aligned");
     const long n = s->n;
+    if (s->tree && tree_use_lane(s, 1)) {
+        const unsigned waves = blocks_for(n, 64);
+        const size_t lds = rblg::lane_lds_bytes_per_wave(s->lane_gen);
+        const float h = s->tree_host.dev.h;
+        const int nsub = s->tree_host.dev.nsub;
+#define RB_LANE_ENV_ARGS s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, s->d_ep_ret, s->d_goal_count, d_act, \
+                         d_obs, d_reward, d_done, s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, h, nsub, n, s->seed, uint64_t(s->env0)
+        if (s->lane_baked) {
+            if (s->integrator == RB_EULER) hipLaunchKernelGGL(rbl_baked::tree_lane_env_step<0>, dim3(waves), dim3(64), lds, s->stream, RB_LANE_ENV_ARGS);
+            else hipLaunchKernelGGL(rbl_baked::tree_lane_env_step<1>, dim3(waves), dim3(64), lds, s->stream, RB_LANE_ENV_ARGS);
+        } else {
+            EnvParams ep = s->env;
+            GoalBox box = s->box;
+            float hh = h;
+            int ns = nsub;
+            long nn = n;
+            uint64_t seed = s->seed, env0 = uint64_t(s->env0);
+            void *args[] = {&ep, &box, &s->d_q, &s->d_qd, &s->d_feas, &s->d_goal, &s->d_step_num, &s->d_ep_ret, &s->d_goal_count, &d_act,
+                            &d_obs, &d_reward, &d_done, &s->d_ep_sum, &s->d_ep_cnt, &s->d_infeas_n, &hh, &ns, &nn, &seed, &env0};
+            RB_HIP(hipModuleLaunchKernel(s->lane_env_k.fn, waves, 1, 1, 64, 1, 1, unsigned(lds), s->stream, args, nullptr));
+        }
+#undef RB_LANE_ENV_ARGS
+        RB_HIP(hipGetLastError());
+        s->env_steps += double(n);
+        return RB_OK;
+    }
     if (s->tree) {
         const int wv = s->tree_waves;
         const size_t lds = rbt::tree_lds_bytes(s->tree_host, wv);

@@ -9,6 +9,7 @@ typedef int int32_t;
 typedef unsigned int uint32_t;
 typedef long long int64_t;
 typedef unsigned long long uint64_t;
+typedef __UINTPTR_TYPE__ uintptr_t;
 namespace std {
 template <class A, class B> struct is_same { static constexpr bool value = false; };
 template <class A> struct is_same<A, A> { static constexpr bool value = true; };

@@ -1,0 +1,305 @@
+// tree_lane.hpp - env-per-lane kernels for joint-tree robots around a GENERATED acceleration function.
+//
+// Included after the text tree_lane_gen.hpp writes for one robot (RBL_NS, RBL_NQ, RBL_NT, RBL_ACCEL_LDS, the
+// tables KSG / QLO / QHI / VMAX and RBL_NS::rbl_accel): by roboy_sim.hip for the committed upper body
+// (tree_lane_baked.hpp) and by hiprtc for any other robot (tree_lane_jit.hpp).  One lane owns one env for the
+// whole step; a wave owns 64 consecutive envs.
+//
+//   * Registers: a workgroup is one wave (64 threads) and may use the whole 512-entry VGPR + AGPR file of a SIMD
+//     (one wave per SIMD, four workgroups per CU by their LDS regions); the acceleration's live set (~450 values
+//     on the upper body) stays on chip.
+//   * LDS: RBL_ACCEL_LDS lane-private slots for values the acceleration parks between its sweeps, plus
+//     2 RBL_NQ slots for the RK4 accumulators.  Slot s of lane l is word s * 64 + l of the wave's region:
+//     every access is conflict-free and needs no address arithmetic beyond the immediate offset.
+//   * HBM: the state rows q[n][n_q], qd[n][n_q], the action rows [n][n_t] (and goal / observation rows in the
+//     env-layer kernel) are env-major, as the octet kernels of tree_aba.hpp keep them.  A wave moves its 64
+//     rows as one contiguous run with coalesced dword accesses and transposes it through the (then idle) LDS
+//     region; nothing the step needs again later is kept in registers across the acceleration - it is read
+//     again (the rows are L2-resident), which is what keeps the RK4 stages inside the register budget.
+// Algorithmic HBM bytes per env step: 4 (4 n_q + n_t + 1), as for every kernel of the library.
+#pragma once
+#include "env_common.hpp"
+#include "philox.hpp"
+
+#ifndef RBL_NS
+#error "include the generated robot header (tree_lane_gen.hpp) first"
+#endif
+
+namespace RBL_NS {
+
+struct LaneLds {
+    float *p;   // the wave's region + lane
+    __device__ __forceinline__ float &operator()(int slot) const { return p[slot * 64]; }
+};
+
+constexpr int STAGE_SLOTS = 3 * RBL_NQ > RBL_NT ? 3 * RBL_NQ : RBL_NT;                   // widest row (set) a wave transposes
+constexpr int REGION_SLOTS = RBL_ACCEL_LDS > STAGE_SLOTS ? RBL_ACCEL_LDS : STAGE_SLOTS;  // acceleration slots, aliased by the transposes
+constexpr int ACC_SLOT = REGION_SLOTS;                                                   // RK4 accumulators: qa at ACC_SLOT + j, va at ACC_SLOT + NQ + j
+constexpr int LDS_SLOTS = REGION_SLOTS + 2 * RBL_NQ;
+constexpr int LDS_BYTES_PER_WAVE = LDS_SLOTS * 64 * 4;
+
+__device__ __forceinline__ void lane_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The rows of a wave as a buffer resource: base = the wave's first row, records = the bytes of its live rows.  A load
+// past the end returns 0 and a store past the end is dropped by the range check, so neither needs a guard: a guarded
+// load is a branch with its own s_waitcnt vmcnt(0), and W of those in a row cost W memory latencies with nothing else
+// on the SIMD to cover them (measured: 63 % of a wave's cycles), and one 64-bit address pair per load.  The
+// descriptor is built from readfirstlane'd values (the wave index comes from threadIdx, which the compiler cannot
+// prove uniform: cdna_hip_programming.md T20).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const float *g, long env0, int width, int live) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(g + env0 * width);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(a)), hi = __builtin_amdgcn_readfirstlane(uint32_t(a >> 32));
+    const int bytes = __builtin_amdgcn_readfirstlane(live * width * 4);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>((uintptr_t(hi) << 32) | lo), 0, bytes, 0x00020000);
+}
+
+// The lane index as a value the optimiser cannot trace: the LDS addresses derived from it are then recomputed where
+// they are used (a few integer adds) instead of being hoisted out of the stage / substep loops as loop invariants -
+// two dozen registers held across the acceleration, which is where the kernel has none to spare (they were spilled
+// to scratch and reloaded inside the loop, each reload a full memory latency with nothing to cover it).
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// Nothing moves across this point, neither in the optimiser (memory accesses) nor in the instruction scheduler: what
+// follows the acceleration (accumulator slots, row loads) must not be started before it, into its register budget.
+__device__ __forceinline__ void fence_code() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// rows [64][W] of a wave, env-major in HBM -> out[W] of each lane.  live = envs of this wave inside the batch;
+// a lane past the end shadows the last live env.  All W loads are issued before the first one is waited for.
+template <int W>
+__device__ __forceinline__ void load_rows(const float *__restrict__ g, long env0, int live, float *region, int lane_, float (&out)[W]) {
+    const int lane = opaque(lane_);
+    const __amdgpu_buffer_rsrc_t r = rows_rsrc(g, env0, W, live);
+    float t[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) t[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, k * 256, 0));
+#pragma unroll
+    for (int k = 0; k < W; ++k) region[k * 64 + lane] = t[k];
+    lane_wave_sync();
+    const int row = (lane < live ? lane : live - 1) * W;
+#pragma unroll
+    for (int j = 0; j < W; ++j) out[j] = region[row + j];
+    lane_wave_sync();
+}
+// two row sets of the same width at once (q and qd): all 2 W loads are in flight together
+template <int W>
+__device__ __forceinline__ void load_rows2(const float *__restrict__ ga, const float *__restrict__ gb, long env0, int live, float *region,
+                                           int lane_, float (&oa)[W], float (&ob)[W]) {
+    const int lane = opaque(lane_);
+    const __amdgpu_buffer_rsrc_t ra = rows_rsrc(ga, env0, W, live), rb = rows_rsrc(gb, env0, W, live);
+    float ta[W], tb[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        ta[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, lane * 4, k * 256, 0));
+        tb[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, k * 256, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) { region[k * 64 + lane] = ta[k]; region[(W + k) * 64 + lane] = tb[k]; }
+    lane_wave_sync();
+    const int row = (lane < live ? lane : live - 1) * W;
+#pragma unroll
+    for (int j = 0; j < W; ++j) { oa[j] = region[row + j]; ob[j] = region[W * 64 + row + j]; }
+    lane_wave_sync();
+}
+template <int W>
+__device__ __forceinline__ void store_rows(float *__restrict__ g, long env0, int live, float *region, int lane_, const float (&in)[W]) {
+    const int lane = opaque(lane_);
+#pragma unroll
+    for (int j = 0; j < W; ++j) region[lane * W + j] = in[j];
+    lane_wave_sync();
+    const __amdgpu_buffer_rsrc_t r = rows_rsrc(g, env0, W, live);
+#pragma unroll
+    for (int k = 0; k < W; ++k) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(region[k * 64 + lane]), r, lane * 4, k * 256, 0);
+    lane_wave_sync();
+}
+
+__device__ __forceinline__ float sat(float v, int j) { return __builtin_amdgcn_fmed3f(v, -VMAX[j], VMAX[j]); }
+
+// One env step of this lane's env: n_sub integrator substeps with the activation offsets held; velocity saturation
+// and joint limits as in tree_aba.hpp tree_integrate.  State in and out through the HBM rows (in place).  Returns
+// false if a joint hit a limit.  On return q / v hold the new state.
+// `load_spu(spu)` fetches the activation offsets of the step (action row x scale): called again before every
+// acceleration rather than held across it (38 registers on the upper body, which the stage loop would spill).
+template <int INTEG, class SPU>
+__device__ __forceinline__ bool lane_step(float *__restrict__ gq, float *__restrict__ gqd, long env0, int live, float *region,
+                                          const LaneLds &L, int lane, const SPU &load_spu, float h, int nsub,
+                                          float (&q)[RBL_NQ], float (&v)[RBL_NQ]) {
+    bool ok = true;
+    for (int sub = 0; sub < nsub; ++sub) {
+        if (INTEG == 0) {
+            float a[RBL_NQ], spu[RBL_NT];
+            load_rows2<RBL_NQ>(gq, gqd, env0, live, region, lane, q, v);
+            load_spu(spu);
+            fence_code();
+            rbl_accel(q, v, spu, a, L);
+            fence_code();
+            load_rows<RBL_NQ>(gq, env0, live, region, lane, q);        // not kept across the acceleration
+#pragma unroll
+            for (int j = 0; j < RBL_NQ; ++j) { v[j] = sat(v[j] + h * a[j], j); q[j] = q[j] + h * v[j]; }
+        } else {
+            // RK4 with every stage velocity saturated, as a loop over the four stages (one copy of the acceleration
+            // code); the weighted sums live in LDS and accumulate in the order k1 + 2 k2 + 2 k3 + k4
+            const float h6 = h * (1.0f / 6.0f);
+            float kq[RBL_NQ], kv[RBL_NQ];
+#pragma unroll
+            for (int j = 0; j < RBL_NQ; ++j) { kq[j] = 0.0f; kv[j] = 0.0f; L(ACC_SLOT + j) = 0.0f; L(ACC_SLOT + RBL_NQ + j) = 0.0f; }
+#pragma unroll 1
+            for (int st = 0; st < 4; ++st) {
+                const float wgt = (st == 0 || st == 3) ? 1.0f : 2.0f, cst = st == 0 ? 0.0f : (st == 3 ? h : 0.5f * h);
+                float qs[RBL_NQ], spu[RBL_NT];
+                load_rows2<RBL_NQ>(gq, gqd, env0, live, region, lane, q, v);
+                load_spu(spu);
+#pragma unroll
+                for (int j = 0; j < RBL_NQ; ++j) {
+                    qs[j] = q[j] + cst * kq[j];                   // state of this stage ...
+                    kq[j] = sat(v[j] + cst * kv[j], j);            // ... and its (saturated) velocity
+                }
+                // the velocity's share of the sums before the acceleration (nothing but kq and the loop state lives across it)
+#pragma unroll
+                for (int j = 0; j < RBL_NQ; ++j) L(ACC_SLOT + j) += wgt * kq[j];
+                fence_code();
+                rbl_accel(qs, kq, spu, kv, L);
+                fence_code();
+#pragma unroll
+                for (int j = 0; j < RBL_NQ; ++j) L(ACC_SLOT + RBL_NQ + j) += wgt * kv[j];
+            }
+            load_rows2<RBL_NQ>(gq, gqd, env0, live, region, lane, q, v);
+#pragma unroll
+            for (int j = 0; j < RBL_NQ; ++j) { q[j] = q[j] + h6 * L(ACC_SLOT + j); v[j] = v[j] + h6 * L(ACC_SLOT + RBL_NQ + j); }
+        }
+#pragma unroll
+        for (int j = 0; j < RBL_NQ; ++j) {
+            float vv = sat(v[j], j);
+            const bool over = q[j] > QHI[j], under = q[j] < QLO[j];
+            if (over) { q[j] = QHI[j]; vv = fminf(vv, 0.0f); }
+            if (under) { q[j] = QLO[j]; vv = fmaxf(vv, 0.0f); }
+            v[j] = vv;
+            ok = ok && !(over || under);
+        }
+        if (sub + 1 < nsub) {       // the next substep reads the rows again
+            store_rows<RBL_NQ>(gq, env0, live, region, lane, q);
+            store_rows<RBL_NQ>(gqd, env0, live, region, lane, v);
+        }
+    }
+    return ok;
+}
+
+// forward_step_command for a batch: act rows are set-points scaled by act_scale (tree_step_aba's contract)
+template <int INTEG>
+__global__ void __launch_bounds__(64)
+tree_lane_step(float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas, const float *__restrict__ act,
+               float act_scale, float h, int nsub, long n) {
+    extern __shared__ float lds_lane[];
+    const int lane = threadIdx.x;
+    const long env0 = long(blockIdx.x) * 64;      // a workgroup is ONE wave: everything derived from the block index is scalar
+    if (env0 >= n) return;
+    const int live = n - env0 < 64 ? int(n - env0) : 64;
+    float *region = lds_lane;
+    const LaneLds L{region + lane};
+    float qq[RBL_NQ], vv[RBL_NQ];
+    auto load_spu = [&](float (&spu)[RBL_NT]) {
+        load_rows<RBL_NT>(act, env0, live, region, lane, spu);
+#pragma unroll
+        for (int k = 0; k < RBL_NT; ++k) spu[k] = (spu[k] * act_scale) * KSG[k];   // (a product act_scale * KSG[k] would be hoisted out of the substep loop: 38 registers held across the acceleration)
+    };
+    const bool ok = lane_step<INTEG>(q, qd, env0, live, region, L, lane, load_spu, h, nsub, qq, vv);
+    store_rows<RBL_NQ>(q, env0, live, region, lane, qq);
+    store_rows<RBL_NQ>(qd, env0, live, region, lane, vv);
+    if (lane < live) feas[env0 + lane] = ok ? 1u : 0u;
+}
+
+// RoboyEnv.step fused around the step (semantics of tree_env_step_aba / msj_env_step_kernel)
+template <int INTEG>
+__global__ void __launch_bounds__(64)
+tree_lane_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__restrict__ q, float *__restrict__ qd,
+                   uint32_t *__restrict__ feas, float *__restrict__ goal, uint32_t *__restrict__ step_num,
+                   float *__restrict__ ep_ret, uint32_t *__restrict__ goal_count, const float *__restrict__ act,
+                   float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
+                   double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt, uint32_t *__restrict__ infeas_n,
+                   float h, int nsub, long n, uint64_t seed, uint64_t env_id0) {
+    extern __shared__ float lds_lane[];
+    const int lane = threadIdx.x;
+    const long env0 = long(blockIdx.x) * 64;      // a workgroup is ONE wave: everything derived from the block index is scalar
+    if (env0 >= n) return;
+    const int live = n - env0 < 64 ? int(n - env0) : 64;
+    float *region = lds_lane;
+    const LaneLds L{region + lane};
+    float qq[RBL_NQ], vv[RBL_NQ];
+    auto load_spu = [&](float (&spu)[RBL_NT]) {
+        load_rows<RBL_NT>(act, env0, live, region, lane, spu);
+#pragma unroll
+        for (int k = 0; k < RBL_NT; ++k) {
+            // clamp to the action box, then slope * (x - in_high) + out_high with two roundings (roboy_env.py:157-158)
+            const float x = fminf(fmaxf(spu[k], -1.0f), 1.0f);
+            spu[k] = rbe::mul_then_add(ep.slope, x - 1.0f, ep.act_hi) * KSG[k];
+        }
+    };
+    const bool ok = lane_step<INTEG>(q, qd, env0, live, region, L, lane, load_spu, h, nsub, qq, vv);
+    // observation [q | qd | goal], reward, done; goal redraw (and reset) on done
+    float o[3 * RBL_NQ];
+    {
+        float gg[RBL_NQ];
+        load_rows<RBL_NQ>(goal, env0, live, region, lane, gg);
+#pragma unroll
+        for (int j = 0; j < RBL_NQ; ++j) { o[j] = qq[j]; o[RBL_NQ + j] = vv[j]; o[2 * RBL_NQ + j] = gg[j]; }
+    }
+    float dq2 = 0.0f, dv2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < RBL_NQ; ++j) {
+        const float dq = o[j] - o[2 * RBL_NQ + j];
+        dq2 += dq * dq; dv2 += o[RBL_NQ + j] * o[RBL_NQ + j];
+    }
+    const bool mine = lane < live;
+    const long me = env0 + (mine ? lane : live - 1);
+    uint32_t sn = step_num[me] + 1u;
+    bool reached;
+    const float r = rbe::env_reward(ep, dq2, dv2, ok, reached);
+    const bool dn = reached || (sn > uint32_t(ep.max_len));
+    float ret = ep_ret[me] + r;
+    uint32_t fz = ok ? 1u : 0u;
+    float gn[RBL_NQ];                                     // the goal after this step (redrawn on done)
+#pragma unroll
+    for (int j = 0; j < RBL_NQ; ++j) gn[j] = o[2 * RBL_NQ + j];
+    if (dn) {
+        const uint64_t gid = env_id0 + uint64_t(me);
+        uint32_t draw = goal_count[me];
+        auto draw_goals = [&](uint32_t dnum) {
+#pragma unroll
+            for (int b = 0; 4 * b < RBL_NQ; ++b) {
+                const rb::Philox4 rnd = rb::philox_draw(seed, gid, dnum, rb::STREAM_GOALS, uint32_t(b));
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (4 * b + k < RBL_NQ) gn[4 * b + k] = rbe::goal_value(box.lo[4 * b + k], box.hi[4 * b + k], rnd.v[k]);
+            }
+        };
+        draw_goals(draw++);                               // RoboyEnv.step: _set_new_goal (:67-68), AFTER the observation was made (:60)
+        if (ep.auto_reset) {                              // VecEnv worker: env.reset() (:82-87): the reset observation replaces it
+            draw_goals(draw++);
+#pragma unroll
+            for (int j = 0; j < RBL_NQ; ++j) { qq[j] = 0.0f; vv[j] = 0.0f; o[j] = 0.0f; o[RBL_NQ + j] = 0.0f; o[2 * RBL_NQ + j] = gn[j]; }
+        }
+        if (mine) {
+            ep_sum[me] += double(ret); ep_sum[n + me] += double(ret) * double(ret);
+            ep_cnt[me] += 1u; ep_cnt[n + me] += sn - 1u; ep_cnt[2 * n + me] += reached ? 1u : 0u;
+            goal_count[me] = draw;
+        }
+        if (ep.auto_reset) { sn = 1u; fz = 1u; }
+        ret = 0.0f;
+    }
+    // rows back: state, goal (only the lanes that redrew change it), observation
+    store_rows<RBL_NQ>(q, env0, live, region, lane, qq);
+    store_rows<RBL_NQ>(qd, env0, live, region, lane, vv);
+    if (__builtin_amdgcn_ballot_w64(dn && mine) != 0ull) store_rows<RBL_NQ>(goal, env0, live, region, lane, gn);
+    store_rows<3 * RBL_NQ>(obs, env0, live, region, lane, o);
+    if (mine) {
+        feas[me] = fz; step_num[me] = sn; ep_ret[me] = ret; reward[me] = r; done[me] = dn ? 1u : 0u;
+        if (!ok) infeas_n[me] += 1u;
+    }
+}
+
+}  // namespace RBL_NS

@@ -96,14 +96,17 @@ def upper_body():
 
 
 @pytest.mark.parametrize("integrator", ["euler", "rk4"])
-def test_upper_body_full_batch_sample_determinism_permutation(upper_body, integrator):
+@pytest.mark.parametrize("kernel", [1, 3])      # env-per-lane (the library's choice) / octets
+def test_upper_body_full_batch_sample_determinism_permutation(upper_body, integrator, kernel):
     from gym_roboy_amd.envs.simulations import HipBatchSimulation
     from oracle.c_oracle import COracle
     desc = upper_body.get_description()
     n = 8192
     q, qd, sp = _states(desc, n, 7)
     sim = HipBatchSimulation(upper_body, n, integrator=integrator)
-    assert sim.info()["kernel"] == 3
+    assert sim.info()["kernel"] == 1
+    sim.select_kernel(kernel)
+    assert sim.info()["kernel"] == kernel
     sim.set_state(q, qd)
     q1, qd1, f1 = sim.forward_step_command(sp)
     assert np.isfinite(q1).all() and np.isfinite(qd1).all()

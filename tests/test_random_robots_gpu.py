@@ -57,6 +57,38 @@ def test_random_tree_robot_matches_oracle(seed):
     sim.close()
 
 
+@pytest.mark.parametrize("seed", [0, 3, 11, 13])
+def test_random_tree_robot_env_per_lane_kernel_matches_oracle(seed):
+    """The env-per-lane form, generated for the robot and built by hiprtc (an explicit choice: batches this small
+    take the octets on their own), against the same oracle and against the octets."""
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    from oracle.c_oracle import COracle
+    if isinstance(seed, str):
+        robot, desc = random_tree_robot(100 + sorted(EXTREMES).index(seed), **EXTREMES[seed])
+        seed = 100 + sorted(EXTREMES).index(seed)
+    else:
+        robot, desc = random_tree_robot(seed)
+    integrator = "rk4" if seed % 2 else "euler"
+    n = 70                                                     # one full wave and a ragged one
+    q, qd, sp = random_states(desc, n, seed)
+    sim = HipBatchSimulation(robot, n, integrator=integrator)
+    sim.set_state(q, qd)
+    qa, qda, fa = sim.forward_step_command(sp)                 # octets
+    assert sim.info()["kernel"] == 3
+    sim.select_kernel(1)
+    assert sim.info()["kernel"] == 1 and sim.specialization() == "jit"
+    sim.set_state(q, qd)
+    q1, qd1, f1 = sim.forward_step_command(sp)
+    qo, qdo, fo = COracle(desc, "f64").step(q, qd, sp, integrator=0 if integrator == "euler" else 1)
+    tol = tolerance(desc, q, qd, sp)
+    assert np.all(np.abs(q1 - qo) < tol), (desc.n_q, desc.n_t, np.abs(q1 - qo).max())
+    assert np.all(np.abs(qd1 - qdo) < tol), (desc.n_q, desc.n_t, np.abs(qd1 - qdo).max())
+    assert np.all(np.abs(q1 - qa) < 2 * tol) and np.all(np.abs(qd1 - qda) < 2 * tol)
+    near = np.minimum(np.abs(qo - desc.q_lo), np.abs(qo - desc.q_hi)).min(axis=1) < 1e-5
+    assert not np.any((f1 != fo) & ~near)
+    sim.close()
+
+
 def test_random_robot_fused_env_layer_runs_and_matches_plain_step():
     """The fused env kernel of the joint-tree class on a random robot: its physics leg equals the plain step."""
     from gym_roboy_amd.envs.simulations import HipBatchSimulation

@@ -1,0 +1,174 @@
+"""The source generator of the env-per-lane joint-tree kernels (gym_roboy_amd/csrc/tree_lane_gen.hpp), checked
+without a GPU: the text it writes for a robot is compiled with g++ (tests/hostmath/tree_lane_host.cpp supplies the
+host forms of the few device primitives) and its fp32 accelerations are compared with the fp64 oracle
+(oracle/physics_np.py: Jacobian-sum mass matrix, RNE bias, dense solve - an algorithm independent of the generated
+articulated-body code) on the upper body and on seeded random robots: random topologies, arbitrary axes, massless
+links, tendons over the base, over several links and inside one link.  Also: the committed tree_lane_baked.hpp is
+what the generator writes today for the committed upper body."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+BUILD = os.path.join(ROOT, "tests", "_build")
+
+
+def host_accel(desc, tag, lds_c=True):
+    """generate -> g++ -> ctypes; returns (accel(q, qd, sp) -> qdd, (lds_slots, statements))."""
+    import gen_tree_lane_baked as gen
+    os.makedirs(BUILD, exist_ok=True)
+    hdr = os.path.join(BUILD, "lane_%s.hpp" % tag)
+    info = gen.generate(desc, hdr, lds_c)
+    so = os.path.join(BUILD, "liblane_%s.so" % tag)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", '-DRBL_GENERATED="%s"' % hdr,
+                           "-o", so, os.path.join(ROOT, "tests", "hostmath", "tree_lane_host.cpp")])
+    lib = ctypes.CDLL(so)
+    dims = (ctypes.c_int * 3)()
+    lib.tl_dims(dims)
+    assert (dims[0], dims[1]) == (desc.n_q, desc.n_t) and dims[2] == info[0]
+
+    def accel(q, qd, sp):
+        q = np.ascontiguousarray(q, np.float32); qd = np.ascontiguousarray(qd, np.float32)
+        sp = np.ascontiguousarray(sp, np.float32)
+        out = np.zeros_like(q)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        assert lib.tl_accel(p(q), p(qd), p(sp), p(out), q.shape[0]) == 0
+        return out
+    return accel, info
+
+
+def check(desc, tag, n=24, tol=2e-4, lds_c=True):
+    from oracle.physics_np import TendonRobotOracle
+    accel, info = host_accel(desc, tag, lds_c)
+    rng = np.random.default_rng(7)
+    q = rng.uniform(0.9 * desc.q_lo, 0.9 * desc.q_hi, (n, desc.n_q)).astype(np.float32)
+    qd = rng.uniform(-desc.qd_max, desc.qd_max, (n, desc.n_q)).astype(np.float32)
+    sp = rng.uniform(-0.3, 0.3, (n, desc.n_t)).astype(np.float32)
+    ref = TendonRobotOracle(desc).acceleration(q.astype(np.float64), qd.astype(np.float64), sp.astype(np.float64))
+    got = accel(q, qd, sp)
+    # fp32 vs fp64: relative to the size of the accelerations of the env (deep chains with light links have large ones)
+    scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))
+    err = np.abs(got - ref) / scale
+    assert np.isfinite(got).all()
+    assert err.max() < tol, "generated acceleration differs from the oracle: %g" % err.max()
+    return info
+
+
+def test_upper_body_generated_acceleration_matches_oracle():
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    slots, stmts, _ = check(UpperBodyRobot().get_description(), "upper_body")
+    assert slots <= 120 and stmts < 14000       # fits four waves' LDS regions on a CU; the folding still works
+
+
+def test_upper_body_without_lds_parking_is_the_same_function():
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    check(UpperBodyRobot().get_description(), "upper_body_nolds", lds_c=False)
+
+
+def test_msj_as_a_joint_tree():
+    from gym_roboy_amd.envs.robots import MsjRobot
+    check(MsjRobot().get_description(), "msj")
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_random_robots(seed):
+    from gym_roboy_amd.envs.robots.description import RobotDescription
+    from random_robots import random_tree_spec
+    desc = RobotDescription(random_tree_spec(seed))
+    check(desc, "random%d" % seed, tol=5e-4)
+
+
+@pytest.mark.parametrize("shape,n_q", [("chain", 17), ("star", 12), ("chain", 32)])
+def test_random_shapes(shape, n_q):
+    from gym_roboy_amd.envs.robots.description import RobotDescription
+    from random_robots import random_tree_spec
+    desc = RobotDescription(random_tree_spec(40 + n_q, n_q=n_q, shape=shape))
+    check(desc, "shape_%s%d" % (shape, n_q), tol=2e-3 if n_q > 20 else 5e-4)
+
+
+def test_committed_baked_header_is_current():
+    import gen_tree_lane_baked as gen
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    fresh = os.path.join(BUILD, "tree_lane_baked_fresh.hpp")
+    gen.generate(UpperBodyRobot().get_description(), fresh)
+    committed = os.path.join(ROOT, "gym_roboy_amd", "csrc", "tree_lane_baked.hpp")
+    assert open(fresh).read() == open(committed).read(), "run tools/gen_tree_lane_baked.py"
+
+
+def test_generated_text_does_not_depend_on_the_host_compiler():
+    """The library (hipcc's host compiler) regenerates the text at run time and compares its hash with the committed
+    header's (written through g++): argument-evaluation order must not leak into the text."""
+    import ctypes
+    import shutil
+    import gen_tree_lane_baked as gen
+    from gym_roboy_amd.envs.robots import RobotDescription, UpperBodyRobot
+    from random_robots import random_tree_spec
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        clang = shutil.which("clang++")
+    if not clang:
+        pytest.skip("no clang++ to compare g++ with")
+    so = os.path.join(BUILD, "libgen_tree_lane_clang.so")
+    subprocess.check_call([clang, "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so,
+                           os.path.join(ROOT, "gym_roboy_amd", "csrc", "gen_tree_lane.cpp")])
+    lib = ctypes.CDLL(so)
+    for k, desc in enumerate([UpperBodyRobot().get_description()] + [RobotDescription(random_tree_spec(s)) for s in (2, 3)]):
+        a = os.path.join(BUILD, "cmp_gcc_%d.hpp" % k); b = os.path.join(BUILD, "cmp_clang_%d.hpp" % k)
+        gen.generate(desc, a)
+        assert lib.rb_gen_tree_lane(ctypes.byref(desc.as_c_struct()), 1, b.encode(), None, None, None) == 0
+        assert open(a).read() == open(b).read()
+
+
+def _hiprtc_compile(src, name, exprs):
+    """Compile `src` for gfx950 with hiprtc (no GPU needed) with the options rbj::compile_and_load uses; returns the log on failure."""
+    import ctypes
+    try:
+        rtc = ctypes.CDLL("libhiprtc.so")
+    except OSError:
+        try:
+            rtc = ctypes.CDLL("/opt/rocm/lib/libhiprtc.so")
+        except OSError:
+            pytest.skip("hiprtc is not installed")
+    prog = ctypes.c_void_p()
+    assert rtc.hiprtcCreateProgram(ctypes.byref(prog), src.encode(), name.encode(), 0, None, None) == 0
+    for e in exprs:
+        assert rtc.hiprtcAddNameExpression(prog, e.encode()) == 0
+    opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", b"-fno-slp-vectorize",
+            ("-I" + os.path.join(ROOT, "gym_roboy_amd", "csrc")).encode()]
+    arr = (ctypes.c_char_p * len(opts))(*opts)
+    rc = rtc.hiprtcCompileProgram(prog, len(opts), arr)
+    log = ""
+    if rc:
+        n = ctypes.c_size_t(0)
+        rtc.hiprtcGetProgramLogSize(prog, ctypes.byref(n))
+        buf = ctypes.create_string_buffer(n.value + 1)
+        rtc.hiprtcGetProgramLog(prog, buf)
+        log = buf.value.decode(errors="replace")
+    size = ctypes.c_size_t(0)
+    if not rc:
+        rtc.hiprtcGetCodeSize(prog, ctypes.byref(size))
+    rtc.hiprtcDestroyProgram(ctypes.byref(prog))
+    return rc, log, size.value
+
+
+def test_hiprtc_builds_the_kernels_of_a_random_robot():
+    """What rblj::build (csrc/tree_lane_jit.hpp) hands to hiprtc at run time, compiled here for gfx950: the run-time
+    compiler has no standard headers, so every name the kernels use must come from rtc_compat.hpp."""
+    import gen_tree_lane_baked as gen
+    from gym_roboy_amd.envs.robots import RobotDescription
+    from random_robots import random_tree_spec
+    hdr = os.path.join(BUILD, "lane_rtc.hpp")
+    gen.generate(RobotDescription(random_tree_spec(3)), hdr)
+    text = open(hdr).read()
+    text = text[:text.rindex("#define RBL_TEXT_HASH")]
+    src = '#include "tree_lane_defs.hpp"\n#define RBL_NS rbl_jit\n' + text + '#include "tree_lane.hpp"\n'
+    for kern in ("rbl_jit::tree_lane_step<1>", "rbl_jit::tree_lane_env_step<0>"):
+        rc, log, size = _hiprtc_compile(src, "roboy_tree_lane_jit.hip", [kern])
+        assert rc == 0, log[:2000]
+        assert size > 10000

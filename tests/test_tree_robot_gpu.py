@@ -1,7 +1,8 @@
-"""GPU parity of the generic joint-tree kernel (one env per wave, LDS working
-set) against the fp64 oracle, on the synthetic 20-DOF / 38-tendon upper body
-(BASELINE.json configs[3]) and on an MSJ variant that is not a ball joint.
-Tolerance 2e-5 on the state after one env step (fp32 Cholesky of a 20x20 M)."""
+"""GPU parity of the joint-tree kernels against the fp64 oracle, on the synthetic 20-DOF / 38-tendon upper body
+(BASELINE.json configs[3]) and on MSJ variants that are not ball joints, in both kernel forms: env-per-lane
+(rb_kernel 1: code generated for the robot - compiled ahead of time for the upper body, by hiprtc otherwise) and
+octets (rb_kernel 3: two envs per wave, eight lanes per link, tables in LDS).
+Tolerance 2e-5 on the state after one env step."""
 import numpy as np
 import pytest
 
@@ -23,12 +24,19 @@ def upper_oracle(upper_body):
     return COracle(upper_body.get_description(), "f64")
 
 
-def _check(robot, oracle, n, integrator, nsub, seed):
+LANE, OCTET = 1, 3      # rb_kernel: RB_KERNEL_ENV_PER_LANE, RB_KERNEL_ENV_PER_WAVE
+
+
+def _check(robot, oracle, n, integrator, nsub, seed, kernel=None, expect=OCTET):
+    """kernel None: the library's own choice, which must be `expect`."""
     from gym_roboy_amd.envs.simulations import HipBatchSimulation
     desc = robot.get_description()
     q, qd, sp = random_states(desc, n, seed)
     sim = HipBatchSimulation(robot, n, integrator=integrator, n_substeps=nsub)
-    assert sim.info()["kernel"] == 3
+    if kernel is not None:
+        sim.select_kernel(kernel)
+        expect = kernel
+    assert sim.info()["kernel"] == expect
     sim.set_state(q, qd)
     q1, qd1, f1 = sim.forward_step_command(sp)
     qo, qdo, fo = oracle.step(q, qd, sp, integrator=0 if integrator == "euler" else 1, n_substeps=nsub)
@@ -42,8 +50,21 @@ def _check(robot, oracle, n, integrator, nsub, seed):
 @pytest.mark.parametrize("integrator", ["euler", "rk4"])
 @pytest.mark.parametrize("nsub", [1, 2])
 @pytest.mark.parametrize("n", [1, 257])
-def test_upper_body_step_matches_oracle(upper_body, upper_oracle, integrator, nsub, n):
-    _check(upper_body, upper_oracle, n, integrator, nsub, seed=n + nsub)
+@pytest.mark.parametrize("kernel", [None, OCTET])
+def test_upper_body_step_matches_oracle(upper_body, upper_oracle, integrator, nsub, n, kernel):
+    # the library's choice for the committed upper body is the env-per-lane form compiled ahead of time
+    _check(upper_body, upper_oracle, n, integrator, nsub, seed=n + nsub, kernel=kernel, expect=LANE)
+
+
+def test_upper_body_specialization_is_the_ahead_of_time_table(upper_body):
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    sim = HipBatchSimulation(upper_body, 64)
+    assert sim.specialization() == "table"
+    sim.select_kernel(OCTET)
+    assert sim.specialization() == "kernarg" and sim.info()["kernel"] == OCTET
+    sim.select_kernel(0)
+    assert sim.info()["kernel"] == LANE
+    sim.close()
 
 
 def test_upper_body_numpy_oracle_agrees_too(upper_body):
@@ -112,6 +133,9 @@ def test_msj_variant_outside_the_ball_joint_class_takes_the_tree_kernel(msj_robo
             return desc
     for integrator in ("euler", "rk4"):
         _check(OffsetMsj(), COracle(desc, "f64"), 100, integrator, 1, seed=4)
+    # and the env-per-lane form, built by hiprtc for this robot (a batch this small takes the octets on its own)
+    for integrator in ("euler", "rk4"):
+        _check(OffsetMsj(), COracle(desc, "f64"), 100, integrator, 2, seed=5, kernel=LANE)
 
 
 def test_tree_kernel_on_the_msj_robot_equals_the_closed_form(msj_robot, msj_oracle):

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Regenerate gym_roboy_amd/csrc/tree_lane_baked.hpp: the env-per-lane acceleration of the committed upper body
+(gym_roboy_amd/envs/robots/data/upper_body.json) as straight-line code, written by csrc/tree_lane_gen.hpp
+(built with g++ through csrc/gen_tree_lane.cpp).
+
+    python tools/gen_tree_lane_baked.py [output path]
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def load_generator():
+    build = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(build, exist_ok=True)
+    so = os.path.join(build, "libgen_tree_lane.so")
+    csrc = os.path.join(ROOT, "gym_roboy_amd", "csrc")
+    deps = [os.path.join(csrc, f) for f in ("gen_tree_lane.cpp", "tree_lane_gen.hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-o", so, deps[0]])
+    return ctypes.CDLL(so)
+
+
+def generate(desc, path, lds_c=True):
+    """Write the generated header of `desc` to `path`; returns (lds_slots, statements, hash)."""
+    lib = load_generator()
+    slots, stmts, h = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_ulonglong(0)
+    rc = lib.rb_gen_tree_lane(ctypes.byref(desc.as_c_struct()), int(lds_c), path.encode(), ctypes.byref(slots),
+                              ctypes.byref(stmts), ctypes.byref(h))
+    if rc:
+        raise RuntimeError("rb_gen_tree_lane failed: %d" % rc)
+    return slots.value, stmts.value, h.value
+
+
+if __name__ == "__main__":
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gym_roboy_amd", "csrc", "tree_lane_baked.hpp")
+    print("wrote", out, generate(UpperBodyRobot().get_description(), out))
