@@ -51,12 +51,13 @@ WORKLOADS = {
     "msj-2097152-euler": (2097152, "euler", 1, 300, 30, "large batch: MsjRobot 2 097 152 envs on one GPU, Euler fp32"),
     "upper-body-8192-euler": (8192, "euler", 1, 300, 30, "configs[3]: upper body (20 DOF / 38 tendons) 8 192 envs, Euler fp32"),
     "upper-body-8192-rk4": (8192, "rk4", 1, 100, 10, "configs[3]: upper body (20 DOF / 38 tendons) 8 192 envs, RK4 fp32"),
+    "upper-body-65536-euler": (65536, "euler", 1, 300, 30, "large batch: upper body (20 DOF / 38 tendons) 65 536 envs (one wave per SIMD), Euler fp32"),
 }
 DEFAULT_WORKLOAD = "msj-262144-rk4"
 RING = 4
-# Steps between two all-reduces of the statistics block: one episode horizon
-# (RoboyEnv.max_episode_length = 400 env steps, roboy_env.py:23).
-STATS_EVERY = int(os.environ.get("ROBOY_BENCH_STATS_EVERY", "400"))
+# Steps between two all-reduces of the statistics block: K = 100, the measurement spec of SURVEY.md §8(d) config (5)
+# (a quarter of an episode horizon: RoboyEnv.max_episode_length = 400 env steps, roboy_env.py:23).
+STATS_EVERY = int(os.environ.get("ROBOY_BENCH_STATS_EVERY", "100"))
 MIN_TIMED_S = float(os.environ.get("ROBOY_BENCH_MIN_TIMED_S", "0.05"))   # device time the repeats must cover
 MAX_REPEATS = 256
 HBM_PEAK = 8.0e12          # B/s, spec (MI355X_MICROARCH.md "HBM3E peak BW")
@@ -67,7 +68,8 @@ VALU_PEAK = 157.3e12       # flop/s, fp32 vector peak (MI355X_MICROARCH.md "Peak
 # x 1024 SIMDs / 1.20 ns.  The spec peak is the roof `frac` is quoted against; this is what an all-FMA stream reaches.
 VALU_FMA_MEASURED = 64 * 2 * 1024 / 1.20e-9
 KERNEL_NAMES = {1: "msj_step_env_per_lane", 2: "msj_step_tendon_per_lane", 3: "tree_step_aba"}
-PROFILE_DIRS = ("r2_a", "r1_b")   # newest first: where the committed rocprofv3 PMC passes live
+TREE_KERNEL_NAMES = {1: "tree_lane_step", 3: "tree_step_aba"}       # joint-tree robots: env-per-lane (generated) / octets
+PROFILE_DIRS = ("r3_a", "r2_a", "r1_b")   # newest first: where the committed rocprofv3 PMC passes live
 
 
 def pmc_traffic(workload):
@@ -85,18 +87,24 @@ def pmc_traffic(workload):
     return None, None
 
 
-def flops_per_env_step(robot_name, integrator, substeps):
+def flops_per_env_step(robot_name, integrator, substeps, kernel=None):
     """Floating-point operations of one env step, from the committed count of the
     instrumented restatement (oracle/flop_count.cpp -> profiles/flops_per_env_step.json);
-    None for a robot that has not been counted."""
+    None for a robot that has not been counted.  The generated env-per-lane kernels of the
+    joint-tree robots execute fewer operations than the general algorithm (constants folded):
+    they are priced with their own count ("<robot>/<integrator>/lane")."""
     try:
         with open(os.path.join(ROOT, "profiles", "flops_per_env_step.json")) as fh:
-            return json.load(fh)["%s/%s" % (robot_name, integrator)]["flops"] * substeps
+            table = json.load(fh)
+        key = "%s/%s" % (robot_name, integrator)
+        if kernel == "tree_lane_step" and key + "/lane" in table:
+            key += "/lane"
+        return table[key]["flops"] * substeps
     except Exception:
         return None
 
 
-def roofline(robot_name, integrator, substeps, n_envs, bytes_per_env_step, launch_s, workload=None):
+def roofline(robot_name, integrator, substeps, n_envs, bytes_per_env_step, launch_s, workload=None, kernel=None):
     """Both candidate roofs for one launch of the step kernel; ``bound`` names the one
     the kernel sits closer to (the larger fraction)."""
     nbytes = bytes_per_env_step * n_envs
@@ -104,7 +112,7 @@ def roofline(robot_name, integrator, substeps, n_envs, bytes_per_env_step, launc
     hbm = {"achieved": gbps, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": gbps * 1e9 / HBM_PEAK,
            "frac_of_measured_copy_6.29TBps": gbps * 1e9 / HBM_COPY,
            "bytes_per_env_step": bytes_per_env_step, "bytes_per_launch": nbytes}
-    flops = flops_per_env_step(robot_name, integrator, substeps)
+    flops = flops_per_env_step(robot_name, integrator, substeps, kernel)
     valu = None
     if flops is not None:
         tf = flops * n_envs / launch_s / 1e12
@@ -127,7 +135,7 @@ def parse():
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=None, help="override envs per GPU")
     ap.add_argument("--substeps", type=int, default=None, help="override integrator substeps per env step")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 env-per-lane, 2 tendon-per-lane")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 env-per-lane, 2 tendon-per-lane (ball joints), 3 octets (joint trees)")
     ap.add_argument("--no-graph", action="store_true", help="eager per-step launches instead of hipGraph replay")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -165,7 +173,7 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
     # for the whole rollout, independent of how often it runs; in line it costs its own
     # ~20 us per call and nothing else.
     stats_ring = [torch.zeros(8, dtype=torch.float64, device="cuda") for _ in range(2)]
-    state = {"chunk": 0, "last": stats_ring[0], "steps_issued": 0, "calls": 0}
+    state = {"chunk": 0, "last": stats_ring[0], "steps_issued": 0, "calls": 0, "ar_events": []}
     act_scale = float(robot.get_action_space().high[0])
 
     def reduce_stats():
@@ -179,7 +187,13 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
         if dist is None:                                            # one GPU: the local reduction alone
             return
         if dist.get_backend() == "nccl":
+            # events around the in-line collective (same stream): lets a scaling line be decomposed
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
             dist.all_reduce(buf)                                    # RCCL over xGMI
+            e1.record(stream)
+            if len(state["ar_events"]) < 64:
+                state["ar_events"].append((e0, e1))
         else:                                                       # rehearsal over gloo: through the host
             host = buf.cpu()
             dist.all_reduce(host)
@@ -263,11 +277,14 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
         collective = {"backend": "rccl (torch.distributed 'nccl')" if dist.get_backend() == "nccl" else dist.get_backend(),
                       "world_size": dist.get_world_size(), "allreduce_calls": state["calls"],
                       "payload_bytes": 64, "every_steps": STATS_EVERY,
+                      "us_per_allreduce": (statistics.median([a.elapsed_time(b) * 1e3 for a, b in state["ar_events"][1:]])
+                                           if len(state["ar_events"]) > 1 else None),
                       "n_env_steps_allreduced": last[6], "expected": expected,
                       "ok": last[6] == expected and dist.get_world_size() == world}
     stats = [float(x) for x in state["last"].cpu()]
     sim.close()
     robot_name = type(robot).__name__
+    kernel_name = (TREE_KERNEL_NAMES if robot_name == "UpperBodyRobot" else KERNEL_NAMES)[info["kernel"]]
     return {
         "workload": name, "label": label, "envs_per_gpu": n_envs, "integrator": integrator,
         "substeps": nsub, "steps": steps, "warmup": warmup, "repeats": repeats,
@@ -276,8 +293,8 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
         "timed_device_ms": sum(devs) * 1e3,
         "launch_us_events": launch_s * 1e6,
         "roofline": roofline(robot_name, integrator, nsub, n_envs, info["bytes_per_env_step"], launch_s,
-                             name if envs is None and substeps is None else None),
-        "kernel": KERNEL_NAMES[info["kernel"]],
+                             name if envs is None and substeps is None else None, kernel_name),
+        "kernel": kernel_name,
         "stats": stats, "collective": collective,
         "finite": bool(np.isfinite(q).all() and np.isfinite(qd).all()),
         "feasible_frac": float(feas.mean()),
@@ -310,11 +327,13 @@ def run_fused_env(torch, robot, n_envs, steps=300, warmup=30):
     bytes_per = 4 * (4 * env.n_q + env.n_t + 1) + 4 * (3 * env.n_q + env.n_q + 6)   # + obs, goal, counter x2, return x2, reward, done
     finite = bool(torch.isfinite(obs).all().item() and torch.isfinite(rew).all().item())
     q, qd, feas = env.sim.read_state()
+    env.sim_kernel = env.sim.info()["kernel"]
     env.close()
     name = "fused-env-%d" % n_envs if type(robot).__name__ == "MsjRobot" else "fused-env-%s-%d" % (type(robot).__name__, n_envs)
     return {"workload": name, "label": "fused env layer (RoboyVecEnv.step), %s, %d envs, Euler fp32" % (type(robot).__name__, n_envs),
             "value": n_envs * steps / wall, "ms_per_step": wall * 1e3 / steps, "launch_us_events": us, "steps": steps,
-            "roofline": roofline(type(robot).__name__, "euler", 1, n_envs, bytes_per, us * 1e-6, name),
+            "roofline": roofline(type(robot).__name__, "euler", 1, n_envs, bytes_per, us * 1e-6, name,
+                                 "tree_lane_step" if env.sim_kernel == 1 and type(robot).__name__ != "MsjRobot" else None),
             "finite": finite and bool(np.isfinite(q).all() and np.isfinite(qd).all()), "feasible_frac": float(feas.mean())}
 
 
@@ -456,7 +475,7 @@ def cpu_baseline(robot, seconds, name):
     best = max(out, key=lambda th: out[th][0])
     py_loop = None
     if small:
-        num_cpu = min(cores_avail, 32)
+        num_cpu = min(cores_avail, 64)          # num_cpu = the host cores, capped where the process start-up would eat the budget
         py_loop = cpu_python_env_loop(num_cpu, max(2.0, seconds * 0.25))
         py_loop["cores"] = num_cpu
         py_loop["what"] = ("RoboyEnv.step (Python, one env per process x %d processes, Euler) over the oracle-backed "
@@ -529,12 +548,13 @@ def main():
                             rank, world, dist, args.substeps, args.kernel, args.repeats)
         if world == 1 and not args.no_also:
             for name in ("msj-4096-euler", "msj-262144-euler", "msj-262144-rk4", "msj-2097152-euler",
-                         "upper-body-8192-euler", "upper-body-8192-rk4"):
+                         "upper-body-8192-euler", "upper-body-8192-rk4", "upper-body-65536-euler"):
                 if name != args.workload:
                     rob = UpperBodyRobot() if name.startswith("upper-body") else MsjRobot()
                     also.append(brief(run_workload(torch, rob, name, None, None, None, use_graph, rank, world, dist)))
             also.append(brief(run_fused_env(torch, MsjRobot(), 2097152)))
             also.append(brief(run_fused_env(torch, UpperBodyRobot(), 8192)))
+            also.append(brief(run_fused_env(torch, UpperBodyRobot(), 65536)))
             for n_fused in (4096, 2097152):
                 also.append(brief(run_fused_rollout(torch, MsjRobot(), n_fused)))
             for fused in (True, False):                      # the consumer, end to end (timesteps/s, not env-steps/s)

@@ -8,7 +8,7 @@
 #include "tree_lane_gen.hpp"
 
 extern "C" int rb_gen_tree_lane(const rb_robot_desc *d, int lds_c, const char *path, int *lds_slots, int *n_stmt,
-                                unsigned long long *hash) {
+                                unsigned long long *hash, int *flops) {
     rblg::Generated g;
     std::string err;
     const int rc = rblg::generate(d, lds_c != 0, g, err);
@@ -22,5 +22,6 @@ extern "C" int rb_gen_tree_lane(const rb_robot_desc *d, int lds_c, const char *p
     if (lds_slots) *lds_slots = g.lds_slots;
     if (n_stmt) *n_stmt = g.n_stmt;
     if (hash) *hash = g.hash;
+    if (flops) *flops = g.flops;
     return RB_OK;
 }

@@ -14,8 +14,7 @@
 //   * HBM: the state rows q[n][n_q], qd[n][n_q], the action rows [n][n_t] (and goal / observation rows in the
 //     env-layer kernel) are env-major, as the octet kernels of tree_aba.hpp keep them.  A wave moves its 64
 //     rows as one contiguous run with coalesced dword accesses and transposes it through the (then idle) LDS
-//     region; nothing the step needs again later is kept in registers across the acceleration - it is read
-//     again (the rows are L2-resident), which is what keeps the RK4 stages inside the register budget.
+//     region, all input rows of a step in one batch of loads (one memory latency).
 // Algorithmic HBM bytes per env step: 4 (4 n_q + n_t + 1), as for every kernel of the library.
 #pragma once
 #include "env_common.hpp"
@@ -32,7 +31,7 @@ struct LaneLds {
     __device__ __forceinline__ float &operator()(int slot) const { return p[slot * 64]; }
 };
 
-constexpr int STAGE_SLOTS = 3 * RBL_NQ > RBL_NT ? 3 * RBL_NQ : RBL_NT;                   // widest row (set) a wave transposes
+constexpr int STAGE_SLOTS = 3 * RBL_NQ > 2 * RBL_NQ + RBL_NT ? 3 * RBL_NQ : 2 * RBL_NQ + RBL_NT;   // widest row set a wave transposes (obs | q, qd, act)
 constexpr int REGION_SLOTS = RBL_ACCEL_LDS > STAGE_SLOTS ? RBL_ACCEL_LDS : STAGE_SLOTS;  // acceleration slots, aliased by the transposes
 constexpr int ACC_SLOT = REGION_SLOTS;                                                   // RK4 accumulators: qa at ACC_SLOT + j, va at ACC_SLOT + NQ + j
 constexpr int LDS_SLOTS = REGION_SLOTS + 2 * RBL_NQ;
@@ -86,26 +85,6 @@ __device__ __forceinline__ void load_rows(const float *__restrict__ g, long env0
     for (int j = 0; j < W; ++j) out[j] = region[row + j];
     lane_wave_sync();
 }
-// two row sets of the same width at once (q and qd): all 2 W loads are in flight together
-template <int W>
-__device__ __forceinline__ void load_rows2(const float *__restrict__ ga, const float *__restrict__ gb, long env0, int live, float *region,
-                                           int lane_, float (&oa)[W], float (&ob)[W]) {
-    const int lane = opaque(lane_);
-    const __amdgpu_buffer_rsrc_t ra = rows_rsrc(ga, env0, W, live), rb = rows_rsrc(gb, env0, W, live);
-    float ta[W], tb[W];
-#pragma unroll
-    for (int k = 0; k < W; ++k) {
-        ta[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, lane * 4, k * 256, 0));
-        tb[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, k * 256, 0));
-    }
-#pragma unroll
-    for (int k = 0; k < W; ++k) { region[k * 64 + lane] = ta[k]; region[(W + k) * 64 + lane] = tb[k]; }
-    lane_wave_sync();
-    const int row = (lane < live ? lane : live - 1) * W;
-#pragma unroll
-    for (int j = 0; j < W; ++j) { oa[j] = region[row + j]; ob[j] = region[W * 64 + row + j]; }
-    lane_wave_sync();
-}
 template <int W>
 __device__ __forceinline__ void store_rows(float *__restrict__ g, long env0, int live, float *region, int lane_, const float (&in)[W]) {
     const int lane = opaque(lane_);
@@ -121,24 +100,19 @@ __device__ __forceinline__ void store_rows(float *__restrict__ g, long env0, int
 __device__ __forceinline__ float sat(float v, int j) { return __builtin_amdgcn_fmed3f(v, -VMAX[j], VMAX[j]); }
 
 // One env step of this lane's env: n_sub integrator substeps with the activation offsets held; velocity saturation
-// and joint limits as in tree_aba.hpp tree_integrate.  State in and out through the HBM rows (in place).  Returns
-// false if a joint hit a limit.  On return q / v hold the new state.
-// `load_spu(spu)` fetches the activation offsets of the step (action row x scale): called again before every
-// acceleration rather than held across it (38 registers on the upper body, which the stage loop would spill).
-template <int INTEG, class SPU>
-__device__ __forceinline__ bool lane_step(float *__restrict__ gq, float *__restrict__ gqd, long env0, int live, float *region,
-                                          const LaneLds &L, int lane, const SPU &load_spu, float h, int nsub,
-                                          float (&q)[RBL_NQ], float (&v)[RBL_NQ]) {
+// and joint limits as in tree_aba.hpp tree_integrate.  q / v hold the state on entry and the new state on return;
+// returns false if a joint hit a limit.  What is live across the acceleration besides its own ~370 registers: the
+// activation offsets (its input anyway), q (Euler) or q0, v0 (RK4: 2 n_q) - inside the 512-register file of a
+// SIMD's only wave on the upper body; the RK4 sums go to LDS.
+template <int INTEG>
+__device__ __forceinline__ bool lane_step(const LaneLds &L, const float (&spu)[RBL_NT], float h, int nsub, float (&q)[RBL_NQ], float (&v)[RBL_NQ]) {
     bool ok = true;
     for (int sub = 0; sub < nsub; ++sub) {
         if (INTEG == 0) {
-            float a[RBL_NQ], spu[RBL_NT];
-            load_rows2<RBL_NQ>(gq, gqd, env0, live, region, lane, q, v);
-            load_spu(spu);
+            float a[RBL_NQ];
             fence_code();
             rbl_accel(q, v, spu, a, L);
             fence_code();
-            load_rows<RBL_NQ>(gq, env0, live, region, lane, q);        // not kept across the acceleration
 #pragma unroll
             for (int j = 0; j < RBL_NQ; ++j) { v[j] = sat(v[j] + h * a[j], j); q[j] = q[j] + h * v[j]; }
         } else {
@@ -151,15 +125,13 @@ __device__ __forceinline__ bool lane_step(float *__restrict__ gq, float *__restr
 #pragma unroll 1
             for (int st = 0; st < 4; ++st) {
                 const float wgt = (st == 0 || st == 3) ? 1.0f : 2.0f, cst = st == 0 ? 0.0f : (st == 3 ? h : 0.5f * h);
-                float qs[RBL_NQ], spu[RBL_NT];
-                load_rows2<RBL_NQ>(gq, gqd, env0, live, region, lane, q, v);
-                load_spu(spu);
+                float qs[RBL_NQ];
 #pragma unroll
                 for (int j = 0; j < RBL_NQ; ++j) {
                     qs[j] = q[j] + cst * kq[j];                   // state of this stage ...
                     kq[j] = sat(v[j] + cst * kv[j], j);            // ... and its (saturated) velocity
                 }
-                // the velocity's share of the sums before the acceleration (nothing but kq and the loop state lives across it)
+                // the velocity's share of the sums before the acceleration
 #pragma unroll
                 for (int j = 0; j < RBL_NQ; ++j) L(ACC_SLOT + j) += wgt * kq[j];
                 fence_code();
@@ -168,7 +140,6 @@ __device__ __forceinline__ bool lane_step(float *__restrict__ gq, float *__restr
 #pragma unroll
                 for (int j = 0; j < RBL_NQ; ++j) L(ACC_SLOT + RBL_NQ + j) += wgt * kv[j];
             }
-            load_rows2<RBL_NQ>(gq, gqd, env0, live, region, lane, q, v);
 #pragma unroll
             for (int j = 0; j < RBL_NQ; ++j) { q[j] = q[j] + h6 * L(ACC_SLOT + j); v[j] = v[j] + h6 * L(ACC_SLOT + RBL_NQ + j); }
         }
@@ -181,12 +152,36 @@ __device__ __forceinline__ bool lane_step(float *__restrict__ gq, float *__restr
             v[j] = vv;
             ok = ok && !(over || under);
         }
-        if (sub + 1 < nsub) {       // the next substep reads the rows again
-            store_rows<RBL_NQ>(gq, env0, live, region, lane, q);
-            store_rows<RBL_NQ>(gqd, env0, live, region, lane, v);
-        }
     }
     return ok;
+}
+
+// the three input row sets of a step at once: every load is in flight before the first is waited for
+__device__ __forceinline__ void load_inputs(const float *__restrict__ gq, const float *__restrict__ gqd, const float *__restrict__ act,
+                                            long env0, int live, float *region, int lane_, float (&q)[RBL_NQ], float (&v)[RBL_NQ],
+                                            float (&a)[RBL_NT]) {
+    const int lane = opaque(lane_);
+    const __amdgpu_buffer_rsrc_t rq = rows_rsrc(gq, env0, RBL_NQ, live), rv = rows_rsrc(gqd, env0, RBL_NQ, live), ra = rows_rsrc(act, env0, RBL_NT, live);
+    float tq[RBL_NQ], tv[RBL_NQ], ta[RBL_NT];
+#pragma unroll
+    for (int k = 0; k < RBL_NQ; ++k) {
+        tq[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rq, lane * 4, k * 256, 0));
+        tv[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, lane * 4, k * 256, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < RBL_NT; ++k) ta[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, lane * 4, k * 256, 0));
+    constexpr int OV = RBL_NQ * 64, OA = 2 * RBL_NQ * 64;
+#pragma unroll
+    for (int k = 0; k < RBL_NQ; ++k) { region[k * 64 + lane] = tq[k]; region[OV + k * 64 + lane] = tv[k]; }
+#pragma unroll
+    for (int k = 0; k < RBL_NT; ++k) region[OA + k * 64 + lane] = ta[k];
+    lane_wave_sync();
+    const int row = lane < live ? lane : live - 1;
+#pragma unroll
+    for (int j = 0; j < RBL_NQ; ++j) { q[j] = region[row * RBL_NQ + j]; v[j] = region[OV + row * RBL_NQ + j]; }
+#pragma unroll
+    for (int k = 0; k < RBL_NT; ++k) a[k] = region[OA + row * RBL_NT + k];
+    lane_wave_sync();
 }
 
 // forward_step_command for a batch: act rows are set-points scaled by act_scale (tree_step_aba's contract)
@@ -201,13 +196,11 @@ tree_lane_step(float *__restrict__ q, float *__restrict__ qd, uint32_t *__restri
     const int live = n - env0 < 64 ? int(n - env0) : 64;
     float *region = lds_lane;
     const LaneLds L{region + lane};
-    float qq[RBL_NQ], vv[RBL_NQ];
-    auto load_spu = [&](float (&spu)[RBL_NT]) {
-        load_rows<RBL_NT>(act, env0, live, region, lane, spu);
+    float qq[RBL_NQ], vv[RBL_NQ], spu[RBL_NT];
+    load_inputs(q, qd, act, env0, live, region, lane, qq, vv, spu);
 #pragma unroll
-        for (int k = 0; k < RBL_NT; ++k) spu[k] = (spu[k] * act_scale) * KSG[k];   // (a product act_scale * KSG[k] would be hoisted out of the substep loop: 38 registers held across the acceleration)
-    };
-    const bool ok = lane_step<INTEG>(q, qd, env0, live, region, L, lane, load_spu, h, nsub, qq, vv);
+    for (int k = 0; k < RBL_NT; ++k) spu[k] = (spu[k] * act_scale) * KSG[k];
+    const bool ok = lane_step<INTEG>(L, spu, h, nsub, qq, vv);
     store_rows<RBL_NQ>(q, env0, live, region, lane, qq);
     store_rows<RBL_NQ>(qd, env0, live, region, lane, vv);
     if (lane < live) feas[env0 + lane] = ok ? 1u : 0u;
@@ -229,17 +222,15 @@ tree_lane_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__res
     const int live = n - env0 < 64 ? int(n - env0) : 64;
     float *region = lds_lane;
     const LaneLds L{region + lane};
-    float qq[RBL_NQ], vv[RBL_NQ];
-    auto load_spu = [&](float (&spu)[RBL_NT]) {
-        load_rows<RBL_NT>(act, env0, live, region, lane, spu);
+    float qq[RBL_NQ], vv[RBL_NQ], spu[RBL_NT];
+    load_inputs(q, qd, act, env0, live, region, lane, qq, vv, spu);
 #pragma unroll
-        for (int k = 0; k < RBL_NT; ++k) {
-            // clamp to the action box, then slope * (x - in_high) + out_high with two roundings (roboy_env.py:157-158)
-            const float x = fminf(fmaxf(spu[k], -1.0f), 1.0f);
-            spu[k] = rbe::mul_then_add(ep.slope, x - 1.0f, ep.act_hi) * KSG[k];
-        }
-    };
-    const bool ok = lane_step<INTEG>(q, qd, env0, live, region, L, lane, load_spu, h, nsub, qq, vv);
+    for (int k = 0; k < RBL_NT; ++k) {
+        // clamp to the action box, then slope * (x - in_high) + out_high with two roundings (roboy_env.py:157-158)
+        const float x = fminf(fmaxf(spu[k], -1.0f), 1.0f);
+        spu[k] = rbe::mul_then_add(ep.slope, x - 1.0f, ep.act_hi) * KSG[k];
+    }
+    const bool ok = lane_step<INTEG>(L, spu, h, nsub, qq, vv);
     // observation [q | qd | goal], reward, done; goal redraw (and reset) on done
     float o[3 * RBL_NQ];
     {

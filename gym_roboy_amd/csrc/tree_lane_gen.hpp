@@ -51,6 +51,8 @@ struct Generated {
     int n_q = 0, n_t = 0;
     int lds_slots = 0;         // lane-private LDS slots rbl_accel uses
     int n_stmt = 0;            // statements emitted (a proxy of the instruction count)
+    int flops = 0;             // floating-point operations of one acceleration as written (one per arithmetic statement: the
+                               // folded products and sums are not counted - they are not executed)
     uint64_t hash = 0;         // FNV-1a of the text
 };
 
@@ -91,7 +93,7 @@ class Gen {
     void barrier() { stmts.push_back({"//", "    RBL_SCHED_BARRIER;\n"}); }
     // The text of the function body without the statements nothing depends on (a parent's accumulated inertia that
     // only feeds a root's unused I^a, products folded away further down, ...); n_stmt = statements kept.
-    std::string body(int &n_stmt) const {
+    std::string body(int &n_stmt, int &flops) const {
         std::vector<char> keep(stmts.size(), 0);
         std::map<std::string, char> live;
         for (size_t k = stmts.size(); k-- > 0;) {
@@ -110,9 +112,15 @@ class Gen {
                 }
         }
         std::string out;
-        n_stmt = 0;
+        n_stmt = 0; flops = 0;
         for (size_t k = 0; k < stmts.size(); ++k)
-            if (keep[k]) { out += stmts[k].text; if (stmts[k].target != "//") ++n_stmt; }
+            if (keep[k]) {
+                out += stmts[k].text;
+                if (stmts[k].target == "//") continue;
+                ++n_stmt;
+                // arithmetic = a kept temporary that is not an LDS read-back
+                if (!stmts[k].target.empty() && stmts[k].text.find("RBL_LDS(") == std::string::npos) ++flops;
+            }
         return out;
     }
     static Val negv(Val a) {
@@ -439,8 +447,17 @@ inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::str
         for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) IA[i].m[r][c] = K(0.0);
         for (int a = 0; a < 6; ++a) pA[i][a] = g.add(bown[i][a], pT[i][a]);
     }
+    // the parked c of a link is requested one link ahead of its use: a wave is alone on its SIMD, so an LDS latency
+    // met at the point of use is idle time (the scheduling barriers keep the request where it is written)
+    std::vector<std::array<Val, 6>> cpre(nq);
+    std::vector<char> cpre_ok(nq, 0);
+    auto prefetch_c = [&](int i) { if (i >= 0 && i < nq && !cpre_ok[i]) { cpre[i] = load_c(i); cpre_ok[i] = 1; } };
+    auto next_user = [&](int i) { int n = i - 1; while (n >= 0 && parent[n] < 0) --n; return n; };   // (a root's backward step uses no c)
+    auto take_c = [&](int i) { if (!cpre_ok[i]) cpre[i] = load_c(i); cpre_ok[i] = 0; return cpre[i]; };
+    prefetch_c(next_user(nq));
     for (int i = nq - 1; i >= 0; --i) {
         g.comment("link " + std::to_string(i) + ": backward pass");
+        prefetch_c(next_user(i));
         Sym6 &I = IA[i];
         for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) I.m[r][c] = g.add(I.m[r][c], Iown[i].m[r][c]);
         const std::array<Val, 6> s = {z[i][0], z[i][1], z[i][2], sl[i][0], sl[i][1], sl[i][2]};
@@ -459,7 +476,7 @@ inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::str
         const int par = parent[i];
         if (par >= 0) {
             // I^a = I^A - U U^T / D,  p^a = p^A + I^a c + U u / D, added to the parent
-            const std::array<Val, 6> c = load_c(i);
+            const std::array<Val, 6> c = take_c(i);
             std::array<Val, 6> Kk;
             for (int r = 0; r < 6; ++r) Kk[r] = g.mul(U[i][r], invD[i]);
             Sym6 Ia;
@@ -479,10 +496,13 @@ inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::str
     // ---------------- sweep 3: accelerations, root to leaves ----------------
     std::vector<std::array<Val, 6>> acc(nq);
     const std::array<Val, 6> a0 = {K(0), K(0), K(0), K(-d->gravity[0]), K(-d->gravity[1]), K(-d->gravity[2])};
+    for (int i = 0; i < nq; ++i) cpre_ok[i] = 0;
+    prefetch_c(0);
     for (int i = 0; i < nq; ++i) {
         g.comment("link " + std::to_string(i) + ": acceleration");
+        prefetch_c(i + 1);
         const std::array<Val, 6> &apar = parent[i] < 0 ? a0 : acc[parent[i]];
-        const std::array<Val, 6> c = load_c(i);
+        const std::array<Val, 6> c = take_c(i);
         std::array<Val, 6> ap;
         for (int r = 0; r < 6; ++r) ap[r] = g.add(apar[r], c[r]);
         std::vector<std::pair<Val, Val>> terms;
@@ -514,7 +534,7 @@ inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::str
     table("VMAX", nq, [&](int k) { return d->qd_max[k]; });
     t += "template <class RBL_L>\nRBL_FN void rbl_accel(const float (&q)[RBL_NQ], const float (&qd)[RBL_NQ], const float (&spu)[RBL_NT], "
          "float (&qdd)[RBL_NQ], RBL_L rbl_lds) {\n";
-    t += g.body(out.n_stmt);
+    t += g.body(out.n_stmt, out.flops);
     t += "}\n}  // namespace RBL_NS\n";
     out.text = t;
     out.n_q = nq; out.n_t = nt; out.lds_slots = g.n_lds;
@@ -525,7 +545,7 @@ inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::str
 // LDS slots per lane of the kernels of tree_lane.hpp (the formula of its LDS_SLOTS): the acceleration's slots, aliased
 // by the row transposes, then the RK4 accumulators
 inline int lane_lds_slots(const Generated &g) {
-    const int stage = 3 * g.n_q > g.n_t ? 3 * g.n_q : g.n_t;
+    const int stage = 3 * g.n_q > 2 * g.n_q + g.n_t ? 3 * g.n_q : 2 * g.n_q + g.n_t;
     return (g.lds_slots > stage ? g.lds_slots : stage) + 2 * g.n_q;
 }
 inline size_t lane_lds_bytes_per_wave(const Generated &g) { return size_t(lane_lds_slots(g)) * 64 * 4; }

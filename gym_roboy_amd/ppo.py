@@ -293,6 +293,10 @@ class PPO:
         side.wait_stream(torch.cuda.current_stream(dev))
         # the env kernel is launched on the simulation's stream: make that the capture stream
         env.set_stream(side.cuda_stream)
+        # kernels the simulation specialises at run time (hiprtc) are built now: a compilation and a module load
+        # must not fall into the capture below
+        if hasattr(getattr(env, "sim", None), "specialization"):
+            env.sim.specialization()
         with torch.cuda.stream(side), torch.no_grad():
             # first use of the GEMM library for these shapes (handle, workspace) must not fall into the capture
             self.policy.act(b["carry"]); self.policy.value(b["carry"])

@@ -67,7 +67,8 @@ def table():
     qd = rng.uniform(-0.5 * desc.qd_max, 0.5 * desc.qd_max)
     sp = rng.uniform(-0.3, 0.3, desc.n_t)
     out = {"_about": "floating-point operations per env step, counted by oracle/flop_count.cpp (MsjRobot: the kernels' closed "
-                     "form instantiated with a tallying scalar; UpperBodyRobot: a scalar restatement of tree_aba.hpp's algorithm); flops = add + mul + div + minmax + trans; "
+                     "form instantiated with a tallying scalar; UpperBodyRobot: a scalar restatement of tree_aba.hpp's algorithm; "
+                     "UpperBodyRobot/*/lane: the operations the generated env-per-lane code executes, constants folded); flops = add + mul + div + minmax + trans; "
                      "regenerate with `python -m oracle.flop_count`"}
     for name, integ in (("euler", 0), ("rk4", 1)):
         c, *_ = count_msj_step(desc, integ, q, qd, sp)
@@ -80,6 +81,21 @@ def table():
     for name, integ in (("euler", 0), ("rk4", 1)):
         c, *_ = count_tree_step(desc, integ, q, qd, sp)
         out["UpperBodyRobot/%s" % name] = c
+    # The env-per-lane kernels run code generated for the robot with every constant folded (csrc/tree_lane_gen.hpp):
+    # they execute fewer operations than the general algorithm counted above, and their VALU fraction is priced with
+    # what they execute.  accel_flops = arithmetic statements of one generated acceleration (the generator's own
+    # count); per joint the integrator adds 10 (Euler: v + h a, saturation, q + h v, limit tests) or 26 (RK4: four
+    # stage states and saturations, the two weighted sums, the final update, limit tests), per tendon 2 (set-point scaling).
+    import sys
+    root = os.path.dirname(_HERE)
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import gen_tree_lane_baked as gen
+    build = os.path.join(root, "tests", "_build")
+    os.makedirs(build, exist_ok=True)
+    accel = gen.generate(desc, os.path.join(build, "flop_count_lane.hpp"))[3]
+    for name, evals, per_joint in (("euler", 1, 10), ("rk4", 4, 26)):
+        out["UpperBodyRobot/%s/lane" % name] = {"accel_flops": accel, "accel_evaluations": evals,
+                                                "flops": evals * accel + per_joint * desc.n_q + 2 * desc.n_t}
     return out
 
 

@@ -161,6 +161,28 @@ def test_graph_mode_learns_counts_and_resumes(tmp_path):
 
 
 @pytest.mark.gpu
+def test_graph_mode_on_a_robot_whose_kernels_are_built_at_run_time():
+    """An 8-tendon ball-joint robot that is not the reference's MsjRobot, above 65 536 envs: its env-per-lane kernels
+    are specialised with hiprtc.  The build (a compilation and a module load) must happen before the rollout is
+    captured - rb_env_configure does it, and PPO's warm-up asks again - and the captured rollout must run them."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from random_robots import random_ball_joint_robot
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    robot, _ = random_ball_joint_robot(1)
+    env = RoboyVecEnv(robot, 65536 + 256, seed=2)
+    agent = PPO(env, n_steps=4, device="cuda", ent_coef=0.1, reward_scale=0.01, seed=1, use_graphs=True)
+    roll = agent.collect()                                       # builds the graph
+    assert env.sim.specialization() == "jit"
+    assert all(bool(torch.isfinite(v).all()) for v in roll.values())
+    first = roll["rew"].clone()
+    roll = agent.collect()                                       # replays it
+    assert bool(torch.isfinite(roll["rew"]).all()) and not torch.equal(first, roll["rew"])
+    env.close()
+
+
+@pytest.mark.gpu
 def test_train_then_play_back(tmp_path, capsys):
     """train_parallel.py -> model.pkl -> visualize_agent.py, the reference's two drivers."""
     from gym_roboy_amd import train_parallel, visualize_agent

@@ -26,14 +26,14 @@ def load_generator():
 
 
 def generate(desc, path, lds_c=True):
-    """Write the generated header of `desc` to `path`; returns (lds_slots, statements, hash)."""
+    """Write the generated header of `desc` to `path`; returns (lds_slots, statements, hash, flops of one acceleration)."""
     lib = load_generator()
-    slots, stmts, h = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_ulonglong(0)
+    slots, stmts, h, fl = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_ulonglong(0), ctypes.c_int(0)
     rc = lib.rb_gen_tree_lane(ctypes.byref(desc.as_c_struct()), int(lds_c), path.encode(), ctypes.byref(slots),
-                              ctypes.byref(stmts), ctypes.byref(h))
+                              ctypes.byref(stmts), ctypes.byref(h), ctypes.byref(fl))
     if rc:
         raise RuntimeError("rb_gen_tree_lane failed: %d" % rc)
-    return slots.value, stmts.value, h.value
+    return slots.value, stmts.value, h.value, fl.value
 
 
 if __name__ == "__main__":
