@@ -8,7 +8,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-RP_ABI_VERSION = 1
+RP_ABI_VERSION = 2
 
 
 class MlpParams(ctypes.Structure):
@@ -27,8 +27,15 @@ SIGNATURES = {
     "rp_pack_train": (ctypes.c_int, [ctypes.POINTER(MlpParams), ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "rp_grad_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),
     "rp_ppo_workspace_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
-    "rp_ppo_grad_dev": (ctypes.c_int, [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+    "rp_ppo_grad_dev": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                        ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rp_perm_dev": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "rp_perm_host": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    "rp_adv_stats_scratch_doubles": (ctypes.c_int64, []),
+    "rp_adv_stats_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rp_clip_adam_dev": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_float] * 4 +
+                                        [ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
+    "rp_debug_lds_grant_needed": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
     "rp_act_dev": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
                                   ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
 }

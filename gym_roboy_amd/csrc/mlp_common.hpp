@@ -12,6 +12,17 @@ namespace rpd {
 extern thread_local std::string g_err;
 int fail(int code, const std::string &msg);
 
+// The rp_* entry points take no device argument: the device of a call is the one its first device pointer lives on.
+// enter_device() looks it up and makes it current (one process per GPU never notices; a process that drives several
+// GPUs gets its launches, its CU count and its LDS opt-ins on the right one).
+int enter_device(const void *d_ptr, int *dev_out);
+int cu_count(int dev);
+// Dynamic LDS above 64 KB has to be granted per kernel with hipFuncSetAttribute - per DEVICE: the grant is remembered per
+// (kernel id, device), under a mutex.  lds_grant_needed() is the bookkeeping alone (host only; tests/test_policy_abi.py
+// drives it through rp_debug_lds_grant_needed).
+bool lds_grant_needed(int kernel_id, int dev, size_t lds);
+int grant_lds(const void *kernel, int kernel_id, int dev, size_t lds);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int H = RP_HIDDEN, HT = H / 32;            // hidden units, row tiles of a hidden layer
 constexpr int STREAM_POLICY = 2;                     // Philox stream of the exploration noise (0: actions, 1: goals)
@@ -91,6 +102,26 @@ __device__ __forceinline__ void mfma_stream(const float *w, const B0 &b0, const 
         if (k + 2 < N) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
     }
+}
+
+// offsets of one net's parameters inside its gradient vector (torch layout)
+struct GOff { int w1, b1, w2, b2, w3, b3, ls, loss; };
+__host__ __device__ inline GOff goff_of(int obs_dim, int n_out) {
+    GOff g;
+    int o = 0;
+    g.w1 = o; o += H * obs_dim;
+    g.b1 = o; o += H;
+    g.w2 = o; o += H * H;
+    g.b2 = o; o += H;
+    g.w3 = o; o += n_out * H;
+    g.b3 = o; o += n_out;
+    g.ls = o; o += n_out;          // log-std gradient (action net only; zero for the value net)
+    g.loss = o; o += 4;            // [sum of the per-sample loss terms / B, ...]
+    return g;
+}
+__host__ __device__ inline int gstride_of(int obs_dim, int act_dim) {
+    const int a = goff_of(obs_dim, act_dim).loss + 4;
+    return (a + 3) & ~3;
 }
 
 }  // namespace rpd

@@ -22,6 +22,8 @@
 // is what keeps the quarter-rate instructions of tanh issuing (85 -> 78 us at 262 144 samples).
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -33,6 +35,50 @@
 namespace rpd {
 thread_local std::string g_err;
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+int enter_device(const void *d_ptr, int *dev_out) {
+    hipPointerAttribute_t at;
+    int dev = 0;
+    if (d_ptr && hipPointerGetAttributes(&at, d_ptr) == hipSuccess && at.type == hipMemoryTypeDevice) dev = at.device;
+    else {
+        (void)hipGetLastError();                           // (a pointer the runtime does not know leaves an error behind)
+        if (hipGetDevice(&dev) != hipSuccess) return fail(RP_EHIP, "no HIP device");
+    }
+    const hipError_t e = hipSetDevice(dev);
+    if (e != hipSuccess) return fail(RP_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    *dev_out = dev;
+    return RP_OK;
+}
+
+int cu_count(int dev) {
+    int n = 256;
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+}
+
+namespace {
+constexpr int GRANT_KERNELS = 8, GRANT_DEVICES = 64;
+std::mutex g_grant_mutex;
+size_t g_granted[GRANT_KERNELS][GRANT_DEVICES];            // bytes granted so far (0: the default 64 KB)
+}
+bool lds_grant_needed(int kernel_id, int dev, size_t lds) {
+    if (lds <= 64 * 1024) return false;
+    if (kernel_id < 0 || kernel_id >= GRANT_KERNELS || dev < 0 || dev >= GRANT_DEVICES) return true;   // not tracked: always ask
+    std::lock_guard<std::mutex> lock(g_grant_mutex);
+    if (g_granted[kernel_id][dev] >= lds) return false;
+    g_granted[kernel_id][dev] = lds;
+    return true;
+}
+int grant_lds(const void *kernel, int kernel_id, int dev, size_t lds) {
+    if (!lds_grant_needed(kernel_id, dev, lds)) return RP_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) {
+        std::lock_guard<std::mutex> lock(g_grant_mutex);
+        if (kernel_id >= 0 && kernel_id < GRANT_KERNELS && dev >= 0 && dev < GRANT_DEVICES) g_granted[kernel_id][dev] = 0;
+        return fail(RP_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+    }
+    return RP_OK;
+}
 }  // namespace rpd
 
 namespace {
@@ -195,6 +241,7 @@ mlp_act_kernel(const float *__restrict__ packed, const float *__restrict__ obs, 
 extern "C" {
 
 int rp_abi_version(void) { return RP_ABI_VERSION; }
+int rp_debug_lds_grant_needed(int kernel_id, int dev, int64_t lds_bytes) { return lds_grant_needed(kernel_id, dev, size_t(lds_bytes)) ? 1 : 0; }
 const char *rp_last_error(void) { return g_err.c_str(); }
 
 int64_t rp_packed_floats(int obs_dim, int act_dim) {
@@ -252,14 +299,10 @@ int rp_act_dev(const float *d_packed, const float *d_obs, float *d_act, float *d
     const size_t lds = sizeof(float) * size_t(L.total);
     if (lds > 160 * 1024) return fail(RP_EUNSUPPORTED, "policy too large for the LDS-resident form");
     hipError_t e = hipSuccess;
-    static size_t lds_allowed = 64 * 1024;          // raised once per process and size (not a stream operation)
-    if (lds > lds_allowed) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_act_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        if (e != hipSuccess) return fail(RP_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
-        lds_allowed = lds;
-    }
-    int dev = 0, n_cu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    int dev = 0;
+    if (int rc = enter_device(d_packed, &dev)) return rc;          // the blob's device is the device of the call
+    if (int rc = grant_lds(reinterpret_cast<const void *>(&mlp_act_kernel), 0, dev, lds)) return rc;   // per kernel and device
+    const int n_cu = cu_count(dev);
     const long n_tiles = (n + 63) / 64;
     // 4 waves per workgroup (one per SIMD), two workgroups per CU, persistent over tiles; 6-wave workgroups spread
     // unevenly over the 4 SIMDs and were slower (107 against 78 us at 262 144 samples)

@@ -45,32 +45,14 @@ __device__ __forceinline__ f32x16 transpose_tile(const f32x16 &d, float *T, int 
 struct TrainArgs {
     const float *packed;                                  // rp_pack_train blob
     const float *obs, *act, *adv, *logp_old, *val_old, *ret;
-    const long long *index;                               // row of sample i in obs / act / logp_old / val_old / ret (NULL: i); adv is direct
+    const long long *index;                               // row of sample i in obs / act / logp_old / val_old / ret (NULL: i); adv is direct ...
+    const float *adv_stats;                               // ... unless this is given: {mean, 1 / (std + 1e-8)} of the minibatch's advantages
+                                                          // (rp_adv_stats_dev); adv is then indexed like the rest and normalised here
     float *partials;                                      // [waves][gstride]
     long B;
     int obs_dim, act_dim, gstride;
     float cliprange, vf_coef, inv_B;
 };
-
-// offsets of one net's parameters inside its gradient vector (torch layout)
-struct GOff { int w1, b1, w2, b2, w3, b3, ls, loss; };
-__host__ __device__ inline GOff goff_of(int obs_dim, int n_out) {
-    GOff g;
-    int o = 0;
-    g.w1 = o; o += H * obs_dim;
-    g.b1 = o; o += H;
-    g.w2 = o; o += H * H;
-    g.b2 = o; o += H;
-    g.w3 = o; o += n_out * H;
-    g.b3 = o; o += n_out;
-    g.ls = o; o += n_out;          // log-std gradient (action net only; zero for the value net)
-    g.loss = o; o += 4;            // [sum of the per-sample loss terms / B, ...]
-    return g;
-}
-__host__ __device__ inline int gstride_of(int obs_dim, int act_dim) {
-    const int a = goff_of(obs_dim, act_dim).loss + 4;
-    return (a + 3) & ~3;
-}
 
 // KX: 32-column tiles of [obs | 1] (obs_dim + 1 <= 32 KX);  NJ: compile-time bound of the outputs (n_out <= NJ,
 // a multiple of 8): the per-sample arrays of the loss derivative are NJ registers each
@@ -251,7 +233,8 @@ mlp_grad_kernel(const TrainArgs a) {
                     lp -= 0.5f * z[j] * z[j] * iv[j] + ls;
                 }
             }
-            const float A = a.adv[im], ratio = __expf(lp - a.logp_old[ii]);
+            const float A = a.adv_stats ? (a.adv[ii] - a.adv_stats[0]) * a.adv_stats[1] : a.adv[im];
+            const float ratio = __expf(lp - a.logp_old[ii]);
             const float rc = __builtin_amdgcn_fmed3f(ratio, 1.0f - a.cliprange, 1.0f + a.cliprange);
             const float t1 = -A * ratio, t2 = -A * rc;
             const float g = live ? (t1 >= t2 ? -A : 0.0f) * ratio * a.inv_B : 0.0f;      // dL / dlogp
@@ -477,15 +460,14 @@ __global__ void gae_kernel(const float *__restrict__ rew, const float *__restric
 }
 
 constexpr int WAVES_PER_BLOCK = 4;
-int n_cus() {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n;
-}
+// (every MI355X of a node has the same CU count, so the workspace size a caller asks for before it names a device -
+// rp_ppo_workspace_floats - and the grid of the launch agree; the count is the current device's)
 long grad_blocks(long B) {
     const long tiles = (B + 63) / 64;
     long blocks = (tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    const long cap = n_cus();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const long cap = cu_count(dev);
     return blocks < cap ? blocks : cap;
 }
 
@@ -505,14 +487,10 @@ bool grad_fits(int obs_dim, int act_dim) {
 }
 
 template <int NET, int KX, int NJ>
-int launch_grad(const TrainArgs &a, long blocks, size_t lds, hipStream_t stream) {
-    static size_t allowed = 64 * 1024;
-    if (lds > allowed) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_grad_kernel<NET, KX, NJ>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        if (e != hipSuccess) return fail(RP_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
-        allowed = lds;
-    }
+int launch_grad(const TrainArgs &a, long blocks, size_t lds, int dev, hipStream_t stream) {
+    // the opt-in above 64 KB of dynamic LDS is per kernel AND per device (mlp_common.hpp: grant_lds)
+    constexpr int kernel_id = 1 + NET * 2 + (KX - 1);
+    if (int rc = grant_lds(reinterpret_cast<const void *>(&mlp_grad_kernel<NET, KX, NJ>), kernel_id, dev, lds)) return rc;
     hipLaunchKernelGGL((mlp_grad_kernel<NET, KX, NJ>), dim3(unsigned(blocks)), dim3(64 * WAVES_PER_BLOCK), lds, stream, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RP_EHIP, std::string("mlp_grad_kernel: ") + hipGetErrorString(e));
@@ -561,6 +539,8 @@ int rp_gae_dev(const float *d_rew, const float *d_val, const float *d_done, cons
                float *d_adv, float *d_ret, int n_steps, int64_t n_envs, void *stream) {
     if (!d_rew || !d_val || !d_done || !d_last_val || !d_adv || !d_ret) return fail(RP_EINVAL, "null argument");
     if (n_steps < 1 || n_envs < 1) return fail(RP_EINVAL, "n_steps and n_envs must be >= 1");
+    int dev = 0;
+    if (int rc = enter_device(d_rew, &dev)) return rc;
     hipLaunchKernelGGL(gae_kernel, dim3(unsigned((n_envs + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), d_rew,
                        d_val, d_done, d_last_val, gamma, lam, d_adv, d_ret, n_steps, long(n_envs));
     const hipError_t e = hipGetLastError();
@@ -579,20 +559,22 @@ int64_t rp_ppo_workspace_floats(int obs_dim, int act_dim, int64_t batch) {
 }
 
 int rp_ppo_grad_dev(const float *d_packed_train, const float *d_obs, const float *d_act, const float *d_adv,
-                    const float *d_logp_old, const float *d_val_old, const float *d_ret, const int64_t *d_index,
-                    int64_t batch, int obs_dim, int act_dim, float cliprange, float vf_coef, float *d_grad,
-                    float *d_workspace, void *stream) {
+                    const float *d_adv_stats, const float *d_logp_old, const float *d_val_old, const float *d_ret,
+                    const int64_t *d_index, int64_t batch, int obs_dim, int act_dim, float cliprange, float vf_coef,
+                    float *d_grad, float *d_workspace, void *stream) {
     if (!d_packed_train || !d_obs || !d_act || !d_adv || !d_logp_old || !d_val_old || !d_ret || !d_grad || !d_workspace)
         return fail(RP_EINVAL, "null argument");
     if (batch < 1) return fail(RP_EINVAL, "batch must be >= 1");
     if (rp_train_packed_floats(obs_dim, act_dim) < 0) return RP_EUNSUPPORTED;
+    int dev = 0;
+    if (int rc0 = enter_device(d_packed_train, &dev)) return rc0;      // the blob's device is the device of the call
     const Layout L = layout_of(obs_dim, act_dim);
     const int gs = gstride_of(obs_dim, act_dim);
     const long blocks = grad_blocks(batch), waves = blocks * WAVES_PER_BLOCK;
     auto lds_of = [&](int net, int nj, int kx_inst) { return grad_lds_bytes(L, net, nj, kx_inst); };
     hipStream_t st = static_cast<hipStream_t>(stream);
     TrainArgs a;
-    a.packed = d_packed_train; a.obs = d_obs; a.act = d_act; a.adv = d_adv; a.logp_old = d_logp_old; a.val_old = d_val_old;
+    a.packed = d_packed_train; a.obs = d_obs; a.act = d_act; a.adv = d_adv; a.adv_stats = d_adv_stats; a.logp_old = d_logp_old; a.val_old = d_val_old;
     a.ret = d_ret; a.index = reinterpret_cast<const long long *>(d_index); a.B = batch; a.obs_dim = obs_dim; a.act_dim = act_dim; a.gstride = gs; a.cliprange = cliprange;
     a.vf_coef = vf_coef; a.inv_B = 1.0f / float(batch);
     const int kx = (obs_dim + 1 + 31) / 32;
@@ -601,12 +583,12 @@ int rp_ppo_grad_dev(const float *d_packed_train, const float *d_obs, const float
     // instances: the reference's robot class (obs <= 31, up to 8 actions) and the general one (obs <= 63, 64 actions)
     // instances: the reference's robot class (obs <= 31, up to 8 actions) and the general one (obs <= 63, 64 actions)
     const bool small = kx == 1 && act_dim <= 8;
-    if (small) rc = launch_grad<0, 1, 8>(a, blocks, lds_of(0, 8, 1), st);
-    else rc = launch_grad<0, 2, 64>(a, blocks, lds_of(0, 64, 2), st);
+    if (small) rc = launch_grad<0, 1, 8>(a, blocks, lds_of(0, 8, 1), dev, st);
+    else rc = launch_grad<0, 2, 64>(a, blocks, lds_of(0, 64, 2), dev, st);
     if (rc) return rc;
     a.partials = d_workspace + waves * gs;
-    if (small) rc = launch_grad<1, 1, 8>(a, blocks, lds_of(1, 8, 1), st);
-    else rc = launch_grad<1, 2, 8>(a, blocks, lds_of(1, 8, 2), st);
+    if (small) rc = launch_grad<1, 1, 8>(a, blocks, lds_of(1, 8, 1), dev, st);
+    else rc = launch_grad<1, 2, 8>(a, blocks, lds_of(1, 8, 2), dev, st);
     if (rc) return rc;
     for (int net = 0; net < 2; ++net) {
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((gs + 255) / 256), dim3(256), 0, st, d_workspace + net * waves * gs,

@@ -31,7 +31,7 @@ struct LaneLds {
     __device__ __forceinline__ float &operator()(int slot) const { return p[slot * 64]; }
 };
 
-constexpr int STAGE_SLOTS = 3 * RBL_NQ > 2 * RBL_NQ + RBL_NT ? 3 * RBL_NQ : 2 * RBL_NQ + RBL_NT;   // widest row set a wave transposes (obs | q, qd, act)
+constexpr int STAGE_SLOTS = 5 * RBL_NQ > 3 * RBL_NQ + RBL_NT ? 5 * RBL_NQ : 3 * RBL_NQ + RBL_NT;   // widest row set a wave transposes (q, qd, obs out | q, qd, goal, act in)
 constexpr int REGION_SLOTS = RBL_ACCEL_LDS > STAGE_SLOTS ? RBL_ACCEL_LDS : STAGE_SLOTS;  // acceleration slots, aliased by the transposes
 constexpr int ACC_SLOT = REGION_SLOTS;                                                   // RK4 accumulators: qa at ACC_SLOT + j, va at ACC_SLOT + NQ + j
 constexpr int LDS_SLOTS = REGION_SLOTS + 2 * RBL_NQ;
@@ -68,23 +68,7 @@ __device__ __forceinline__ void fence_code() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// rows [64][W] of a wave, env-major in HBM -> out[W] of each lane.  live = envs of this wave inside the batch;
-// a lane past the end shadows the last live env.  All W loads are issued before the first one is waited for.
-template <int W>
-__device__ __forceinline__ void load_rows(const float *__restrict__ g, long env0, int live, float *region, int lane_, float (&out)[W]) {
-    const int lane = opaque(lane_);
-    const __amdgpu_buffer_rsrc_t r = rows_rsrc(g, env0, W, live);
-    float t[W];
-#pragma unroll
-    for (int k = 0; k < W; ++k) t[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, k * 256, 0));
-#pragma unroll
-    for (int k = 0; k < W; ++k) region[k * 64 + lane] = t[k];
-    lane_wave_sync();
-    const int row = (lane < live ? lane : live - 1) * W;
-#pragma unroll
-    for (int j = 0; j < W; ++j) out[j] = region[row + j];
-    lane_wave_sync();
-}
+// out[W] of each lane -> rows [64][W] of a wave, env-major in HBM (live = envs of this wave inside the batch)
 template <int W>
 __device__ __forceinline__ void store_rows(float *__restrict__ g, long env0, int live, float *region, int lane_, const float (&in)[W]) {
     const int lane = opaque(lane_);
@@ -156,13 +140,15 @@ __device__ __forceinline__ bool lane_step(const LaneLds &L, const float (&spu)[R
     return ok;
 }
 
-// the three input row sets of a step at once: every load is in flight before the first is waited for
+// the input row sets of a step at once (GOAL: the env layer's goal rows too): every load is in flight before the
+// first is waited for - one memory latency per step, not one per array
+template <bool GOAL>
 __device__ __forceinline__ void load_inputs(const float *__restrict__ gq, const float *__restrict__ gqd, const float *__restrict__ act,
-                                            long env0, int live, float *region, int lane_, float (&q)[RBL_NQ], float (&v)[RBL_NQ],
-                                            float (&a)[RBL_NT]) {
+                                            const float *__restrict__ ggoal, long env0, int live, float *region, int lane_,
+                                            float (&q)[RBL_NQ], float (&v)[RBL_NQ], float (&a)[RBL_NT], float (&gl)[RBL_NQ]) {
     const int lane = opaque(lane_);
     const __amdgpu_buffer_rsrc_t rq = rows_rsrc(gq, env0, RBL_NQ, live), rv = rows_rsrc(gqd, env0, RBL_NQ, live), ra = rows_rsrc(act, env0, RBL_NT, live);
-    float tq[RBL_NQ], tv[RBL_NQ], ta[RBL_NT];
+    float tq[RBL_NQ], tv[RBL_NQ], ta[RBL_NT], tg[RBL_NQ];
 #pragma unroll
     for (int k = 0; k < RBL_NQ; ++k) {
         tq[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rq, lane * 4, k * 256, 0));
@@ -170,17 +156,59 @@ __device__ __forceinline__ void load_inputs(const float *__restrict__ gq, const 
     }
 #pragma unroll
     for (int k = 0; k < RBL_NT; ++k) ta[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, lane * 4, k * 256, 0));
-    constexpr int OV = RBL_NQ * 64, OA = 2 * RBL_NQ * 64;
+    if (GOAL) {
+        const __amdgpu_buffer_rsrc_t rg = rows_rsrc(ggoal, env0, RBL_NQ, live);
+#pragma unroll
+        for (int k = 0; k < RBL_NQ; ++k) tg[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, lane * 4, k * 256, 0));
+    }
+    constexpr int OV = RBL_NQ * 64, OA = 2 * RBL_NQ * 64, OG = (2 * RBL_NQ + RBL_NT) * 64;
 #pragma unroll
     for (int k = 0; k < RBL_NQ; ++k) { region[k * 64 + lane] = tq[k]; region[OV + k * 64 + lane] = tv[k]; }
 #pragma unroll
     for (int k = 0; k < RBL_NT; ++k) region[OA + k * 64 + lane] = ta[k];
+    if (GOAL) {
+#pragma unroll
+        for (int k = 0; k < RBL_NQ; ++k) region[OG + k * 64 + lane] = tg[k];
+    }
     lane_wave_sync();
     const int row = lane < live ? lane : live - 1;
 #pragma unroll
     for (int j = 0; j < RBL_NQ; ++j) { q[j] = region[row * RBL_NQ + j]; v[j] = region[OV + row * RBL_NQ + j]; }
 #pragma unroll
     for (int k = 0; k < RBL_NT; ++k) a[k] = region[OA + row * RBL_NT + k];
+    if (GOAL) {
+#pragma unroll
+        for (int j = 0; j < RBL_NQ; ++j) gl[j] = region[OG + row * RBL_NQ + j];
+    }
+    lane_wave_sync();
+}
+
+// the output row sets of a step at once: one transpose, then every store back to back (q | qd, then - env layer -
+// the observation rows, which repeat them in front of the goal)
+template <bool OBS>
+__device__ __forceinline__ void store_outputs(float *__restrict__ gq, float *__restrict__ gqd, float *__restrict__ gobs, long env0, int live,
+                                              float *region, int lane_, const float (&q)[RBL_NQ], const float (&v)[RBL_NQ],
+                                              const float (&o)[3 * RBL_NQ]) {
+    const int lane = opaque(lane_);
+    constexpr int OV = RBL_NQ * 64, OO = 2 * RBL_NQ * 64;
+#pragma unroll
+    for (int j = 0; j < RBL_NQ; ++j) { region[lane * RBL_NQ + j] = q[j]; region[OV + lane * RBL_NQ + j] = v[j]; }
+    if (OBS) {
+#pragma unroll
+        for (int j = 0; j < 3 * RBL_NQ; ++j) region[OO + lane * (3 * RBL_NQ) + j] = o[j];
+    }
+    lane_wave_sync();
+    const __amdgpu_buffer_rsrc_t rq = rows_rsrc(gq, env0, RBL_NQ, live), rv = rows_rsrc(gqd, env0, RBL_NQ, live);
+#pragma unroll
+    for (int k = 0; k < RBL_NQ; ++k) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(region[k * 64 + lane]), rq, lane * 4, k * 256, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(region[OV + k * 64 + lane]), rv, lane * 4, k * 256, 0);
+    }
+    if (OBS) {
+        const __amdgpu_buffer_rsrc_t ro = rows_rsrc(gobs, env0, 3 * RBL_NQ, live);
+#pragma unroll
+        for (int k = 0; k < 3 * RBL_NQ; ++k) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(region[OO + k * 64 + lane]), ro, lane * 4, k * 256, 0);
+    }
     lane_wave_sync();
 }
 
@@ -196,13 +224,15 @@ tree_lane_step(float *__restrict__ q, float *__restrict__ qd, uint32_t *__restri
     const int live = n - env0 < 64 ? int(n - env0) : 64;
     float *region = lds_lane;
     const LaneLds L{region + lane};
-    float qq[RBL_NQ], vv[RBL_NQ], spu[RBL_NT];
-    load_inputs(q, qd, act, env0, live, region, lane, qq, vv, spu);
+    float qq[RBL_NQ], vv[RBL_NQ], spu[RBL_NT], none[RBL_NQ];
+    load_inputs<false>(q, qd, act, nullptr, env0, live, region, lane, qq, vv, spu, none);
 #pragma unroll
     for (int k = 0; k < RBL_NT; ++k) spu[k] = (spu[k] * act_scale) * KSG[k];
     const bool ok = lane_step<INTEG>(L, spu, h, nsub, qq, vv);
-    store_rows<RBL_NQ>(q, env0, live, region, lane, qq);
-    store_rows<RBL_NQ>(qd, env0, live, region, lane, vv);
+    {
+        float no_obs[3 * RBL_NQ];
+        store_outputs<false>(q, qd, nullptr, env0, live, region, lane, qq, vv, no_obs);
+    }
     if (lane < live) feas[env0 + lane] = ok ? 1u : 0u;
 }
 
@@ -222,8 +252,13 @@ tree_lane_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__res
     const int live = n - env0 < 64 ? int(n - env0) : 64;
     float *region = lds_lane;
     const LaneLds L{region + lane};
-    float qq[RBL_NQ], vv[RBL_NQ], spu[RBL_NT];
-    load_inputs(q, qd, act, env0, live, region, lane, qq, vv, spu);
+    float qq[RBL_NQ], vv[RBL_NQ], spu[RBL_NT], gg[RBL_NQ];
+    load_inputs<true>(q, qd, act, goal, env0, live, region, lane, qq, vv, spu, gg);
+    // the env's counters, requested now as well (their latency passes behind the acceleration)
+    const bool mine = lane < live;
+    const long me = env0 + (mine ? lane : live - 1);
+    const uint32_t sn_old = step_num[me];
+    const float ret_old = ep_ret[me];
 #pragma unroll
     for (int k = 0; k < RBL_NT; ++k) {
         // clamp to the action box, then slope * (x - in_high) + out_high with two roundings (roboy_env.py:157-158)
@@ -233,25 +268,19 @@ tree_lane_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__res
     const bool ok = lane_step<INTEG>(L, spu, h, nsub, qq, vv);
     // observation [q | qd | goal], reward, done; goal redraw (and reset) on done
     float o[3 * RBL_NQ];
-    {
-        float gg[RBL_NQ];
-        load_rows<RBL_NQ>(goal, env0, live, region, lane, gg);
 #pragma unroll
-        for (int j = 0; j < RBL_NQ; ++j) { o[j] = qq[j]; o[RBL_NQ + j] = vv[j]; o[2 * RBL_NQ + j] = gg[j]; }
-    }
+    for (int j = 0; j < RBL_NQ; ++j) { o[j] = qq[j]; o[RBL_NQ + j] = vv[j]; o[2 * RBL_NQ + j] = gg[j]; }
     float dq2 = 0.0f, dv2 = 0.0f;
 #pragma unroll
     for (int j = 0; j < RBL_NQ; ++j) {
         const float dq = o[j] - o[2 * RBL_NQ + j];
         dq2 += dq * dq; dv2 += o[RBL_NQ + j] * o[RBL_NQ + j];
     }
-    const bool mine = lane < live;
-    const long me = env0 + (mine ? lane : live - 1);
-    uint32_t sn = step_num[me] + 1u;
+    uint32_t sn = sn_old + 1u;
     bool reached;
     const float r = rbe::env_reward(ep, dq2, dv2, ok, reached);
     const bool dn = reached || (sn > uint32_t(ep.max_len));
-    float ret = ep_ret[me] + r;
+    float ret = ret_old + r;
     uint32_t fz = ok ? 1u : 0u;
     float gn[RBL_NQ];                                     // the goal after this step (redrawn on done)
 #pragma unroll
@@ -283,10 +312,8 @@ tree_lane_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__res
         ret = 0.0f;
     }
     // rows back: state, goal (only the lanes that redrew change it), observation
-    store_rows<RBL_NQ>(q, env0, live, region, lane, qq);
-    store_rows<RBL_NQ>(qd, env0, live, region, lane, vv);
+    store_outputs<true>(q, qd, obs, env0, live, region, lane, qq, vv, o);
     if (__builtin_amdgcn_ballot_w64(dn && mine) != 0ull) store_rows<RBL_NQ>(goal, env0, live, region, lane, gn);
-    store_rows<3 * RBL_NQ>(obs, env0, live, region, lane, o);
     if (mine) {
         feas[me] = fz; step_num[me] = sn; ep_ret[me] = ret; reward[me] = r; done[me] = dn ? 1u : 0u;
         if (!ok) infeas_n[me] += 1u;

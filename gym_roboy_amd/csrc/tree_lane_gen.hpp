@@ -545,7 +545,7 @@ inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::str
 // LDS slots per lane of the kernels of tree_lane.hpp (the formula of its LDS_SLOTS): the acceleration's slots, aliased
 // by the row transposes, then the RK4 accumulators
 inline int lane_lds_slots(const Generated &g) {
-    const int stage = 3 * g.n_q > 2 * g.n_q + g.n_t ? 3 * g.n_q : 2 * g.n_q + g.n_t;
+    const int stage = 5 * g.n_q > 3 * g.n_q + g.n_t ? 5 * g.n_q : 3 * g.n_q + g.n_t;
     return (g.lds_slots > stage ? g.lds_slots : stage) + 2 * g.n_q;
 }
 inline size_t lane_lds_bytes_per_wave(const Generated &g) { return size_t(lane_lds_slots(g)) * 64 * 4; }

@@ -141,8 +141,8 @@ class FusedPolicyGrad:
     """The PPO minibatch gradient of an ``MlpPolicy`` as MFMA kernels (include/roboy_policy.h: rp_ppo_grad_dev,
     csrc/mlp_train.hip): forward, clipped-surrogate / clipped-value loss derivative, back-propagation and the weight
     gradients of both networks without materialising an activation in memory.  ``run()`` fills ``p.grad`` of every
-    parameter (views of one flat buffer) and returns the two loss terms; optimiser, gradient clipping and the
-    cross-rank average stay torch's."""
+    parameter (views of one flat buffer) and returns the two loss terms.  The advantage's per-minibatch normalisation
+    happens inside (``adv_stats`` from ``minibatch_adv_stats()``); clipping and the optimiser step are ``FusedAdam``."""
 
     def __init__(self, policy):
         import ctypes
@@ -150,6 +150,10 @@ class FusedPolicyGrad:
         self._pn, self._ct, self._lib = pn, ctypes, pn.load()
         self.policy = policy
         self.obs_dim, self.act_dim = policy.pi[0].in_features, policy.pi[-1].out_features
+        # the gather map and the gradient layout are built for MlpPolicy's shape: anything else would be indexed wrongly
+        if (len(policy.pi) != 5 or len(policy.vf) != 5 or policy.pi[0].out_features != 64 or policy.pi[2].out_features != 64
+                or policy.vf[0].out_features != 64 or policy.vf[2].out_features != 64):
+            raise ValueError("the fused PPO gradient is built for MlpPolicy's two hidden layers of 64 units")
         dev = policy.log_std.device
         m, _ = pn.gather_map(self.obs_dim, self.act_dim, train=True)
         self._map = torch.from_numpy(m).to(dev)
@@ -167,12 +171,28 @@ class FusedPolicyGrad:
             off, shape = layout[name]
             self._views[name] = self._g[off:off + p.numel()].view(shape)
         self._ws = None
+        self._stats = torch.zeros(2, device=dev)
+        self._stat_scratch = torch.zeros(int(self._lib.rp_adv_stats_scratch_doubles()), dtype=torch.float64, device=dev)
 
     @torch.no_grad()
-    def run(self, obs, act, adv, logp_old, val_old, ret, cliprange, vf_coef, ent_coef, index=None):
+    def minibatch_adv_stats(self, adv_full, index):
+        """{mean, 1 / (std + 1e-8)} of adv_full[index] (device tensor of 2 floats, overwritten by the next call)."""
+        c = self._ct
+        self._pn.check(self._lib.rp_adv_stats_dev(
+            c.c_void_p(adv_full.data_ptr()), c.c_void_p(index.data_ptr()) if index is not None else None,
+            int(index.shape[0] if index is not None else adv_full.shape[0]), c.c_void_p(self._stats.data_ptr()),
+            c.c_void_p(self._stat_scratch.data_ptr()), c.c_void_p(torch.cuda.current_stream(adv_full.device).cuda_stream)))
+        return self._stats
+
+    @torch.no_grad()
+    def run(self, obs, act, adv, logp_old, val_old, ret, cliprange, vf_coef, ent_coef, index=None, adv_stats=None,
+            entropy_grad=True):
         """index (int64 [B], optional): minibatch sample i is row index[i] of obs / act / logp_old / val_old / ret
-        (the whole rollout's tensors, no gathered copies); adv is always in minibatch order."""
-        c, B = self._ct, int(adv.shape[0])
+        (the whole rollout's tensors, no gathered copies).  adv: in minibatch order and normalised by the caller, or
+        - with adv_stats (minibatch_adv_stats()) - the rollout's raw advantage, indexed like the rest and normalised
+        in the kernel.  entropy_grad=False leaves the entropy bonus of the log-std to FusedAdam.step()."""
+        c = self._ct
+        B = int(index.shape[0]) if (index is not None and adv_stats is not None) else int(adv.shape[0])
         flat = torch.cat([self._named[k].detach().reshape(-1) for k in self._pn.PARAM_ORDER] + [self._zero])
         packed = flat[self._map]
         need = int(self._lib.rp_ppo_workspace_floats(self.obs_dim, self.act_dim, B))
@@ -180,15 +200,67 @@ class FusedPolicyGrad:
             self._ws = torch.empty(need, device=obs.device)
         ptr = lambda t: c.c_void_p(t.data_ptr()) if t is not None else None
         self._pn.check(self._lib.rp_ppo_grad_dev(
-            ptr(packed), ptr(obs), ptr(act), ptr(adv), ptr(logp_old), ptr(val_old), ptr(ret), ptr(index), B, self.obs_dim, self.act_dim,
+            ptr(packed), ptr(obs), ptr(act), ptr(adv), ptr(adv_stats), ptr(logp_old), ptr(val_old), ptr(ret), ptr(index), B,
+            self.obs_dim, self.act_dim,
             float(cliprange), float(vf_coef), ptr(self._g), ptr(self._ws),
             c.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)))
-        self._views["log_std"] -= ent_coef            # entropy bonus of a state-independent log-std
+        if entropy_grad:
+            self._views["log_std"] -= ent_coef        # entropy bonus of a state-independent log-std
         for name, p in self._named.items():
             p.grad = self._views[name]
         pg = self._g[self._layout["pi_loss"][0]]
         vf = self._g[self._layout["vf_loss"][0]]
         return pg, vf
+
+
+class FusedAdam:
+    """``clip_grad_norm_`` + ``torch.optim.Adam.step`` as ONE launch (include/roboy_policy.h: rp_clip_adam_dev) over the
+    flat gradient vector of a ``FusedPolicyGrad``.  The policy's parameters become views of one flat buffer laid out
+    like that vector, so the kernel updates them in place and the cross-rank average is one all-reduce of one
+    contiguous tensor.  State (first / second moments, step count) is checkpointed by ``state_dict()``."""
+
+    def __init__(self, fgrad, lr, betas=(0.9, 0.999), eps=1e-5, max_grad_norm=0.5):
+        self._f = fgrad
+        self.lr, self.betas, self.eps, self.max_grad_norm = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(max_grad_norm)
+        g = fgrad._g
+        self.params = torch.zeros_like(g)
+        with torch.no_grad():
+            for name, p in fgrad._named.items():
+                off, shape = fgrad._layout[name]
+                view = self.params[off:off + p.numel()].view(shape)
+                view.copy_(p.data)
+                p.data = view                              # the module's parameter IS the slice of the flat buffer
+        self.m, self.v = torch.zeros_like(g), torch.zeros_like(g)
+        self.t = 0
+
+    @torch.no_grad()
+    def step(self, ent_coef, dist=None):
+        f, c = self._f, self._f._ct
+        scale = 1.0
+        if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(f._g)                      # one bucket: the whole gradient vector, contiguous
+            else:                                          # rehearsal over gloo: through the host
+                host = f._g.cpu()
+                dist.all_reduce(host)
+                f._g.copy_(host)
+            scale = 1.0 / dist.get_world_size()
+        self.t += 1
+        ptr = lambda t: c.c_void_p(t.data_ptr())
+        f._pn.check(f._lib.rp_clip_adam_dev(ptr(self.params), ptr(f._g), ptr(self.m), ptr(self.v), f.obs_dim, f.act_dim, self.lr,
+                                            self.betas[0], self.betas[1], self.eps, self.t, self.max_grad_norm, scale, float(ent_coef),
+                                            c.c_void_p(torch.cuda.current_stream(f._g.device).cuda_stream)))
+        return scale
+
+    def state_dict(self):
+        return {"fused_adam": True, "m": self.m.clone(), "v": self.v.clone(), "t": self.t}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.t = int(sd["t"])
+
+    def rebind(self, state_dict):
+        """load_state_dict() of the module copies INTO the views (in place), so nothing to re-point; kept for clarity."""
+        return state_dict
 
 
 def average_gradients(module, dist=None):
@@ -206,11 +278,26 @@ def average_gradients(module, dist=None):
             off += n
 
 
+def _fused_kernels_apply(policy, obs_dim, act_dim):
+    """MlpPolicy's shape (two hidden layers of 64 units per net) in dimensions the kernels of include/roboy_policy.h
+    support, and the library is there."""
+    try:
+        from . import _policy_native as pn
+        ok_shape = (isinstance(policy, MlpPolicy) and len(policy.pi) == 5 and len(policy.vf) == 5
+                    and all(l.out_features == 64 for l in (policy.pi[0], policy.pi[2], policy.vf[0], policy.vf[2])))
+        return bool(ok_shape and pn.load().rp_train_packed_floats(obs_dim, act_dim) > 0)
+    except Exception:
+        return False
+
+
 class PPO:
     def __init__(self, env, policy=None, n_steps=128, nminibatches=4, noptepochs=4, gamma=0.99, lam=0.95,
                  learning_rate=2.5e-4, cliprange=0.2, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5,
-                 device="cuda", dist=None, reward_scale=1.0, seed=0, use_graphs=False, fused_policy=False,
-                 fused_update=False):
+                 device="cuda", dist=None, reward_scale=1.0, seed=0, use_graphs=False, fused_policy=None,
+                 fused_update=None):
+        """fused_policy / fused_update: None = the fused MFMA kernels whenever they apply (a GPU, MlpPolicy's shape,
+        dimensions the kernels support), True = insist, False = the torch path (the statement the kernels are
+        tested against)."""
         self.env, self.dist, self.device = env, dist, torch.device(device)
         torch.manual_seed(seed)
         obs_dim = env.observation_space.shape[0]
@@ -223,8 +310,16 @@ class PPO:
             # `rank` with seed + rank (/root/reference/gym_roboy/train_parallel.py:24)
             torch.manual_seed(seed + dist.get_rank())
         multi_rank = dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        self.use_graphs = bool(use_graphs) and self.device.type == "cuda" and hasattr(env, "step_dev") and not multi_rank
+        # the rollout (policy step, env step, GAE) is rank-local, so it is captured on every rank; the collectives
+        # (gradient average, statistics) stay outside the graph
+        self.use_graphs = bool(use_graphs) and self.device.type == "cuda" and hasattr(env, "step_dev")
+        if fused_policy is None or fused_update is None:
+            auto = self.device.type == "cuda" and _fused_kernels_apply(self.policy, obs_dim, act_dim)
+            fused_policy = auto if fused_policy is None else fused_policy
+            fused_update = auto if fused_update is None else fused_update
         self.opt = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5)
+        self._epoch = 0                       # update epochs so far: keys the fused path's sample order
+        self._seed = int(seed) + (7919 * dist.get_rank() if multi_rank else 0)
         self._rollout_graph = None
         # fused_policy: the rollout's policy step runs as one MFMA kernel (FusedPolicyStep) instead of ~30 torch kernels
         self._fused = None
@@ -240,6 +335,7 @@ class PPO:
             if self.device.type != "cuda":
                 raise ValueError("fused_update needs a GPU")
             self._fgrad = FusedPolicyGrad(self.policy)
+            self._fadam = FusedAdam(self._fgrad, learning_rate, eps=1e-5, max_grad_norm=max_grad_norm)
         self.n_steps, self.nminibatches, self.noptepochs = n_steps, nminibatches, noptepochs
         self.gamma, self.lam, self.cliprange = gamma, lam, cliprange
         self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
@@ -304,7 +400,9 @@ class PPO:
                 self._fused.act_into(b["carry"], b["act"][0], b["logp"][0], b["val"][0], deterministic=True)
         side.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
+        # thread-local capture mode: another thread of the process (RCCL's watchdog in a multi-rank run) may call into
+        # the runtime while this one captures
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
             self._rollout_body(b)
         torch.cuda.current_stream(dev).wait_stream(side)
         # replays (and every later eager env call) run on the caller's current stream
@@ -372,15 +470,14 @@ class PPO:
         return pg - self.ent_coef * ent + self.vf_coef * vf, pg, vf, ent
 
     def _minibatch_step_fused(self, flat, idx):
-        adv = flat["adv"][idx]
-        adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).contiguous()
-        # the rollout's own tensors + the minibatch's row indices: the kernels gather, nothing is copied
-        pg, vf = self._fgrad.run(flat["obs"], flat["act"], adv, flat["logp"], flat["val"], flat["ret"], self.cliprange,
-                                 self.vf_coef, self.ent_coef, index=idx.contiguous())
+        """Four launches + two small reductions per minibatch: advantage statistics, the two gradient kernels (which
+        gather the rollout's rows through idx and normalise the advantage per sample), clip + Adam."""
+        stats = self._fgrad.minibatch_adv_stats(flat["adv"], idx)
+        pg, vf = self._fgrad.run(flat["obs"], flat["act"], flat["adv"], flat["logp"], flat["val"], flat["ret"], self.cliprange,
+                                 self.vf_coef, self.ent_coef, index=idx, adv_stats=stats, entropy_grad=False)
+        scale = self._fadam.step(self.ent_coef, self.dist)          # all-reduces the gradient vector first when ranks > 1
         ent = (0.5 + 0.5 * math.log(2 * math.pi) + self.policy.log_std.detach()).sum()
-        average_gradients(self.policy, self.dist)
-        nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
-        self.opt.step()
+        pg, vf = pg * scale, vf * scale                              # (the loss slots were summed over the ranks with the rest)
         return pg - self.ent_coef * ent + self.vf_coef * vf, pg, vf, ent
 
     def _minibatch_step(self, flat, idx):
@@ -394,15 +491,32 @@ class PPO:
         self.opt.step()
         return loss, pg, vf, ent
 
-    def update(self, roll):
+    def _sample_order(self, n):
+        """The epoch's sample order.  Torch path: torch.randperm (a sort of n random keys).  Fused path: a keyed bijection
+        of [0, n) evaluated per element on the device (rp_perm_dev), key = (seed, epochs so far)."""
+        self._epoch += 1
+        if self._fgrad is None:
+            return torch.randperm(n, device=self.device)
+        import ctypes as c
+        if getattr(self, "_perm_buf", None) is None or self._perm_buf.numel() != n:
+            self._perm_buf = torch.empty(n, dtype=torch.int64, device=self.device)
+        key = ((self._seed & 0xFFFFFFFF) << 32) | (self._epoch & 0xFFFFFFFF)
+        f = self._fgrad
+        f._pn.check(f._lib.rp_perm_dev(key, n, 0, n, c.c_void_p(self._perm_buf.data_ptr()),
+                                       c.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        return self._perm_buf
+
+    def update(self, roll, sample_orders=None):
+        """sample_orders (optional): one int64 index tensor per epoch instead of the generated order (tests feed the
+        same orders to both optimiser paths)."""
         flat = {k: v.reshape(-1, *v.shape[2:]) for k, v in roll.items()}
         if self._fgrad is not None:          # the gradient kernels index the rollout tensors directly
             flat = {k: v.contiguous() for k, v in flat.items()}
         n = flat["obs"].shape[0]
         mb = max(n // self.nminibatches, 1)
         out = None
-        for _ in range(self.noptepochs):
-            perm = torch.randperm(n, device=self.device)
+        for ep in range(self.noptepochs):
+            perm = self._sample_order(n) if sample_orders is None else sample_orders[ep].contiguous()
             for s in range(0, n - mb + 1, mb):
                 out = self._minibatch_step(flat, perm[s:s + mb])
         if out is None:
@@ -422,11 +536,24 @@ class PPO:
         return self
 
     def save(self, path):
-        torch.save({"policy": self.policy.state_dict(), "optimizer": self.opt.state_dict(),
-                    "num_timesteps": self.num_timesteps}, path)
+        opt = self._fadam.state_dict() if self._fgrad is not None else self.opt.state_dict()
+        torch.save({"policy": self.policy.state_dict(), "optimizer": opt, "num_timesteps": self.num_timesteps,
+                    "epoch": self._epoch}, path)
 
     def load(self, path):
         ck = torch.load(path, map_location=self.device)
-        self.policy.load_state_dict(ck["policy"]); self.opt.load_state_dict(ck["optimizer"])
+        self.policy.load_state_dict(ck["policy"])      # copies in place: the views of the fused optimiser's flat buffer stay valid
+        fused_ck = isinstance(ck["optimizer"], dict) and ck["optimizer"].get("fused_adam", False)
+        if self._fgrad is not None and fused_ck:
+            self._fadam.load_state_dict(ck["optimizer"])
+        elif self._fgrad is None and not fused_ck:
+            self.opt.load_state_dict(ck["optimizer"])
+        # (a checkpoint of the other optimiser form: the moments start afresh)
         self.num_timesteps = ck["num_timesteps"]
+        self._epoch = int(ck.get("epoch", 0))
+        if self._fused is not None:
+            # the exploration noise is keyed (seed; sample, step): continue the step count where the run stopped, so that a
+            # resumed run does not replay the noise of its first rollouts
+            n_envs = getattr(self.env, "num_envs", 1)
+            self._step_base.fill_(int(self.num_timesteps // max(n_envs, 1)) & 0x7FFFFFFF)
         return self

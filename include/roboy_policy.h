@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 1
+#define RP_ABI_VERSION 2
 #define RP_HIDDEN 64          /* units per hidden layer (stable_baselines' MlpPolicy) */
 #define RP_MAX_OBS 95         /* obs_dim + 1 (bias column) <= 96 */
 #define RP_MAX_ACT 64
@@ -82,13 +82,38 @@ int64_t rp_ppo_workspace_floats(int obs_dim, int act_dim, int64_t batch);
 
 /* Device pointers.  d_index == NULL: obs [batch][obs_dim], act [batch][act_dim], adv / logp_old / val_old / ret
  * [batch].  d_index != NULL (int64 [batch]): sample i of the minibatch is ROW d_index[i] of obs, act, logp_old,
- * val_old, ret (the whole rollout's tensors - no gathered copies), while adv [batch] stays in minibatch order (it is
- * normalised per minibatch by the caller).  d_grad: rp_grad_floats() floats (overwritten), d_workspace:
- * rp_ppo_workspace_floats() floats.  Four launches on `stream` (one per net, two reductions); asynchronous. */
+ * val_old, ret (the whole rollout's tensors - no gathered copies).  The advantage: with d_adv_stats == NULL, adv
+ * [batch] is in minibatch order and already normalised by the caller; with d_adv_stats = the {mean, 1 / (std + 1e-8)}
+ * pair rp_adv_stats_dev wrote, adv is the rollout's raw advantage, indexed like the rest and normalised per sample
+ * in the kernel.  d_grad: rp_grad_floats() floats (overwritten), d_workspace: rp_ppo_workspace_floats() floats.
+ * Four launches on `stream` (one per net, two reductions); asynchronous.  Like every rp_*_dev entry point it runs
+ * on the device its first device pointer lives on (made current for the call). */
 int rp_ppo_grad_dev(const float *d_packed_train, const float *d_obs, const float *d_act, const float *d_adv,
-                    const float *d_logp_old, const float *d_val_old, const float *d_ret, const int64_t *d_index,
-                    int64_t batch, int obs_dim, int act_dim, float cliprange, float vf_coef, float *d_grad,
-                    float *d_workspace, void *stream);
+                    const float *d_adv_stats, const float *d_logp_old, const float *d_val_old, const float *d_ret,
+                    const int64_t *d_index, int64_t batch, int obs_dim, int act_dim, float cliprange, float vf_coef,
+                    float *d_grad, float *d_workspace, void *stream);
+
+/* ---- the rest of a PPO update (gym_roboy_amd/ppo.py: update) ---- */
+/* The sample order of an epoch: out[j] = P(first + j), j < count, for a bijection P of [0, n) keyed by `key` (a
+ * four-round Feistel network on the next even power of two, cycle-walked into [0, n)): what torch.randperm(n) is to
+ * the torch path, evaluated per element instead of sorting n keys.  _host: the same function on the CPU. */
+int rp_perm_dev(uint64_t key, int64_t n, int64_t first, int64_t count, int64_t *d_out, void *stream);
+int rp_perm_host(uint64_t key, int64_t n, int64_t first, int64_t count, int64_t *out);
+/* d_stats2 = {mean, 1 / (std + 1e-8)} (std: the unbiased estimate, as torch.Tensor.std) of adv[d_index[i]], i < batch
+ * (d_index == NULL: adv[i]).  d_scratch: rp_adv_stats_scratch_doubles() doubles, zeroed ONCE by the caller (the kernel
+ * leaves it ready for the next call).  One launch; sums in fp64 in a fixed order. */
+int64_t rp_adv_stats_scratch_doubles(void);
+int rp_adv_stats_dev(const float *d_adv, const int64_t *d_index, int64_t batch, float *d_stats2, double *d_scratch, void *stream);
+/* clip_grad_norm_(max_grad_norm) followed by Adam.step() as one launch: d_params, d_m, d_v are rp_grad_floats()
+ * floats in the layout of the gradient vector d_grad (a policy whose parameters are views of d_params sees the
+ * update in place); the gradient is first scaled by grad_scale (1 / world size after an all-reduce) and the entropy
+ * bonus of the state-independent log-std (-ent_coef per component) is added; the loss slots are left alone.  step =
+ * the number of this update, from 1 (bias corrections); eps enters as in torch.optim.Adam. */
+int rp_clip_adam_dev(float *d_params, const float *d_grad, float *d_m, float *d_v, int obs_dim, int act_dim, float lr,
+                     float beta1, float beta2, float eps, int64_t step, float max_grad_norm, float grad_scale, float ent_coef,
+                     void *stream);
+/* test hook: would a grant of lds_bytes of dynamic LDS be issued for (kernel id, device) now?  Records it. */
+int rp_debug_lds_grant_needed(int kernel_id, int dev, int64_t lds_bytes);
 
 #ifdef __cplusplus
 }

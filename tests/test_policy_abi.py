@@ -100,3 +100,36 @@ def test_packed_blob_follows_the_documented_operand_order(obs_dim, act_dim):
                     assert np.array_equal(blob[o:o + 64], p[net + "_w2"][32 * oo + _U(r) + 4 * hf, 32 * ip + row])
                     o += 64
     assert ((o + 3) & ~3) == pn.load().rp_train_packed_floats(obs_dim, act_dim)
+
+
+def test_lds_opt_in_is_remembered_per_kernel_and_per_device():
+    """More than 64 KB of dynamic LDS is granted per kernel with hipFuncSetAttribute - per device: a second device in
+    the same process must get its own grant (the bookkeeping behind csrc/mlp_common.hpp: grant_lds)."""
+    from gym_roboy_amd import _policy_native as pn
+    lib = pn.load()
+    need = lib.rp_debug_lds_grant_needed
+    big = 100 * 1024
+    assert need(7, 40, 32 * 1024) == 0                    # under 64 KB: nothing to grant
+    assert need(7, 40, big) == 1 and need(7, 40, big) == 0
+    assert need(7, 41, big) == 1                          # another device: its own grant
+    assert need(6, 40, big) == 1                          # another kernel too
+    assert need(7, 40, big + 4096) == 1 and need(7, 40, big) == 0      # a larger request is granted again, a smaller one is covered
+
+
+def test_host_permutation_is_a_keyed_bijection():
+    import ctypes as c
+    from gym_roboy_amd import _policy_native as pn
+    lib = pn.load()
+    seen = []
+    for n in (1, 2, 3, 5, 64, 1000, 4097, 65536, 250000):
+        out = np.empty(n, np.int64)
+        assert lib.rp_perm_host(1234, n, 0, n, out.ctypes.data_as(c.c_void_p)) == 0
+        assert np.array_equal(np.sort(out), np.arange(n))
+        if n >= 1000:
+            assert np.mean(out == np.arange(n)) < 0.01                 # not the identity
+            other = np.empty(n, np.int64)
+            assert lib.rp_perm_host(1235, n, 0, n, other.ctypes.data_as(c.c_void_p)) == 0
+            assert np.mean(out == other) < 0.01                        # another key, another order
+            # no structure a shuffle should not have: neighbours in the order are not neighbours in the batch
+            assert np.mean(np.abs(np.diff(out)) == 1) < 0.01
+    assert lib.rp_perm_host(1, 10, 5, 6, np.empty(6, np.int64).ctypes.data_as(c.c_void_p)) != 0

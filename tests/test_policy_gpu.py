@@ -195,14 +195,99 @@ def test_ppo_with_fused_rollout_and_fused_update_learns_like_the_torch_path():
     from gym_roboy_amd.ppo import PPO
     env = RoboyVecEnv(MsjRobot(), 512, seed=1)
     a = PPO(env, n_steps=16, seed=4, reward_scale=0.01, fused_update=True)
-    b = PPO(env, n_steps=16, seed=4, reward_scale=0.01)
+    b = PPO(env, n_steps=16, seed=4, reward_scale=0.01, fused_policy=False, fused_update=False)
+    assert a._fgrad is not None and b._fgrad is None
     b.policy.load_state_dict(copy.deepcopy(a.policy.state_dict()))
     roll = a.collect()
-    torch.manual_seed(9); a.update({k: v.clone() for k, v in roll.items()})
-    torch.manual_seed(9); b.update({k: v.clone() for k, v in roll.items()})       # same minibatch permutations
+    n = roll["obs"].shape[0] * roll["obs"].shape[1]
+    orders = [torch.randperm(n, device="cuda") for _ in range(a.noptepochs)]      # the same sample orders for both
+    a.update({k: v.clone() for k, v in roll.items()}, sample_orders=orders)
+    b.update({k: v.clone() for k, v in roll.items()}, sample_orders=orders)
     for (n, p), (_, q) in zip(a.policy.named_parameters(), b.policy.named_parameters()):
-        assert (p - q).abs().max().item() < 2e-4, n            # 16 Adam steps apart by rounding only
+        assert (p - q).abs().max().item() < 2e-4, n            # 16 clip + Adam steps apart by rounding only
+    # and on its own sample order (the device-side permutation) it keeps training
+    stats = a.update({k: v.clone() for k, v in roll.items()})
+    assert all(np.isfinite(v) for v in stats.values())
     env.close()
+
+
+def test_device_permutation_equals_the_host_statement_and_is_a_bijection():
+    import ctypes as c
+    import torch
+    from gym_roboy_amd import _policy_native as pn
+    lib = pn.load()
+    for n, key in ((1, 5), (2, 6), (37, 7), (4096, 8), (100003, 9), (1 << 20, (3 << 32) | 4)):
+        out = torch.empty(n, dtype=torch.int64, device="cuda")
+        pn.check(lib.rp_perm_dev(key, n, 0, n, c.c_void_p(out.data_ptr()), c.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        host = np.empty(n, np.int64)
+        pn.check(lib.rp_perm_host(key, n, 0, n, host.ctypes.data_as(c.c_void_p)))
+        got = out.cpu().numpy()
+        assert np.array_equal(got, host)
+        assert np.array_equal(np.sort(got), np.arange(n))
+    # a slice of the order is the slice of the whole
+    part = torch.empty(1000, dtype=torch.int64, device="cuda")
+    pn.check(lib.rp_perm_dev(9, 100003, 5000, 1000, c.c_void_p(part.data_ptr()), c.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    whole = np.empty(100003, np.int64)
+    pn.check(lib.rp_perm_host(9, 100003, 0, 100003, whole.ctypes.data_as(c.c_void_p)))
+    assert np.array_equal(part.cpu().numpy(), whole[5000:6000])
+
+
+@pytest.mark.parametrize("B,total", [(1, 10), (2, 10), (1000, 5000), (70001, 300000)])
+def test_minibatch_advantage_statistics_match_torch(B, total):
+    import torch
+    from gym_roboy_amd.ppo import FusedPolicyGrad
+    fg = FusedPolicyGrad(_policy(9, 8, 1).cuda())
+    g = torch.Generator().manual_seed(B)
+    adv = (torch.randn(total, generator=g) * 3.0 + 1.5).cuda()
+    idx = torch.randperm(total, generator=g)[:B].cuda()
+    for _ in range(2):                                         # the scratch block is left ready for the next call
+        st = fg.minibatch_adv_stats(adv, idx).cpu()
+        sel = adv[idx].double()
+        mean = sel.mean().item()
+        inv = 1.0 / ((sel.std().item() if B > 1 else float("nan")) + 1e-8) if B > 1 else 1e8
+        assert abs(st[0].item() - mean) < 1e-5 * max(1.0, abs(mean))
+        assert abs(st[1].item() - inv) < 1e-4 * inv
+
+
+@pytest.mark.parametrize("obs_dim,act_dim", [(9, 8), (60, 38)])
+def test_fused_clip_and_adam_equal_torch_clip_and_adam(obs_dim, act_dim):
+    """FusedAdam.step() over the gradient vector against clip_grad_norm_ + torch.optim.Adam.step() on a copy of the
+    policy, for gradients that are clipped (large) and not (small), over several steps (bias corrections)."""
+    import copy
+    import torch
+    from gym_roboy_amd.ppo import FusedAdam, FusedPolicyGrad
+    policy = _policy(obs_dim, act_dim, 3).cuda()
+    ref = copy.deepcopy(policy)
+    fg = FusedPolicyGrad(policy)
+    fa = FusedAdam(fg, 2.5e-4, eps=1e-5, max_grad_norm=0.5)
+    opt = torch.optim.Adam(ref.parameters(), lr=2.5e-4, eps=1e-5)
+    names = [n for n, _ in policy.named_parameters()]
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    ent_coef = 0.1
+    for step, mag in enumerate((5.0, 1e-3, 0.3, 2.0, 1e-2)):
+        fg._g.copy_(torch.randn(fg._g.shape, device="cuda", generator=gen) * mag)
+        for (name, p), (_, q) in zip(fg._named.items(), [(n, dict(ref.named_parameters())[_torch_name(n)]) for n in fg._named]):
+            q.grad = fg._views[name].detach().clone()
+        dict(ref.named_parameters())["log_std"].grad -= ent_coef                   # the entropy bonus FusedAdam adds itself
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+        opt.step()
+        fa.step(ent_coef)
+        torch.cuda.synchronize()
+        for name, p in fg._named.items():
+            q = dict(ref.named_parameters())[_torch_name(name)]
+            assert (p.detach() - q.detach()).abs().max().item() < 2e-6 * (step + 1), (name, step)
+    # the module's parameters are views of the flat buffer: a state_dict round trip keeps them attached
+    sd = copy.deepcopy(policy.state_dict())
+    policy.load_state_dict(sd)
+    assert policy.log_std.data_ptr() == fa.params[fg._layout["log_std"][0]:].data_ptr()
+
+
+def _torch_name(n):
+    """'pi_w1' -> 'pi.0.weight' ..."""
+    if n == "log_std":
+        return n
+    net, kind = n.split("_")
+    return "%s.%d.%s" % (net, {"1": 0, "2": 2, "3": 4}[kind[1]], "weight" if kind[0] == "w" else "bias")
 
 
 def test_fused_gae_equals_the_torch_loop():

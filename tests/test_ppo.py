@@ -113,7 +113,8 @@ def test_graph_mode_rollout_is_a_valid_rollout():
     from gym_roboy_amd.ppo import gae
     T, N = 16, 512
     env = RoboyVecEnv(MsjRobot(), N, seed=3)
-    agent = PPO(env, n_steps=T, device="cuda", ent_coef=0.1, reward_scale=0.01, seed=4, use_graphs=True)
+    agent = PPO(env, n_steps=T, device="cuda", ent_coef=0.1, reward_scale=0.01, seed=4, use_graphs=True,
+                fused_policy=False, fused_update=False)     # the torch path: the exact statement of a rollout
     assert agent.use_graphs
     roll = {k: v.clone() for k, v in agent.collect().items()}
     assert all(bool(torch.isfinite(v).all()) for v in roll.values())
@@ -192,3 +193,40 @@ def test_train_then_play_back(tmp_path, capsys):
     total = visualize_agent.main([os.path.join(out, "model.pkl"), "--steps", "20", "--pause", "0"])
     assert np.isfinite(total)
     assert "reward" in capsys.readouterr().out
+
+
+def _train_rank(rank, world, port, out_dir):
+    import torch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from gym_roboy_amd import train_parallel
+    import contextlib, io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        agent = train_parallel.main(["256", os.path.join(out_dir, "results"), "--rounds", "1", "--steps-per-round", str(256 * 32 * 3),
+                                     "--n-steps", "32", "--backend", "gloo"])
+    torch.cuda.synchronize()
+    torch.save({"params": [p.detach().cpu() for p in agent.policy.parameters()], "graphs": agent.use_graphs,
+                "graph_built": agent._rollout_graph is not None, "stdout": buf.getvalue(),
+                "local_steps": agent.env.stats()["n_env_steps"]}, os.path.join(out_dir, "rank%d.pt" % rank))
+
+
+@pytest.mark.gpu
+def test_two_rank_training_replays_graphs_and_reports_the_statistics_of_all_ranks(tmp_path):
+    """train_parallel with two ranks (sharing the one GPU, collectives over gloo): every rank replays its own captured
+    rollout graph, the parameters stay identical across the ranks, and the statistics rank 0 prints are the sum over
+    both ranks' envs (reference: one process per env, /root/reference/gym_roboy/train_parallel.py:19-35)."""
+    import re
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    mp.spawn(_train_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert a["graphs"] and b["graphs"] and a["graph_built"] and b["graph_built"]
+    for p, q in zip(a["params"], b["params"]):
+        assert torch.equal(p, q)
+    assert a["local_steps"] == b["local_steps"] == 256 * 32 * 3
+    m = re.search(r"'n_env_steps': ([0-9.]+)", a["stdout"])
+    assert m and float(m.group(1)) == 2 * 256 * 32 * 3          # both ranks' env steps
+    assert "episode statistics" not in b["stdout"]             # one report, by rank 0
