@@ -49,6 +49,7 @@ WORKLOADS = {
     "msj-262144-euler": (262144, "euler", 1, 800, 80, "configs[4] shard: MsjRobot 262 144 envs per GPU, semi-implicit Euler fp32"),
     "msj-4096-euler": (4096, "euler", 1, 4000, 200, "configs[1]: MsjRobot 4 096 envs, semi-implicit Euler fp32"),
     "msj-2097152-euler": (2097152, "euler", 1, 300, 30, "large batch: MsjRobot 2 097 152 envs on one GPU, Euler fp32"),
+    "msj-2097152-rk4": (2097152, "rk4", 1, 100, 10, "large batch: MsjRobot 2 097 152 envs on one GPU, RK4 fp32 (the headline kernel at 8x its waves per SIMD)"),
     "upper-body-8192-euler": (8192, "euler", 1, 300, 30, "configs[3]: upper body (20 DOF / 38 tendons) 8 192 envs, Euler fp32"),
     "upper-body-8192-rk4": (8192, "rk4", 1, 100, 10, "configs[3]: upper body (20 DOF / 38 tendons) 8 192 envs, RK4 fp32"),
     "upper-body-65536-euler": (65536, "euler", 1, 300, 30, "large batch: upper body (20 DOF / 38 tendons) 65 536 envs (one wave per SIMD), Euler fp32"),
@@ -547,7 +548,7 @@ def main():
         head = run_workload(torch, robot, args.workload, args.steps, args.warmup, args.envs, use_graph,
                             rank, world, dist, args.substeps, args.kernel, args.repeats)
         if world == 1 and not args.no_also:
-            for name in ("msj-4096-euler", "msj-262144-euler", "msj-262144-rk4", "msj-2097152-euler",
+            for name in ("msj-4096-euler", "msj-262144-euler", "msj-262144-rk4", "msj-2097152-euler", "msj-2097152-rk4",
                          "upper-body-8192-euler", "upper-body-8192-rk4", "upper-body-65536-euler"):
                 if name != args.workload:
                     rob = UpperBodyRobot() if name.startswith("upper-body") else MsjRobot()

@@ -4,7 +4,7 @@ kernel_stats.csv / domain_stats.csv (rocprofv3 --kernel-trace --stats of the def
 JSON lines, hbm_traffic_pmc.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes per workload, FETCH_SIZE
 doubled as MI355X_MICROARCH.md's HBM section prescribes for gfx950) and sq_counters.json.
 
-    python tools/summarize_profile.py r2_a
+    python tools/summarize_profile.py r3_a
 """
 import collections
 import csv
@@ -19,7 +19,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r2_a"
 SRC = os.path.join(ROOT, "gpurun_out", tag)
 DST = os.path.join(ROOT, "profiles", tag)
 os.makedirs(DST, exist_ok=True)
-STEP_KERNELS = ("msj_step_env_per_lane", "msj_step_tendon_per_lane", "tree_step_aba", "msj_env_step_kernel")
+STEP_KERNELS = ("msj_step_env_per_lane", "msj_step_tendon_per_lane", "tree_step_aba", "msj_env_step_kernel",
+                "tree_lane_step", "tree_lane_env_step", "tree_env_step_aba")
 
 
 def counters(dirname):
@@ -44,6 +45,30 @@ for name in ("bench_unprofiled.json", "bench_under_rocprof.json", "bench_2rank_g
 for f in glob.glob(os.path.join(SRC, "prof_stats", "**", "*_stats.csv"), recursive=True):
     base = os.path.basename(f).split("_", 1)[1]
     shutil.copy(f, os.path.join(DST, base))
+
+# The step kernels per (symbol, grid size): one symbol serves several workloads of the bench run (the RK4 env-per-lane kernel
+# runs the 262 144-env headline and the 2 097 152-env batch), so rocprofv3's per-symbol average mixes them; the per-dispatch
+# trace has the grid size, which tells them apart.  Also the registers / scratch / LDS the dispatches were launched with.
+by_grid = collections.defaultdict(list)
+meta = {}
+for f in glob.glob(os.path.join(SRC, "prof_stats", "**", "*kernel_trace.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        name = row["Kernel_Name"]
+        if not any(k in name for k in STEP_KERNELS):
+            continue
+        key = (name, int(row["Grid_Size_X"]), int(row["Workgroup_Size_X"]))
+        by_grid[key].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+        meta[key] = (row["VGPR_Count"], row["Accum_VGPR_Count"], row["SGPR_Count"], row["Scratch_Size"], row["LDS_Block_Size"])
+if by_grid:
+    with open(os.path.join(DST, "kernel_stats_by_grid.csv"), "w") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Name", "Grid_Size_X", "Workgroup_Size_X", "Envs", "Calls", "AverageNs", "MinNs", "MaxNs", "VGPR", "AGPR", "SGPR", "Scratch", "LDS"])
+        for key in sorted(by_grid, key=lambda k: (k[0], k[1])):
+            v = by_grid[key]
+            tail = v[10:] if len(v) > 20 else v
+            # threads per env: 8 in the tendon-per-lane form, 32 in the octet kernels (2 envs per wave), 1 otherwise
+            per_env = 8 if "tendon_per_lane" in key[0] else (32 if "_aba" in key[0] else 1)
+            w.writerow([key[0], key[1], key[2], key[1] // per_env, len(v), "%.1f" % (sum(tail) / len(tail)), min(tail), max(tail)] + list(meta[key]))
 
 traffic = {}
 for d in sorted(glob.glob(os.path.join(SRC, "pmc_*_FETCH_SIZE"))):
@@ -78,7 +103,10 @@ for d in sorted(glob.glob(os.path.join(SRC, "pmc_*_SQ1"))):
     c = merged[kern]
     waves = c.get("SQ_WAVES", 0) or 1.0
     per_wave = {k: c[k] / waves for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES") if k in c}
-    frac = {k: c[k] / c["SQ_WAVE_CYCLES"] for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") if k in c and c.get("SQ_WAVE_CYCLES")}
+    frac = {k: c[k] / c["SQ_WAVE_CYCLES"] for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU")
+            if k in c and c.get("SQ_WAVE_CYCLES")}
+    if c.get("SQ_LDS_IDX_ACTIVE"):
+        frac["lds_bank_conflict_of_lds_active"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
     sq[w] = {"kernel": kern, "per_launch": dict(c), "per_wave": per_wave, "fraction_of_wave_cycles": frac,
              "note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, cycle constants)"}
 with open(os.path.join(DST, "sq_counters.json"), "w") as fh:

@@ -2,16 +2,17 @@
 import os, sys, time
 sys.path.insert(0, "/root/repo")
 import torch
-from gym_roboy_amd.envs.robots import MsjRobot
+from gym_roboy_amd.envs.robots import MsjRobot, UpperBodyRobot
 from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+ROBOT = UpperBodyRobot() if os.environ.get("VECENV_ROBOT", "msj") == "upper" else MsjRobot()
 INTEG = os.environ.get("VECENV_INTEGRATOR", "euler")
 SIZES = [int(x) for x in os.environ.get("VECENV_SIZES", "4096,65536,262144,2097152").split(",")]
 for n in SIZES:
     with torch.cuda.stream(torch.cuda.Stream()):
-        env = RoboyVecEnv(MsjRobot(), n, integrator=INTEG)
+        env = RoboyVecEnv(ROBOT, n, integrator=INTEG)
         st = torch.cuda.current_stream(); env.sim.set_stream(st.cuda_stream)
-        acts = [torch.rand((n, 8), device="cuda") * 2 - 1 for _ in range(4)]
-        obs = torch.empty((n, 9), device="cuda"); rew = torch.empty(n, device="cuda"); done = torch.empty(n, dtype=torch.int32, device="cuda")
+        acts = [torch.rand((n, env.n_t), device="cuda") * 2 - 1 for _ in range(4)]
+        obs = torch.empty((n, 3 * env.n_q), device="cuda"); rew = torch.empty(n, device="cuda"); done = torch.empty(n, dtype=torch.int32, device="cuda")
         steps = 2000 if n <= 65536 else 300
         for t in range(50): env.step_dev(acts[t % 4].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
         torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -19,5 +20,5 @@ for n in SIZES:
         for t in range(steps): env.step_dev(acts[t % 4].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
         e1.record(st); torch.cuda.synchronize(); wall = time.perf_counter() - t0
         us = e0.elapsed_time(e1) * 1e3 / steps
-        print(INTEG, "fused env step n=%d: %.2f us/step (events), %.3e env-steps/s wall, %.1f GB/s at 156 B/env-step" % (n, us, n * steps / wall, n * 156 / us / 1e3))
+        print(INTEG, "fused env step n=%d: %.2f us/step (events), %.3e env-steps/s wall, %.1f GB/s algorithmic" % (n, us, n * steps / wall, n * (4 * (4 * env.n_q + env.n_t + 1) + 4 * (4 * env.n_q + 6)) / us / 1e3))
         env.close()
