@@ -8,7 +8,7 @@
 #include "tree_lane_gen.hpp"
 
 extern "C" int rb_gen_tree_lane(const rb_robot_desc *d, int lds_c, const char *path, int *lds_slots, int *n_stmt,
-                                unsigned long long *hash, int *flops) {
+                                unsigned long long *hash, int *flops, int *max_live) {
     rblg::Generated g;
     std::string err;
     const int rc = rblg::generate(d, lds_c != 0, g, err);
@@ -23,5 +23,6 @@ extern "C" int rb_gen_tree_lane(const rb_robot_desc *d, int lds_c, const char *p
     if (n_stmt) *n_stmt = g.n_stmt;
     if (hash) *hash = g.hash;
     if (flops) *flops = g.flops;
+    if (max_live) *max_live = g.max_live;
     return RB_OK;
 }

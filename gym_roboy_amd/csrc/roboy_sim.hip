@@ -83,6 +83,12 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #ifndef RB_TREE_JIT_BATCH
 #define RB_TREE_JIT_BATCH 16384
 #endif
+// ... and only for robots whose generated code keeps at most this many values alive at once (rblg::Generated::max_live;
+// the upper body: 332): beyond it the kernel spills to scratch - minutes to build, and every reload a full memory
+// latency on a SIMD with one wave - and the octets are the better form.  An explicit rb_select_kernel(1) builds anyway.
+#ifndef RB_TREE_LANE_MAX_LIVE
+#define RB_TREE_LANE_MAX_LIVE 400
+#endif
 using namespace rbk;    // the env-per-lane kernels (msj_kernels.hpp), EnvParams, GoalBox, ...
 
 // ------------------------------------------------------------------ kernels
@@ -411,7 +417,7 @@ bool tree_wants_lane(const rb_sim *s) {
     if (!s->tree || !s->lane_ok || s->kernel_choice == RB_KERNEL_ENV_PER_WAVE) return false;
     if (s->kernel_choice == RB_KERNEL_ENV_PER_LANE || s->lane_baked) return true;
     const int lvl = jit_level();
-    return lvl == 2 || (lvl == 1 && s->n >= RB_TREE_JIT_BATCH);
+    return s->lane_gen.max_live <= RB_TREE_LANE_MAX_LIVE && (lvl == 2 || (lvl == 1 && s->n >= RB_TREE_JIT_BATCH));
 }
 
 // kind: 0 = step, 1 = env step.  The kernel to launch, or nullptr for the ahead-of-time instances / the octet kernels.

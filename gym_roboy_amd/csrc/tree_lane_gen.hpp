@@ -51,6 +51,10 @@ struct Generated {
     int n_q = 0, n_t = 0;
     int lds_slots = 0;         // lane-private LDS slots rbl_accel uses
     int n_stmt = 0;            // statements emitted (a proxy of the instruction count)
+    int max_live = 0;          // most temporaries alive at once in the order the text is written (the sched barriers keep the
+                               // compiler close to it): what has to fit the 512 registers of a SIMD's only wave, beside the
+                               // kernel's own ~60 (inputs, addresses).  Robots beyond ~400 spill to scratch - slow to build
+                               // (minutes) and slow to run (every reload a full memory latency) - and keep the octet kernels.
     int flops = 0;             // floating-point operations of one acceleration as written (one per arithmetic statement: the
                                // folded products and sums are not counted - they are not executed)
     uint64_t hash = 0;         // FNV-1a of the text
@@ -93,7 +97,7 @@ class Gen {
     void barrier() { stmts.push_back({"//", "    RBL_SCHED_BARRIER;\n"}); }
     // The text of the function body without the statements nothing depends on (a parent's accumulated inertia that
     // only feeds a root's unused I^a, products folded away further down, ...); n_stmt = statements kept.
-    std::string body(int &n_stmt, int &flops) const {
+    std::string body(int &n_stmt, int &flops, int &max_live) const {
         std::vector<char> keep(stmts.size(), 0);
         std::map<std::string, char> live;
         for (size_t k = stmts.size(); k-- > 0;) {
@@ -110,6 +114,35 @@ class Gen {
                     live[t.substr(i, j - i)] = 1;
                     i = j - 1;
                 }
+        }
+        // live ranges in emission order: a temporary lives from its definition to its last use
+        {
+            std::map<std::string, size_t> last_use;
+            auto names_in = [](const std::string &t, std::vector<std::string> &out) {
+                for (size_t i = 0; i < t.size(); ++i)
+                    if (t[i] == 't' && i + 1 < t.size() && t[i + 1] >= '0' && t[i + 1] <= '9' && (i == 0 || !(isalnum((unsigned char)t[i - 1]) || t[i - 1] == '_'))) {
+                        size_t j = i + 1;
+                        while (j < t.size() && t[j] >= '0' && t[j] <= '9') ++j;
+                        out.push_back(t.substr(i, j - i));
+                        i = j - 1;
+                    }
+            };
+            for (size_t k = 0; k < stmts.size(); ++k) {
+                if (!keep[k] || stmts[k].target == "//") continue;
+                std::vector<std::string> ns;
+                names_in(stmts[k].text, ns);
+                for (const std::string &n : ns) last_use[n] = k;
+            }
+            std::vector<int> dies(stmts.size() + 1, 0);
+            for (const auto &kv : last_use) ++dies[kv.second];
+            int live = 0;
+            max_live = 0;
+            for (size_t k = 0; k < stmts.size(); ++k) {
+                if (!keep[k] || stmts[k].target == "//") continue;
+                if (!stmts[k].target.empty()) ++live;
+                if (live > max_live) max_live = live;
+                live -= dies[k];
+            }
         }
         std::string out;
         n_stmt = 0; flops = 0;
@@ -534,7 +567,7 @@ inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::str
     table("VMAX", nq, [&](int k) { return d->qd_max[k]; });
     t += "template <class RBL_L>\nRBL_FN void rbl_accel(const float (&q)[RBL_NQ], const float (&qd)[RBL_NQ], const float (&spu)[RBL_NT], "
          "float (&qdd)[RBL_NQ], RBL_L rbl_lds) {\n";
-    t += g.body(out.n_stmt, out.flops);
+    t += g.body(out.n_stmt, out.flops, out.max_live);
     t += "}\n}  // namespace RBL_NS\n";
     out.text = t;
     out.n_q = nq; out.n_t = nt; out.lds_slots = g.n_lds;

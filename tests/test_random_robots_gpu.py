@@ -89,6 +89,33 @@ def test_random_tree_robot_env_per_lane_kernel_matches_oracle(seed):
     sim.close()
 
 
+def test_library_builds_the_lane_kernels_on_its_own_only_where_they_fit():
+    """The library's own choice at 16 384 envs: a robot whose generated code keeps few values alive gets the hiprtc-built
+    env-per-lane kernels (and they match the oracle on a sample); a dense 22-joint robot whose live set exceeds a SIMD's
+    register file keeps the octets (no minutes-long build of a kernel that would spill)."""
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    from oracle.c_oracle import COracle
+    n = 16384
+    robot, desc = random_tree_robot(3)                       # 8 joints, 4 tendons
+    q, qd, sp = random_states(desc, n, 3)
+    sim = HipBatchSimulation(robot, n, integrator="euler")
+    sim.set_state(q, qd)
+    q1, qd1, f1 = sim.forward_step_command(sp)
+    assert sim.info()["kernel"] == 1 and sim.specialization() == "jit"
+    idx = np.arange(0, n, 97)
+    qo, qdo, fo = COracle(desc, "f64").step(q[idx], qd[idx], sp[idx], integrator=0)
+    tol = tolerance(desc, q[idx], qd[idx], sp[idx])
+    assert np.all(np.abs(q1[idx] - qo) < tol) and np.all(np.abs(qd1[idx] - qdo) < tol)
+    sim.close()
+    robot, desc = random_tree_robot(1)                       # 22 joints, 24 tendons, dense: ~740 values alive at once
+    sim = HipBatchSimulation(robot, n, integrator="euler")
+    q, qd, sp = random_states(desc, n, 1)
+    sim.set_state(q, qd)
+    sim.forward_step_command(sp)
+    assert sim.info()["kernel"] == 3 and sim.specialization() == "kernarg"
+    sim.close()
+
+
 def test_random_robot_fused_env_layer_runs_and_matches_plain_step():
     """The fused env kernel of the joint-tree class on a random robot: its physics leg equals the plain step."""
     from gym_roboy_amd.envs.simulations import HipBatchSimulation

@@ -26,14 +26,15 @@ def load_generator():
 
 
 def generate(desc, path, lds_c=True):
-    """Write the generated header of `desc` to `path`; returns (lds_slots, statements, hash, flops of one acceleration)."""
+    """Write the generated header of `desc` to `path`; returns (lds_slots, statements, hash, flops of one acceleration, most
+    temporaries alive at once)."""
     lib = load_generator()
-    slots, stmts, h, fl = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_ulonglong(0), ctypes.c_int(0)
+    slots, stmts, h, fl, live = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_ulonglong(0), ctypes.c_int(0), ctypes.c_int(0)
     rc = lib.rb_gen_tree_lane(ctypes.byref(desc.as_c_struct()), int(lds_c), path.encode(), ctypes.byref(slots),
-                              ctypes.byref(stmts), ctypes.byref(h), ctypes.byref(fl))
+                              ctypes.byref(stmts), ctypes.byref(h), ctypes.byref(fl), ctypes.byref(live))
     if rc:
         raise RuntimeError("rb_gen_tree_lane failed: %d" % rc)
-    return slots.value, stmts.value, h.value, fl.value
+    return slots.value, stmts.value, h.value, fl.value, live.value
 
 
 if __name__ == "__main__":
