@@ -26,3 +26,25 @@ extern "C" int rb_gen_tree_lane(const rb_robot_desc *d, int lds_c, const char *p
     if (max_live) *max_live = g.max_live;
     return RB_OK;
 }
+
+// the split form (several waves per env group): writes the header, returns parts / slots / statement counts
+extern "C" int rb_gen_tree_lane_split(const rb_robot_desc *d, int max_parts, const char *path, int *n_parts, int *part_lds, int *x_slots,
+                                      int *max_stmt, int *n_stmt, int *part_of_joint, unsigned long long *hash) {
+    rblg::SplitGenerated g;
+    std::string err;
+    const int rc = rblg::generate_split(d, max_parts, g, err);
+    if (rc) { std::fprintf(stderr, "rb_gen_tree_lane_split: %s\n", err.c_str()); return rc; }
+    FILE *f = std::fopen(path, "w");
+    if (!f) return RB_EINVAL;
+    std::fputs(g.text.c_str(), f);
+    std::fprintf(f, "#define RBL_SPLIT_TEXT_HASH 0x%llxull\n", (unsigned long long)g.hash);
+    std::fclose(f);
+    if (n_parts) *n_parts = g.n_parts;
+    if (part_lds) *part_lds = g.part_lds;
+    if (x_slots) *x_slots = g.x_slots;
+    if (max_stmt) *max_stmt = g.max_stmt;
+    if (n_stmt) *n_stmt = g.n_stmt;
+    if (part_of_joint) for (int i = 0; i < g.n_q; ++i) part_of_joint[i] = g.part_of_joint[i];
+    if (hash) *hash = g.hash;
+    return RB_OK;
+}

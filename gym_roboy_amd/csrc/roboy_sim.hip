@@ -32,6 +32,11 @@
 #include "tree_lane_baked.hpp"
 #include "tree_lane.hpp"
 #undef RBL_NS
+// ... and its split form (several waves per group of 64 envs, for small batches): tree_lane_split.hpp
+#define RBL_NS rbl_split_baked
+#include "tree_lane_split_baked.hpp"
+#include "tree_lane_split.hpp"
+#undef RBL_NS
 #include "tree_lane_jit.hpp"
 
 namespace {
@@ -88,6 +93,11 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // latency on a SIMD with one wave - and the octets are the better form.  An explicit rb_select_kernel(1) builds anyway.
 #ifndef RB_TREE_LANE_MAX_LIVE
 #define RB_TREE_LANE_MAX_LIVE 400
+#endif
+// joint-tree robots with split-form instances (several waves per 64 envs): AUTO uses them up to this many envs - while
+// the waves of a launch still find a SIMD each (measured crossover against the one-wave form: profiles/r3_a)
+#ifndef RB_TREE_SPLIT_BATCH
+#define RB_TREE_SPLIT_BATCH 16384
 #endif
 using namespace rbk;    // the env-per-lane kernels (msj_kernels.hpp), EnvParams, GoalBox, ...
 
@@ -368,6 +378,10 @@ struct rb_sim {
     bool lane_ok = false;               // lane_gen is valid (the generator supports the robot)
     bool lane_baked = false;
     rblj::Kernel lane_step_k, lane_env_k;
+    // the split form of the same (tree_lane_split.hpp): several waves per group of 64 envs, for small batches
+    rblg::SplitGenerated split_gen;
+    bool split_ok = false, split_baked = false;
+    rblj::Kernel split_step_k;
     GoalBox box;
     hipStream_t own_stream = nullptr, stream = nullptr;
     float *d_q = nullptr, *d_qd = nullptr;
@@ -420,6 +434,34 @@ bool tree_wants_lane(const rb_sim *s) {
     return s->lane_gen.max_live <= RB_TREE_LANE_MAX_LIVE && (lvl == 2 || (lvl == 1 && s->n >= RB_TREE_JIT_BATCH));
 }
 
+// does this handle run the split form (several waves per 64 envs) of the plain step?  An explicit choice, or AUTO with
+// ahead-of-time instances and a batch small enough that its waves still find a SIMD each
+bool tree_wants_split(const rb_sim *s) {
+    if (!s->tree || !s->split_ok) return false;
+    if (s->kernel_choice == RB_KERNEL_ENV_PER_LANE_SPLIT) return true;
+    return s->kernel_choice == RB_KERNEL_AUTO && s->split_baked && s->n <= RB_TREE_SPLIT_BATCH;
+}
+size_t split_lds_bytes(const rblg::SplitGenerated &g) {      // the formula of tree_lane_split.hpp: SP_LDS_BYTES
+    const int img = 5 * g.n_q > 3 * g.n_q + g.n_t ? 5 * g.n_q : 3 * g.n_q + g.n_t;
+    return size_t(img + 2 * g.x_slots + g.n_parts * (g.part_lds + 2 * g.n_q) + 2 * g.n_parts + 2) * 64 * 4;
+}
+// the hiprtc-built split step kernel of a robot without ahead-of-time instances (explicit choice only)
+bool build_split_kernel(rb_sim *s) {
+    rblj::Kernel &k = s->split_step_k;
+    if (k.state != 0) return k.state == 1;
+    if (hipSetDevice(s->device) != hipSuccess) { k.state = -1; k.why = "hipSetDevice failed"; return false; }
+    const std::string src = "#include \"tree_lane_defs.hpp\"\n#define RBL_NS rbl_jit_split\n" + s->split_gen.text + "#include \"tree_lane_split.hpp\"\n";
+    const std::string name = std::string("rbl_jit_split::tree_split_step<") + (s->integrator == RB_EULER ? "0>" : "1>");
+    const char *names[1] = {name.c_str()};
+    hipFunction_t *slots[1] = {&k.fn};
+    k.state = rbj::compile_and_load(src, "roboy_tree_split_jit.hip", names, 1, k.mod, slots, k.why) ? 1 : -1;
+    if (k.state == 1 && split_lds_bytes(s->split_gen) > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k.fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(split_lds_bytes(s->split_gen))) != hipSuccess) {
+        k.state = -1; k.why = "LDS of the split kernel not granted";
+    }
+    return k.state == 1;
+}
+
 // kind: 0 = step, 1 = env step.  The kernel to launch, or nullptr for the ahead-of-time instances / the octet kernels.
 rblj::Kernel *lane_kernel(rb_sim *s, int kind) {
     rblj::Kernel &k = kind == 0 ? s->lane_step_k : s->lane_env_k;
@@ -467,7 +509,29 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale) {
 #define RB_STEP_LAUNCH_BK(INTEG, B, U)                                                                \
     hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U, true>), dim3(blocks_for(n, B)), dim3(B), 0, \
                        s->stream, s->c8, s->d_q, s->d_qd, s->d_feas, d_act, us, n)
-    if (s->tree && tree_use_lane(s, 0)) {
+    if (s->tree && tree_wants_split(s) && (s->split_baked || s->split_step_k.state == 1)) {
+        // one workgroup of n_parts waves per 64 envs
+        const unsigned groups = blocks_for(n, 64);
+        const size_t lds = split_lds_bytes(s->split_gen);
+        const float h = s->tree_host.dev.h;
+        const int nsub = s->tree_host.dev.nsub;
+        const unsigned threads = 64u * unsigned(s->split_gen.n_parts);
+        s->kernel = RB_KERNEL_ENV_PER_LANE_SPLIT;
+        if (s->split_baked) {
+            if (s->integrator == RB_EULER)
+                hipLaunchKernelGGL(rbl_split_baked::tree_split_step<0>, dim3(groups), dim3(threads), lds, s->stream, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, h, nsub, n);
+            else
+                hipLaunchKernelGGL(rbl_split_baked::tree_split_step<1>, dim3(groups), dim3(threads), lds, s->stream, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, h, nsub, n);
+        } else {
+            float *q = s->d_q, *qd = s->d_qd;
+            uint32_t *feas = s->d_feas;
+            float hh = h;
+            int ns = nsub;
+            long nn = n;
+            void *args[] = {&q, &qd, &feas, &d_act, &act_scale, &hh, &ns, &nn};
+            RB_HIP(hipModuleLaunchKernel(s->split_step_k.fn, groups, 1, 1, threads, 1, 1, unsigned(lds), s->stream, args, nullptr));
+        }
+    } else if (s->tree && tree_use_lane(s, 0)) {
         // one wave (64 envs) per workgroup: the LDS regions admit four per CU, one per SIMD, and a small batch spreads over the CUs
         const unsigned waves = blocks_for(n, 64);
         const size_t lds = rblg::lane_lds_bytes_per_wave(s->lane_gen);
@@ -616,6 +680,8 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
             std::string why_gen;
             s->lane_ok = rblg::generate(robot, true, s->lane_gen, why_gen) == RB_OK;
             s->lane_baked = s->lane_ok && s->lane_gen.hash == RBL_TEXT_HASH && rblg::lane_lds_slots(s->lane_gen) == rbl_baked::LDS_SLOTS;
+            s->split_ok = rblg::generate_split(robot, 4, s->split_gen, why_gen) == RB_OK;
+            s->split_baked = s->split_ok && s->split_gen.hash == RBL_SPLIT_TEXT_HASH && s->split_gen.n_parts == RBL_NPARTS;
         }
         else why = "not a ball-joint robot (" + why + ") and not a supported joint tree (" + why_tree + ")";
     }
@@ -682,6 +748,7 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
         RB_TREE_ATTR((rbt::tree_step_aba<0, rbt::TREE_E, false>)); RB_TREE_ATTR((rbt::tree_step_aba<1, rbt::TREE_E, false>));
         RB_TREE_ATTR((rbt::tree_env_step_aba<0, rbt::TREE_E, true>)); RB_TREE_ATTR((rbt::tree_env_step_aba<1, rbt::TREE_E, true>));
         RB_TREE_ATTR((rbt::tree_env_step_aba<0, rbt::TREE_E, false>)); RB_TREE_ATTR((rbt::tree_env_step_aba<1, rbt::TREE_E, false>));
+        if (s->split_baked) { RB_TREE_ATTR(rbl_split_baked::tree_split_step<0>); RB_TREE_ATTR(rbl_split_baked::tree_split_step<1>); }
 #undef RB_TREE_ATTR
     }
     RB_TRY(hipMemsetAsync(s->d_goal_count, 0, sizeof(uint32_t) * size_t(n_envs), s->stream));
@@ -703,7 +770,7 @@ void rb_destroy(rb_sim *s) {
     if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
     for (auto &kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     rbj::unload(s->jit);
-    rblj::unload(s->lane_step_k); rblj::unload(s->lane_env_k);
+    rblj::unload(s->lane_step_k); rblj::unload(s->lane_env_k); rblj::unload(s->split_step_k);
     (void)hipFree(s->d_q); (void)hipFree(s->d_qd); (void)hipFree(s->d_feas);
     (void)hipFree(s->d_goal_count); (void)hipFree(s->d_rows); (void)hipFree(s->d_u8); (void)hipFree(s->d_ten);
     (void)hipFree(s->d_tree_words);
@@ -759,6 +826,7 @@ int rb_debug_tree_fetch(rb_sim *s, float *out, int n_floats, rbt::TreeDev *dev_o
 int rb_specialization(rb_sim *s) {
     if (check(s)) return -1;
     if (s->tree) {
+        if (tree_wants_split(s)) return s->split_baked ? RB_SPEC_TABLE : (s->split_step_k.state == 1 ? RB_SPEC_JIT : RB_SPEC_NONE);
         if (!tree_wants_lane(s)) { g_err = s->lane_ok ? "the octet kernels are selected (batch below the build threshold, or by choice)" : "no generator for this robot"; return RB_SPEC_NONE; }
         if (s->lane_baked) return RB_SPEC_TABLE;
         if (lane_kernel(s, 0)->state == 1) return RB_SPEC_JIT;
@@ -774,7 +842,9 @@ int rb_specialization(rb_sim *s) {
 
 int rb_select_kernel(rb_sim *s, int kernel) {
     if (check(s)) return RB_EINVAL;
-    if (kernel < RB_KERNEL_AUTO || kernel > RB_KERNEL_ENV_PER_WAVE) return fail(RB_EINVAL, "unknown kernel variant");
+    if (kernel < RB_KERNEL_AUTO || kernel > RB_KERNEL_ENV_PER_LANE_SPLIT) return fail(RB_EINVAL, "unknown kernel variant");
+    if (kernel == RB_KERNEL_ENV_PER_LANE_SPLIT && !(s->tree && s->split_ok))
+        return fail(RB_EUNSUPPORTED, "no split form for this robot (a ball-joint robot, a serial chain, or branches tied together by tendons)");
     s->kernel_choice = kernel;
     if (s->tree) {
         if (kernel == RB_KERNEL_TENDON_PER_LANE) return fail(RB_EUNSUPPORTED, "joint-tree robots have no tendon-per-lane kernel");
@@ -791,7 +861,14 @@ int rb_select_kernel(rb_sim *s, int kernel) {
                 return fail(RB_EUNSUPPORTED, "env-per-lane kernel not available: " + s->lane_step_k.why);
             }
         }
-        s->kernel = tree_wants_lane(s) ? RB_KERNEL_ENV_PER_LANE : RB_KERNEL_ENV_PER_WAVE;
+        if (kernel == RB_KERNEL_ENV_PER_LANE_SPLIT && !s->split_baked) {
+            if (capturing(s)) return fail(RB_EINVAL, "the split-form kernel cannot be built during a stream capture");
+            if (!build_split_kernel(s)) {
+                s->kernel_choice = RB_KERNEL_AUTO;
+                return fail(RB_EUNSUPPORTED, "split-form kernel not available: " + s->split_step_k.why);
+            }
+        }
+        s->kernel = tree_wants_split(s) ? RB_KERNEL_ENV_PER_LANE_SPLIT : (tree_wants_lane(s) ? RB_KERNEL_ENV_PER_LANE : RB_KERNEL_ENV_PER_WAVE);
         return RB_OK;
     }
     if (kernel == RB_KERNEL_ENV_PER_WAVE) return fail(RB_EUNSUPPORTED, "ball-joint robots have no env-per-wave kernel");

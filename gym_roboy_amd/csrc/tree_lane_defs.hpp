@@ -8,6 +8,10 @@
 #define RBL_TABLE(name, n) __device__ constexpr float name[n]
 #define RBL_SCHED_BARRIER __builtin_amdgcn_sched_barrier(0)
 #define RBL_LDS(slot) rbl_lds(slot)
+// split form (several waves per env group, tree_lane_split.hpp): integer tables, the exchange area, the workgroup barrier
+#define RBL_ITABLE(name, n) __device__ constexpr int name[n]
+#define RBL_X(slot) rbl_x(slot)
+#define RBL_PART_BARRIER __syncthreads()
 
 RBL_FN float rbl_sin(float x) { return __sinf(x); }
 RBL_FN float rbl_cos(float x) { return __cosf(x); }

@@ -22,6 +22,7 @@
 // g++ for the CPU tests (tests/test_tree_lane_gen.py), which check it against the fp64 oracle on random robots.
 // Plain host C++ (no HIP).
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cctype>
 #include <cmath>
@@ -260,25 +261,37 @@ inline uint64_t fnv1a(const std::string &s) {
 // constant length and no net wrench).
 struct Crossing { int la, lb; double ra[3], rb[3]; };
 
-// Write the header for robot `d`.  lds_c: keep the velocity-product accelerations in LDS between the sweeps.
-inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::string &err) {
+// The robot as the writers need it: topology, tendon crossings and the folded tendon / muscle constants in fp64
+// (the formulas of tree_build.hpp).
+struct Robot {
+    const rb_robot_desc *d = nullptr;
+    int nq = 0, nt = 0;
+    std::vector<int> parent;
+    std::vector<std::vector<int>> children;
+    std::vector<std::vector<Crossing>> t_cross;
+    std::vector<double> il0s, elcs, ksg, inv_vl0;
+    std::vector<int> t_last;                               // the link after which tendon k can be evaluated (-1: before any)
+    double kps = 0, pe_k2s = 0, inv_pe_den = 0, fv_c1l = 0, fv_c2l = 0, fv_c2s = 0, fv_k = 0;
+};
+
+inline int build_robot(const rb_robot_desc *d, Robot &rob, std::string &err) {
     const int nq = d->n_q, nt = d->n_t;
     if (nq < 1 || nq > 32) { err = "lane kernel generator supports 1..32 joints"; return RB_EUNSUPPORTED; }
     if (nt < 1 || nt > 64) { err = "lane kernel generator supports 1..64 tendons"; return RB_EUNSUPPORTED; }
-    std::vector<int> parent(d->parent, d->parent + nq);
-    std::vector<std::vector<int>> children(nq);
+    rob.d = d; rob.nq = nq; rob.nt = nt;
+    rob.parent.assign(d->parent, d->parent + nq);
+    rob.children.assign(nq, {});
     for (int i = 0; i < nq; ++i) {
-        if (parent[i] < -1 || parent[i] >= i) { err = "parent must be -1 or an earlier joint"; return RB_EINVAL; }
-        if (parent[i] >= 0) children[parent[i]].push_back(i);
+        if (rob.parent[i] < -1 || rob.parent[i] >= i) { err = "parent must be -1 or an earlier joint"; return RB_EINVAL; }
+        if (rob.parent[i] >= 0) rob.children[rob.parent[i]].push_back(i);
     }
-    // ---- tendon constants in fp64 (the formulas of tree_build.hpp) ----
     std::vector<double> org(3 * nq);
     for (int i = 0; i < nq; ++i)
-        for (int a = 0; a < 3; ++a) org[3 * i + a] = (parent[i] < 0 ? 0.0 : org[3 * parent[i] + a]) + d->origin[3 * i + a];
+        for (int a = 0; a < 3; ++a) org[3 * i + a] = (rob.parent[i] < 0 ? 0.0 : org[3 * rob.parent[i] + a]) + d->origin[3 * i + a];
     const double log2e = 1.4426950408889634;
     const double sc = std::sqrt(log2e) / d->fl_width;
-    std::vector<std::vector<Crossing>> t_cross(nt);
-    std::vector<double> il0s(nt), elcs(nt), ksg(nt), inv_vl0(nt);
+    rob.t_cross.assign(nt, {});
+    rob.il0s.assign(nt, 0); rob.elcs.assign(nt, 0); rob.ksg.assign(nt, 0); rob.inv_vl0.assign(nt, 0);
     for (int k = 0; k < nt; ++k) {
         const int v0 = d->vp_offset[k], v1 = d->vp_offset[k + 1];
         if (v1 - v0 < 2) { err = "tendon with fewer than two via-points"; return RB_EINVAL; }
@@ -302,45 +315,62 @@ inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::str
                 Crossing c;
                 c.la = la; c.lb = lb;
                 for (int a = 0; a < 3; ++a) { c.ra[a] = d->vp_pos[3 * v + a]; c.rb[a] = d->vp_pos[3 * (v + 1) + a]; }
-                t_cross[k].push_back(c);
+                rob.t_cross[k].push_back(c);
             }
         }
-        il0s[k] = sc / l0; elcs[k] = sc * (lconst / l0 - 1.0);
-        ksg[k] = d->kp * d->setpoint_scale / l0; inv_vl0[k] = 1.0 / (d->v_max * l0);
+        rob.il0s[k] = sc / l0; rob.elcs[k] = sc * (lconst / l0 - 1.0);
+        rob.ksg[k] = d->kp * d->setpoint_scale / l0; rob.inv_vl0[k] = 1.0 / (d->v_max * l0);
     }
-    const double kps = d->kp / sc, pe_k2s = log2e * d->kpe / (d->e0 * sc), inv_pe_den = 1.0 / (std::exp(d->kpe) - 1.0);
-    const double c2l = (1.0 + 1.0 / d->fv_a) / (d->fv_n - 1.0), fv_c2s = -1.0 / d->fv_a, fv_k = 1.0 + 1.0 / d->fv_a;
-    const double fv_c1l = d->fv_n * c2l, fv_c2l = c2l;
+    rob.kps = d->kp / sc; rob.pe_k2s = log2e * d->kpe / (d->e0 * sc); rob.inv_pe_den = 1.0 / (std::exp(d->kpe) - 1.0);
+    const double c2l = (1.0 + 1.0 / d->fv_a) / (d->fv_n - 1.0);
+    rob.fv_c2s = -1.0 / d->fv_a; rob.fv_k = 1.0 + 1.0 / d->fv_a; rob.fv_c1l = d->fv_n * c2l; rob.fv_c2l = c2l;
+    rob.t_last.assign(nt, -1);
+    for (int k = 0; k < nt; ++k)
+        for (const Crossing &cr : rob.t_cross[k]) { if (cr.la > rob.t_last[k]) rob.t_last[k] = cr.la; if (cr.lb > rob.t_last[k]) rob.t_last[k] = cr.lb; }
+    return RB_OK;
+}
 
-    Gen g;
-    auto K = [](double c) { return Gen::K(c); };
-    // ---------------- sweep 1: frames, joint axes, velocities, velocity-product accelerations ----------------
-    std::vector<M3> R(nq);
-    std::vector<V3> p(nq), w(nq), vo(nq), z(nq), sl(nq);
-    std::vector<std::array<Val, 6>> cacc(nq);
-    std::vector<std::array<int, 6>> cslot(nq);
+// Writes the steps of the articulated-body algorithm of `rob` into one function body (a Gen): the caller decides which
+// links and tendons the function covers and in which order (the whole robot in index order: generate(); a trunk plus
+// some of its branches, with the other branches' contributions arriving through an exchange area: generate_split()).
+class Aba {
+ public:
+    const Robot &rob;
+    Gen &g;
+    bool lds_c;
+    std::vector<M3> R;
+    std::vector<V3> p, w, vo, z, sl;
+    std::vector<std::array<Val, 6>> cacc, bown, pT, pA, U, acc, cpre;
+    std::vector<std::array<int, 6>> cslot;
     // the link's own spatial inertia about the world origin and its bias force v x* (I v), evaluated while the frame
     // and the velocity are at hand: from here to the backward pass a massive link is carried as I_o (6), h (3) and
     // a bias force (6, which also collects the tendon wrenches) instead of R, p, w, vO and its wrenches (24)
-    std::vector<Sym6> Iown(nq);
-    std::vector<std::array<Val, 6>> bown(nq);
-    const M3 ident = {K(1), K(0), K(0), K(0), K(1), K(0), K(0), K(0), K(1)};
-    // ---- tendons: Hill force, wrench sums per link pair; a tendon is evaluated as soon as the frames of all the links
-    //      it touches exist, i.e. right after the link with the largest index among them ----
+    std::vector<Sym6> Iown, IA;
+    std::vector<Val> invD, uu;
+    std::vector<char> cpre_ok;
     std::map<std::pair<int, int>, std::array<Val, 6>> pair_sum;      // sum of F (m ; u) over the crossings la -> lb
     std::map<std::pair<int, int>, std::pair<V3, V3>> pair_vel;       // (w_b - w_a, vO_b - vO_a)
     std::vector<std::pair<int, int>> pair_order;
-    auto link_w = [&](int l) { return l < 0 ? Gen::zero3() : w[l]; };
-    auto link_vo = [&](int l) { return l < 0 ? Gen::zero3() : vo[l]; };
-    std::vector<int> t_last(nt, -1);                                  // the link after which tendon k can be evaluated (-1: before any)
-    for (int k = 0; k < nt; ++k)
-        for (const Crossing &cr : t_cross[k]) { if (cr.la > t_last[k]) t_last[k] = cr.la; if (cr.lb > t_last[k]) t_last[k] = cr.lb; }
-    auto emit_tendon = [&](int k) {
+
+    Aba(const Robot &r, Gen &gen, bool park_c) : rob(r), g(gen), lds_c(park_c) {
+        const int nq = r.nq;
+        R.resize(nq); p.resize(nq); w.resize(nq); vo.resize(nq); z.resize(nq); sl.resize(nq);
+        cacc.resize(nq); bown.resize(nq); pT.resize(nq); pA.resize(nq); U.resize(nq); acc.resize(nq); cpre.resize(nq);
+        cslot.resize(nq); Iown.resize(nq); IA.resize(nq); invD.resize(nq); uu.resize(nq); cpre_ok.assign(nq, 0);
+    }
+    static Val K(double c) { return Gen::K(c); }
+    V3 link_w(int l) const { return l < 0 ? Gen::zero3() : w[l]; }
+    V3 link_vo(int l) const { return l < 0 ? Gen::zero3() : vo[l]; }
+
+    // ---- tendons: Hill force, wrench sums per link pair; a tendon is evaluated as soon as the frames of all the links
+    //      it touches exist, i.e. right after the link with the largest index among them ----
+    void tendon(int k) {
+        const rb_robot_desc *d = rob.d;
         g.comment("tendon " + std::to_string(k));
         Val len = K(0.0), ldot = K(0.0);
         struct Unit { std::pair<int, int> pr; V3 m, u; };
         std::vector<Unit> units;
-        for (const Crossing &cr : t_cross[k]) {
+        for (const Crossing &cr : rob.t_cross[k]) {
             const std::pair<int, int> pr(cr.la, cr.lb);
             if (!pair_vel.count(pr)) {
                 pair_vel[pr] = {g.vsub(link_w(cr.lb), link_w(cr.la)), g.vsub(link_vo(cr.lb), link_vo(cr.la))};
@@ -360,13 +390,13 @@ inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::str
             units.push_back({pr, m, u});
         }
         // Hill-type force, scaled forms as in tree_aba.hpp p2_tendon / msj_math.hpp
-        const Val es = g.fma(len, K(il0s[k]), K(elcs[k]));
-        const Val act = g.call3("rbl_med3", g.sub(g.mul(es, K(kps)), Gen::named("spu[" + std::to_string(k) + "]")), K(0.0), K(1.0));
+        const Val es = g.fma(len, K(rob.il0s[k]), K(rob.elcs[k]));
+        const Val act = g.call3("rbl_med3", g.sub(g.mul(es, K(rob.kps)), Gen::named("spu[" + std::to_string(k) + "]")), K(0.0), K(1.0));
         const Val fl = g.call1("rbl_exp2", Gen::negv(g.mul(es, es)));
-        const Val v = g.mul(ldot, K(inv_vl0[k]));
+        const Val v = g.mul(ldot, K(rob.inv_vl0[k]));
         const Val vp = g.call2("rbl_max", v, K(0.0)), pq = g.call3("rbl_med3", g.add(v, K(1.0)), K(0.0), K(1.0));
-        const Val num = g.fma(vp, K(fv_c1l), pq), den = g.fma(vp, K(fv_c2l), g.fma(pq, K(fv_c2s), K(fv_k)));
-        const Val fpe = g.call2("rbl_max", g.sub(g.mul(g.call1("rbl_exp2", g.mul(es, K(pe_k2s))), K(inv_pe_den)), K(inv_pe_den)), K(0.0));
+        const Val num = g.fma(vp, K(rob.fv_c1l), pq), den = g.fma(vp, K(rob.fv_c2l), g.fma(pq, K(rob.fv_c2s), K(rob.fv_k)));
+        const Val fpe = g.call2("rbl_max", g.sub(g.mul(g.call1("rbl_exp2", g.mul(es, K(rob.pe_k2s))), K(rob.inv_pe_den)), K(rob.inv_pe_den)), K(0.0));
         const Val afn = g.mul(g.mul(act, fl), num);
         const Val rden = g.call1("rbl_rcp", den);
         const Val F = g.mul(g.fma(afn, rden, fpe), K(d->f_max[k]));
@@ -374,11 +404,14 @@ inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::str
             auto &s = pair_sum[un.pr];
             for (int a = 0; a < 3; ++a) { s[a] = g.fma(un.m[a], F, s[a]); s[3 + a] = g.fma(un.u[a], F, s[3 + a]); }
         }
-    };
-    for (int k = 0; k < nt; ++k) if (t_last[k] < 0) emit_tendon(k);      // (tendons that touch no moving link)
-    for (int i = 0; i < nq; ++i) {
+    }
+
+    // ---- forward sweep of one link: frame, joint axis, velocity, velocity-product acceleration (parked), own inertia and bias ----
+    void forward(int i) {
+        const rb_robot_desc *d = rob.d;
+        const M3 ident = {K(1), K(0), K(0), K(0), K(1), K(0), K(0), K(0), K(1)};
         g.comment("link " + std::to_string(i) + ": frame, axis, velocity");
-        const int par = parent[i];
+        const int par = rob.parent[i];
         const M3 &Rp = par < 0 ? ident : R[par];
         const V3 pp = par < 0 ? Gen::zero3() : p[par], wp = par < 0 ? Gen::zero3() : w[par], vop = par < 0 ? Gen::zero3() : vo[par];
         const Val qi = Gen::named("q[" + std::to_string(i) + "]"), qdi = Gen::named("qd[" + std::to_string(i) + "]");
@@ -453,44 +486,40 @@ inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::str
             const V3 bl = g.cross(w[i], Ivl);
             for (int a = 0; a < 3; ++a) { bown[i][a] = ba[a]; bown[i][3 + a] = bl[a]; }
         }
-        for (int k = 0; k < nt; ++k) if (t_last[k] == i) emit_tendon(k);
-        g.barrier();
     }
-    auto load_c = [&](int i) {
+
+    std::array<Val, 6> load_c(int i) {
         std::array<Val, 6> c = cacc[i];
         for (int a = 0; a < 6; ++a) if (cslot[i][a] >= 0) c[a] = g.lds_load(cslot[i][a]);
         return c;
-    };
-
-    // pT = -f_ext: the crossing la -> lb pulls la towards lb (f_ext_la += W, f_ext_lb -= W)
-    std::vector<std::array<Val, 6>> pT(nq);
-    for (int i = 0; i < nq; ++i) pT[i] = {K(0), K(0), K(0), K(0), K(0), K(0)};
-    for (const auto &pr : pair_order) {
-        const auto &s = pair_sum[pr];
-        for (int a = 0; a < 6; ++a) {
-            if (pr.first >= 0) pT[pr.first][a] = g.sub(pT[pr.first][a], s[a]);
-            if (pr.second >= 0) pT[pr.second][a] = g.add(pT[pr.second][a], s[a]);
-        }
-    }
-    // ---------------- sweep 2: articulated inertias and bias forces, leaves to root ----------------
-    std::vector<Sym6> IA(nq);
-    std::vector<std::array<Val, 6>> pA(nq), U(nq);
-    std::vector<Val> invD(nq), uu(nq);
-    for (int i = 0; i < nq; ++i) {
-        for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) IA[i].m[r][c] = K(0.0);
-        for (int a = 0; a < 6; ++a) pA[i][a] = g.add(bown[i][a], pT[i][a]);
     }
     // the parked c of a link is requested one link ahead of its use: a wave is alone on its SIMD, so an LDS latency
     // met at the point of use is idle time (the scheduling barriers keep the request where it is written)
-    std::vector<std::array<Val, 6>> cpre(nq);
-    std::vector<char> cpre_ok(nq, 0);
-    auto prefetch_c = [&](int i) { if (i >= 0 && i < nq && !cpre_ok[i]) { cpre[i] = load_c(i); cpre_ok[i] = 1; } };
-    auto next_user = [&](int i) { int n = i - 1; while (n >= 0 && parent[n] < 0) --n; return n; };   // (a root's backward step uses no c)
-    auto take_c = [&](int i) { if (!cpre_ok[i]) cpre[i] = load_c(i); cpre_ok[i] = 0; return cpre[i]; };
-    prefetch_c(next_user(nq));
-    for (int i = nq - 1; i >= 0; --i) {
-        g.comment("link " + std::to_string(i) + ": backward pass");
-        prefetch_c(next_user(i));
+    void prefetch_c(int i) { if (i >= 0 && i < rob.nq && !cpre_ok[i]) { cpre[i] = load_c(i); cpre_ok[i] = 1; } }
+    std::array<Val, 6> take_c(int i) { if (!cpre_ok[i]) cpre[i] = load_c(i); cpre_ok[i] = 0; return cpre[i]; }
+
+    // pT = -f_ext of the tendons written so far: the crossing la -> lb pulls la towards lb (f_ext_la += W, f_ext_lb -= W)
+    void wrenches_to_links() {
+        for (int i = 0; i < rob.nq; ++i) pT[i] = {K(0), K(0), K(0), K(0), K(0), K(0)};
+        for (const auto &pr : pair_order) {
+            const auto &s = pair_sum[pr];
+            for (int a = 0; a < 6; ++a) {
+                if (pr.first >= 0) pT[pr.first][a] = g.sub(pT[pr.first][a], s[a]);
+                if (pr.second >= 0) pT[pr.second][a] = g.add(pT[pr.second][a], s[a]);
+            }
+        }
+    }
+    // accumulators of the backward pass: no children yet, bias force = own bias + tendon wrenches
+    void init_backward() {
+        for (int i = 0; i < rob.nq; ++i) {
+            for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) IA[i].m[r][c] = K(0.0);
+            for (int a = 0; a < 6; ++a) pA[i][a] = g.add(bown[i][a], pT[i][a]);
+        }
+    }
+    // ---- backward pass of one link.  Its articulated inertia / bias force go to `par_I` / `par_p` (the parent's
+    //      accumulators, or a part's export accumulators when the parent is a trunk link another wave finishes) ----
+    void backward(int i, Sym6 *par_I, std::array<Val, 6> *par_p) {
+        const rb_robot_desc *d = rob.d;
         Sym6 &I = IA[i];
         for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) I.m[r][c] = g.add(I.m[r][c], Iown[i].m[r][c]);
         const std::array<Val, 6> s = {z[i][0], z[i][1], z[i][2], sl[i][0], sl[i][1], sl[i][2]};
@@ -506,8 +535,7 @@ inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::str
         const Val dqd = g.mul(Gen::named("qd[" + std::to_string(i) + "]"), K(d->damping[i]));
         const Val spa = g.dot(sP);
         uu[i] = Gen::negv(g.add(dqd, spa));
-        const int par = parent[i];
-        if (par >= 0) {
+        if (par_I) {
             // I^a = I^A - U U^T / D,  p^a = p^A + I^a c + U u / D, added to the parent
             const std::array<Val, 6> c = take_c(i);
             std::array<Val, 6> Kk;
@@ -520,32 +548,77 @@ inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::str
                 for (int cc = 0; cc < 6; ++cc) terms.push_back({Ia.at(r, cc), c[cc]});
                 const Val pu = g.fma(U[i][r], ud, pA[i][r]);
                 const Val pa = g.add(pu, g.dot(terms));
-                pA[par][r] = g.add(pA[par][r], pa);
+                (*par_p)[r] = g.add((*par_p)[r], pa);
             }
-            for (int r = 0; r < 6; ++r) for (int cc = r; cc < 6; ++cc) IA[par].m[r][cc] = g.add(IA[par].m[r][cc], Ia.m[r][cc]);
+            for (int r = 0; r < 6; ++r) for (int cc = r; cc < 6; ++cc) par_I->m[r][cc] = g.add(par_I->m[r][cc], Ia.m[r][cc]);
         }
-        g.barrier();
     }
-    // ---------------- sweep 3: accelerations, root to leaves ----------------
-    std::vector<std::array<Val, 6>> acc(nq);
-    const std::array<Val, 6> a0 = {K(0), K(0), K(0), K(-d->gravity[0]), K(-d->gravity[1]), K(-d->gravity[2])};
-    for (int i = 0; i < nq; ++i) cpre_ok[i] = 0;
-    prefetch_c(0);
-    for (int i = 0; i < nq; ++i) {
-        g.comment("link " + std::to_string(i) + ": acceleration");
-        prefetch_c(i + 1);
-        const std::array<Val, 6> &apar = parent[i] < 0 ? a0 : acc[parent[i]];
+    // ---- forward accelerations of one link; qdd goes to `qdd[slot]` ----
+    void accel(int i, int slot) {
+        const rb_robot_desc *d = rob.d;
+        const std::array<Val, 6> a0 = {K(0), K(0), K(0), K(-d->gravity[0]), K(-d->gravity[1]), K(-d->gravity[2])};
+        const std::array<Val, 6> &apar = rob.parent[i] < 0 ? a0 : acc[rob.parent[i]];
         const std::array<Val, 6> c = take_c(i);
         std::array<Val, 6> ap;
         for (int r = 0; r < 6; ++r) ap[r] = g.add(apar[r], c[r]);
         std::vector<std::pair<Val, Val>> terms;
         for (int r = 0; r < 6; ++r) terms.push_back({U[i][r], ap[r]});
         const Val qdd = g.mul(g.sub(uu[i], g.dot(terms)), invD[i]);
-        g.store("qdd[" + std::to_string(i) + "]", qdd);
-        if (!children[i].empty()) {
+        g.store("qdd[" + std::to_string(slot) + "]", qdd);
+        if (!rob.children[i].empty()) {
             const std::array<Val, 6> s = {z[i][0], z[i][1], z[i][2], sl[i][0], sl[i][1], sl[i][2]};
             for (int r = 0; r < 6; ++r) acc[i][r] = g.fma(s[r], qdd, ap[r]);
         }
+    }
+};
+
+inline void write_tables(std::string &t, const Robot &rob) {
+    const rb_robot_desc *d = rob.d;
+    auto table = [&](const char *name, int n, auto value) {
+        t += std::string("RBL_TABLE(") + name + ", " + std::to_string(n) + ") = {";
+        for (int k = 0; k < n; ++k) t += Gen::lit(value(k)) + (k + 1 < n ? ", " : "");
+        t += "};\n";
+    };
+    table("KSG", rob.nt, [&](int k) { return rob.ksg[k]; });
+    table("QLO", rob.nq, [&](int k) { return d->q_lo[k]; });
+    table("QHI", rob.nq, [&](int k) { return d->q_hi[k]; });
+    table("VMAX", rob.nq, [&](int k) { return d->qd_max[k]; });
+}
+
+// Write the header for robot `d`: ONE function for the whole robot, links in index order.
+// lds_c: keep the velocity-product accelerations in LDS between the sweeps.
+inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::string &err) {
+    Robot rob;
+    if (int rc = build_robot(d, rob, err)) return rc;
+    const int nq = rob.nq, nt = rob.nt;
+    Gen g;
+    Aba A(rob, g, lds_c);
+    // ---------------- sweep 1: frames, joint axes, velocities, velocity-product accelerations; tendons ----------------
+    for (int k = 0; k < nt; ++k) if (rob.t_last[k] < 0) A.tendon(k);      // (tendons that touch no moving link)
+    for (int i = 0; i < nq; ++i) {
+        A.forward(i);
+        for (int k = 0; k < nt; ++k) if (rob.t_last[k] == i) A.tendon(k);
+        g.barrier();
+    }
+    A.wrenches_to_links();
+    // ---------------- sweep 2: articulated inertias and bias forces, leaves to root ----------------
+    A.init_backward();
+    auto next_user = [&](int i) { int n = i - 1; while (n >= 0 && rob.parent[n] < 0) --n; return n; };   // (a root's backward step uses no c)
+    A.prefetch_c(next_user(nq));
+    for (int i = nq - 1; i >= 0; --i) {
+        g.comment("link " + std::to_string(i) + ": backward pass");
+        A.prefetch_c(next_user(i));
+        const int par = rob.parent[i];
+        A.backward(i, par >= 0 ? &A.IA[par] : nullptr, par >= 0 ? &A.pA[par] : nullptr);
+        g.barrier();
+    }
+    // ---------------- sweep 3: accelerations, root to leaves ----------------
+    for (int i = 0; i < nq; ++i) A.cpre_ok[i] = 0;
+    A.prefetch_c(0);
+    for (int i = 0; i < nq; ++i) {
+        g.comment("link " + std::to_string(i) + ": acceleration");
+        A.prefetch_c(i + 1);
+        A.accel(i, i);
         g.barrier();
     }
 
@@ -555,22 +628,245 @@ inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::str
     t += "// GENERATED by gym_roboy_amd/csrc/tree_lane_gen.hpp - do not edit; the acceleration of ONE robot as straight-line code.\n";
     std::snprintf(buf, sizeof buf, "#define RBL_NQ %d\n#define RBL_NT %d\n#define RBL_ACCEL_LDS %d\n", nq, nt, g.n_lds);
     t += buf;
-    auto table = [&](const char *name, int n, auto value) {
-        t += std::string("RBL_TABLE(") + name + ", " + std::to_string(n) + ") = {";
-        for (int k = 0; k < n; ++k) t += Gen::lit(value(k)) + (k + 1 < n ? ", " : "");
-        t += "};\n";
-    };
     t += "namespace RBL_NS {\n";
-    table("KSG", nt, [&](int k) { return ksg[k]; });
-    table("QLO", nq, [&](int k) { return d->q_lo[k]; });
-    table("QHI", nq, [&](int k) { return d->q_hi[k]; });
-    table("VMAX", nq, [&](int k) { return d->qd_max[k]; });
+    write_tables(t, rob);
     t += "template <class RBL_L>\nRBL_FN void rbl_accel(const float (&q)[RBL_NQ], const float (&qd)[RBL_NQ], const float (&spu)[RBL_NT], "
          "float (&qdd)[RBL_NQ], RBL_L rbl_lds) {\n";
     t += g.body(out.n_stmt, out.flops, out.max_live);
     t += "}\n}  // namespace RBL_NS\n";
     out.text = t;
     out.n_q = nq; out.n_t = nt; out.lds_slots = g.n_lds;
+    out.hash = fnv1a(t);
+    return RB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The split form: SEVERAL WAVES per group of 64 envs, for batches too small to give every SIMD a wave (8 192 upper-body
+// envs are 128 waves for 1 024 SIMDs, and a step is then one wave's whole instruction stream).  Lanes of one wave cannot
+// share an env's work (different code per lane diverges), but waves can: the tree is cut at its first branching link
+// into a TRUNK (that link and its ancestors) and the BRANCHES hanging off it; the branches are packed into up to
+// `max_parts` parts, one wave each.  Every wave runs the trunk's forward sweep itself (cheap, no exchange), then its
+// own branches' forward sweep, tendons and backward pass; what its branches contribute to the trunk links - articulated
+// inertia (21), bias force and tendon wrenches (6) per receiving trunk link - goes to an exchange area in LDS; after ONE
+// workgroup barrier every wave sums all parts' contributions in the same order (so the trunk's accelerations come out
+// bit-identical in every wave), finishes the trunk's backward and forward passes itself and runs the forward-
+// acceleration sweep of its own branches.  Tendons between branches of different parts would need frames of two waves:
+// such branches are merged into one part.  A robot without at least two parts has no split form.
+struct SplitGenerated {
+    std::string text;
+    int n_q = 0, n_t = 0, n_parts = 0;
+    int part_lds = 0;                 // lane-private parking slots a part uses (maximum over the parts)
+    int x_slots = 0;                  // exchange slots per buffer (all parts)
+    int max_stmt = 0;                 // statements of the longest part (what a step waits for)
+    int n_stmt = 0;                   // statements of all parts together
+    std::vector<int> part_of_joint;   // -1: trunk (every wave integrates it), else the part that owns the joint
+    uint64_t hash = 0;
+};
+
+inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated &out, std::string &err) {
+    Robot rob;
+    if (int rc = build_robot(d, rob, err)) return rc;
+    const int nq = rob.nq, nt = rob.nt;
+    // ---- trunk: the shallowest link with two or more children, and its ancestors (a forest: no trunk, the trees are the branches)
+    std::vector<char> in_trunk(nq, 0);
+    int n_roots = 0;
+    for (int i = 0; i < nq; ++i) n_roots += rob.parent[i] < 0;
+    if (n_roots == 1) {
+        int b = 0;
+        while (rob.children[b].size() == 1) b = rob.children[b][0];
+        if (rob.children[b].empty()) { err = "a serial chain has no branches to split"; return RB_EUNSUPPORTED; }
+        for (int j = b; j >= 0; j = rob.parent[j]) in_trunk[j] = 1;
+    }
+    // ---- branches: subtrees under the trunk; merged where a tendon touches two of them
+    std::vector<int> branch(nq, -1), uf;
+    for (int i = 0; i < nq; ++i) {
+        if (in_trunk[i]) continue;
+        const int par = rob.parent[i];
+        if (par < 0 || in_trunk[par]) { branch[i] = int(uf.size()); uf.push_back(int(uf.size())); }
+        else branch[i] = branch[par];
+    }
+    auto find = [&](int x) { while (uf[x] != x) x = uf[x] = uf[uf[x]]; return x; };
+    for (int k = 0; k < nt; ++k) {
+        int first = -1;
+        for (const Crossing &cr : rob.t_cross[k])
+            for (int l : {cr.la, cr.lb}) {
+                if (l < 0 || in_trunk[l]) continue;
+                const int r = find(branch[l]);
+                if (first < 0) first = r; else uf[r] = first;
+                first = find(first);
+            }
+    }
+    // ---- cost of a group (statements, roughly) and packing into parts: largest first onto the lightest part
+    std::map<int, double> cost;
+    for (int i = 0; i < nq; ++i) if (!in_trunk[i]) cost[find(branch[i])] += 290.0;
+    std::vector<int> t_group(nt, -1);
+    for (int k = 0; k < nt; ++k) {
+        for (const Crossing &cr : rob.t_cross[k])
+            for (int l : {cr.la, cr.lb}) if (l >= 0 && !in_trunk[l]) t_group[k] = find(branch[l]);
+        if (t_group[k] >= 0) cost[t_group[k]] += 65.0 * double(rob.t_cross[k].size());
+    }
+    if (cost.size() < 2) { err = "the branches of this robot form one group (tendons tie them together)"; return RB_EUNSUPPORTED; }
+    const int K = int(cost.size()) < max_parts ? int(cost.size()) : max_parts;
+    std::vector<std::pair<double, int>> groups;
+    for (const auto &kv : cost) groups.push_back({-kv.second, kv.first});
+    std::sort(groups.begin(), groups.end());
+    std::vector<double> load(K, 0.0);
+    std::map<int, int> part_of_group;
+    for (const auto &gr : groups) {
+        int best = 0;
+        for (int q = 1; q < K; ++q) if (load[q] < load[best]) best = q;
+        part_of_group[gr.second] = best; load[best] -= gr.first;
+    }
+    std::vector<int> part_of_link(nq, -1), part_of_tendon(nt, -1);
+    for (int i = 0; i < nq; ++i) if (!in_trunk[i]) part_of_link[i] = part_of_group[find(branch[i])];
+    for (int k = 0; k < nt; ++k) {
+        if (t_group[k] >= 0) { part_of_tendon[k] = part_of_group[t_group[k]]; continue; }
+        int best = 0;                                       // a tendon of the trunk (or the base) alone: to the lightest part
+        for (int q = 1; q < K; ++q) if (load[q] < load[best]) best = q;
+        part_of_tendon[k] = best; load[best] += 65.0 * double(rob.t_cross[k].size());
+    }
+    std::vector<int> trunk;
+    for (int i = 0; i < nq; ++i) if (in_trunk[i]) trunk.push_back(i);
+
+    // ---- phase 1 of every part: trunk forward, own branches forward + tendons + backward, exports ----
+    struct Export { int link, r, c; bool is_const; double cval; int slot; };   // c < 0: bias-force component r
+    std::vector<Gen> gens(K);
+    std::vector<Aba *> abas(K, nullptr);
+    std::vector<std::vector<Export>> exports(K);
+    std::vector<std::vector<Val>> export_vals(K);           // the part's own values, in export order (used in place of reading them back)
+    std::vector<int> x_off(K + 1, 0);
+    for (int q = 0; q < K; ++q) {
+        Gen &g = gens[q];
+        abas[q] = new Aba(rob, g, true);
+        Aba &A = *abas[q];
+        auto tendons_after = [&](int link) { for (int k = 0; k < nt; ++k) if (part_of_tendon[k] == q && rob.t_last[k] == link) A.tendon(k); };
+        tendons_after(-1);
+        for (int j : trunk) { A.forward(j); tendons_after(j); g.barrier(); }
+        std::vector<int> own;
+        for (int i = 0; i < nq; ++i) if (part_of_link[i] == q) own.push_back(i);
+        for (int i : own) { A.forward(i); tendons_after(i); g.barrier(); }
+        A.wrenches_to_links();
+        A.init_backward();
+        // what this part hands to the trunk links: its tendons' wrenches on them, and its branches' I^a / p^a
+        std::vector<Sym6> EI(nq);
+        std::vector<std::array<Val, 6>> Ep(nq);
+        for (int j : trunk) {
+            for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) EI[j].m[r][c] = Gen::K(0.0);
+            Ep[j] = A.pT[j];
+        }
+        auto next_user = [&](int pos) { return pos + 1 < int(own.size()) ? own[own.size() - 2 - pos] : -1; };
+        if (!own.empty()) A.prefetch_c(own.back());
+        for (int pos = 0; pos < int(own.size()); ++pos) {
+            const int i = own[own.size() - 1 - pos];
+            g.comment("link " + std::to_string(i) + ": backward pass");
+            A.prefetch_c(next_user(pos));
+            const int par = rob.parent[i];
+            if (par < 0) A.backward(i, nullptr, nullptr);
+            else if (in_trunk[par]) A.backward(i, &EI[par], &Ep[par]);
+            else A.backward(i, &A.IA[par], &A.pA[par]);
+            g.barrier();
+        }
+        g.comment("exports of part " + std::to_string(q));
+        int n_slot = 0;
+        for (int j : trunk) {
+            for (int r = 0; r < 6; ++r)
+                for (int c = r; c < 6; ++c) {
+                    const Val &v = EI[j].m[r][c];
+                    if (Gen::is0(v)) continue;
+                    exports[q].push_back({j, r, c, v.k, v.c, v.k ? -1 : n_slot});
+                    export_vals[q].push_back(v);
+                    if (!v.k) ++n_slot;
+                }
+            for (int r = 0; r < 6; ++r) {
+                const Val &v = Ep[j][r];
+                if (Gen::is0(v)) continue;
+                exports[q].push_back({j, r, -1, v.k, v.c, v.k ? -1 : n_slot});
+                export_vals[q].push_back(v);
+                if (!v.k) ++n_slot;
+            }
+        }
+        x_off[q + 1] = x_off[q] + n_slot;
+    }
+    for (int q = 0; q < K; ++q)
+        for (size_t e = 0; e < exports[q].size(); ++e)
+            if (!exports[q][e].is_const)
+                gens[q].store("RBL_X(" + std::to_string(x_off[q] + exports[q][e].slot) + ")", export_vals[q][e]);
+    // ---- phase 2 of every part: all parts' contributions in part order, trunk backward + forward, own branches forward ----
+    out.max_stmt = 0; out.n_stmt = 0; out.part_lds = 0;
+    std::vector<std::string> bodies(K);
+    for (int q = 0; q < K; ++q) {
+        Gen &g = gens[q];
+        Aba &A = *abas[q];
+        g.stmts.push_back({"//", "    RBL_PART_BARRIER;\n"});
+        for (int j : trunk) {
+            for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) A.IA[j].m[r][c] = Gen::K(0.0);
+            A.pA[j] = A.bown[j];
+        }
+        for (int src = 0; src < K; ++src)
+            for (size_t e = 0; e < exports[src].size(); ++e) {
+                const Export &ex = exports[src][e];
+                const Val v = ex.is_const ? Gen::K(ex.cval)
+                              : (src == q ? export_vals[q][e] : g.emit("RBL_X(" + std::to_string(x_off[src] + ex.slot) + ")"));
+                if (ex.c >= 0) A.IA[ex.link].m[ex.r][ex.c] = g.add(A.IA[ex.link].m[ex.r][ex.c], v);
+                else A.pA[ex.link][ex.r] = g.add(A.pA[ex.link][ex.r], v);
+            }
+        g.barrier();
+        for (int i = 0; i < nq; ++i) A.cpre_ok[i] = 0;
+        for (int pos = int(trunk.size()) - 1; pos >= 0; --pos) {
+            const int j = trunk[pos];
+            g.comment("trunk link " + std::to_string(j) + ": backward pass");
+            const int par = rob.parent[j];
+            if (par >= 0) A.prefetch_c(j);
+            A.backward(j, par >= 0 ? &A.IA[par] : nullptr, par >= 0 ? &A.pA[par] : nullptr);
+            g.barrier();
+        }
+        std::vector<int> order = trunk;
+        for (int i = 0; i < nq; ++i) if (part_of_link[i] == q) order.push_back(i);
+        for (int i = 0; i < nq; ++i) A.cpre_ok[i] = 0;
+        if (!order.empty()) A.prefetch_c(order[0]);
+        for (size_t pos = 0; pos < order.size(); ++pos) {
+            g.comment("link " + std::to_string(order[pos]) + ": acceleration");
+            if (pos + 1 < order.size()) A.prefetch_c(order[pos + 1]);
+            A.accel(order[pos], order[pos]);
+            g.barrier();
+        }
+        int n_stmt = 0, flops = 0, live = 0;
+        bodies[q] = g.body(n_stmt, flops, live);
+        out.n_stmt += n_stmt;
+        if (n_stmt > out.max_stmt) out.max_stmt = n_stmt;
+        if (g.n_lds > out.part_lds) out.part_lds = g.n_lds;
+    }
+    for (Aba *a : abas) delete a;
+
+    // ---- the header ----
+    std::string t;
+    char buf[256];
+    t += "// GENERATED by gym_roboy_amd/csrc/tree_lane_gen.hpp (split form) - do not edit; the acceleration of ONE robot, one function per wave.\n";
+    std::snprintf(buf, sizeof buf, "#define RBL_NQ %d\n#define RBL_NT %d\n#define RBL_NPARTS %d\n#define RBL_PART_LDS %d\n#define RBL_X_SLOTS %d\n",
+                  nq, nt, K, out.part_lds, x_off[K]);
+    t += buf;
+    t += "namespace RBL_NS {\n";
+    write_tables(t, rob);
+    t += "RBL_ITABLE(PART_OF_JOINT, " + std::to_string(nq) + ") = {";
+    for (int i = 0; i < nq; ++i) t += std::to_string(part_of_link[i]) + (i + 1 < nq ? ", " : "");
+    t += "};\nRBL_ITABLE(PART_OF_TENDON, " + std::to_string(nt) + ") = {";
+    for (int k = 0; k < nt; ++k) t += std::to_string(part_of_tendon[k]) + (k + 1 < nt ? ", " : "");
+    t += "};\n";
+    for (int q = 0; q < K; ++q) {
+        t += "template <class RBL_L, class RBL_XA>\nRBL_FN void rbl_part" + std::to_string(q) +
+             "(const float (&q)[RBL_NQ], const float (&qd)[RBL_NQ], const float (&spu)[RBL_NT], float (&qdd)[RBL_NQ], RBL_L rbl_lds, RBL_XA rbl_x) {\n";
+        t += bodies[q];
+        t += "}\n";
+    }
+    t += "template <class RBL_L, class RBL_XA>\nRBL_FN void rbl_part(int part, const float (&q)[RBL_NQ], const float (&qd)[RBL_NQ], "
+         "const float (&spu)[RBL_NT], float (&qdd)[RBL_NQ], RBL_L rbl_lds, RBL_XA rbl_x) {\n";
+    for (int q = 0; q < K; ++q)
+        t += std::string("    ") + (q ? "else " : "") + (q + 1 < K ? "if (part == " + std::to_string(q) + ") " : "") + "rbl_part" +
+             std::to_string(q) + "(q, qd, spu, qdd, rbl_lds, rbl_x);\n";
+    t += "}\n}  // namespace RBL_NS\n";
+    out.text = t;
+    out.n_q = nq; out.n_t = nt; out.n_parts = K; out.x_slots = x_off[K];
+    out.part_of_joint = part_of_link;
     out.hash = fnv1a(t);
     return RB_OK;
 }

@@ -1,0 +1,210 @@
+// tree_lane_split.hpp - joint-tree kernels with SEVERAL WAVES per group of 64 envs, around the split-form text of
+// tree_lane_gen.hpp (generate_split): for batches too small to give every SIMD a wave (configs[3]: 8 192 upper-body envs are
+// 128 waves for 1 024 SIMDs, and a step is then one wave's whole instruction stream, 18 us).  A workgroup is
+// RBL_NPARTS waves, each on a SIMD of its own with the whole register file; wave p runs part p of the generated code:
+// the trunk's forward sweep (every wave for itself), its own branches, one exchange of the branches' contributions to
+// the trunk through LDS behind ONE workgroup barrier per acceleration, the trunk's backward / forward passes (every
+// wave for itself, bit-identical) and its own branches' accelerations.  Every wave integrates the trunk's joints and
+// its own; nothing else of the state crosses between waves until the rows are written back.
+//
+// Included after the generated split header (RBL_NS, RBL_NQ, RBL_NT, RBL_NPARTS, RBL_PART_LDS, RBL_X_SLOTS, the tables
+// KSG / QLO / QHI / VMAX / PART_OF_JOINT and RBL_NS::rbl_part).  LDS of a workgroup, in 64-float slots:
+//   image   max(2 n_q + n_t, 5 n_q)   the rows of the 64 envs, transposed in / out cooperatively by all waves
+//   X       2 x RBL_X_SLOTS           exchange area, double-buffered: acceleration n uses buffer n & 1, so a wave that is
+//                                     already writing for n + 1 cannot disturb one still reading n (it cannot reach n + 2
+//                                     before the other has passed the barrier of n + 1)
+//   per wave: RBL_PART_LDS parking slots + 2 n_q RK4 accumulators; then one flag slot per wave
+#pragma once
+#include "env_common.hpp"
+#include "philox.hpp"
+
+#ifndef RBL_NPARTS
+#error "include the generated split-form header (tree_lane_gen.hpp: generate_split) first"
+#endif
+
+namespace RBL_NS {
+
+struct SplitLds {
+    float *p;   // the wave's private region + lane
+    __device__ __forceinline__ float &operator()(int slot) const { return p[slot * 64]; }
+};
+
+constexpr int SP_IMG_SLOTS = 5 * RBL_NQ > 3 * RBL_NQ + RBL_NT ? 5 * RBL_NQ : 3 * RBL_NQ + RBL_NT;
+constexpr int SP_WAVE_SLOTS = RBL_PART_LDS + 2 * RBL_NQ;
+constexpr int SP_ACC_SLOT = RBL_PART_LDS;
+constexpr int SP_X_OFF = SP_IMG_SLOTS;
+constexpr int SP_WAVE_OFF = SP_X_OFF + 2 * RBL_X_SLOTS;
+constexpr int SP_FLAG_OFF = SP_WAVE_OFF + RBL_NPARTS * SP_WAVE_SLOTS;
+constexpr int SP_LDS_SLOTS = SP_FLAG_OFF + 2 * RBL_NPARTS + 2;
+constexpr int SP_LDS_BYTES = SP_LDS_SLOTS * 64 * 4;
+
+__device__ __forceinline__ int sp_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ void sp_fence_code() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sp_rows_rsrc(const float *g, long env0, int width, int live) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(g + env0 * width);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(a)), hi = __builtin_amdgcn_readfirstlane(uint32_t(a >> 32));
+    const int bytes = __builtin_amdgcn_readfirstlane(live * width * 4);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>((uintptr_t(hi) << 32) | lo), 0, bytes, 0x00020000);
+}
+// `width` slots of a row image, moved by the waves of the workgroup together: wave w takes the slots k = w, w + K, ...
+// (HBM -> image: 64 consecutive floats of the rows' run per slot; the range check of the resource guards the tail)
+template <int W>
+__device__ __forceinline__ void sp_load_image(const float *__restrict__ g, long env0, int live, float *img, int wave, int lane) {
+    const __amdgpu_buffer_rsrc_t r = sp_rows_rsrc(g, env0, W, live);
+    constexpr int PER = (W + RBL_NPARTS - 1) / RBL_NPARTS;
+    float t[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int k = wave + u * RBL_NPARTS;
+        t[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, (k < W ? k : W - 1) * 256, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int k = wave + u * RBL_NPARTS;
+        if (k < W) img[k * 64 + lane] = t[u];
+    }
+}
+template <int W>
+__device__ __forceinline__ void sp_store_image(float *__restrict__ g, long env0, int live, const float *img, int wave, int lane) {
+    const __amdgpu_buffer_rsrc_t r = sp_rows_rsrc(g, env0, W, live);
+    constexpr int PER = (W + RBL_NPARTS - 1) / RBL_NPARTS;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int k = wave + u * RBL_NPARTS;
+        if (k < W) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(img[k * 64 + lane]), r, lane * 4, k * 256, 0);
+    }
+}
+
+__device__ __forceinline__ float sp_sat(float v, int j) { return __builtin_amdgcn_fmed3f(v, -VMAX[j], VMAX[j]); }
+template <int PART>
+__device__ __forceinline__ constexpr bool sp_mine(int j) { return PART_OF_JOINT[j] < 0 || PART_OF_JOINT[j] == PART; }
+
+// One env step of the joints part PART integrates (the trunk's and its own); the other entries of q / v are not touched.
+template <int INTEG, int PART>
+__device__ __forceinline__ bool split_step(const SplitLds &L, float *xbase, int lane, const float (&spu)[RBL_NT], float h, int nsub,
+                                           float (&q)[RBL_NQ], float (&v)[RBL_NQ]) {
+    bool ok = true;
+    int n_acc = 0;                                   // accelerations so far: selects the exchange buffer
+    auto accel = [&](const float (&qq)[RBL_NQ], const float (&vv)[RBL_NQ], float (&out)[RBL_NQ]) {
+        const SplitLds X{xbase + (n_acc & 1) * (RBL_X_SLOTS * 64) + lane};
+        ++n_acc;
+        sp_fence_code();
+        rbl_part(PART, qq, vv, spu, out, L, X);
+        sp_fence_code();
+    };
+    for (int sub = 0; sub < nsub; ++sub) {
+        if (INTEG == 0) {
+            float a[RBL_NQ];
+            accel(q, v, a);
+#pragma unroll
+            for (int j = 0; j < RBL_NQ; ++j)
+                if (sp_mine<PART>(j)) { v[j] = sp_sat(v[j] + h * a[j], j); q[j] = q[j] + h * v[j]; }
+        } else {
+            const float h6 = h * (1.0f / 6.0f);
+            float kq[RBL_NQ], kv[RBL_NQ];
+#pragma unroll
+            for (int j = 0; j < RBL_NQ; ++j) { kq[j] = 0.0f; kv[j] = 0.0f; L(SP_ACC_SLOT + j) = 0.0f; L(SP_ACC_SLOT + RBL_NQ + j) = 0.0f; }
+#pragma unroll 1
+            for (int st = 0; st < 4; ++st) {
+                const float wgt = (st == 0 || st == 3) ? 1.0f : 2.0f, cst = st == 0 ? 0.0f : (st == 3 ? h : 0.5f * h);
+                float qs[RBL_NQ];
+#pragma unroll
+                for (int j = 0; j < RBL_NQ; ++j) {
+                    qs[j] = 0.0f;
+                    if (sp_mine<PART>(j)) { qs[j] = q[j] + cst * kq[j]; kq[j] = sp_sat(v[j] + cst * kv[j], j); }
+                }
+#pragma unroll
+                for (int j = 0; j < RBL_NQ; ++j) if (sp_mine<PART>(j)) L(SP_ACC_SLOT + j) += wgt * kq[j];
+                accel(qs, kq, kv);
+#pragma unroll
+                for (int j = 0; j < RBL_NQ; ++j) if (sp_mine<PART>(j)) L(SP_ACC_SLOT + RBL_NQ + j) += wgt * kv[j];
+            }
+#pragma unroll
+            for (int j = 0; j < RBL_NQ; ++j)
+                if (sp_mine<PART>(j)) { q[j] = q[j] + h6 * L(SP_ACC_SLOT + j); v[j] = v[j] + h6 * L(SP_ACC_SLOT + RBL_NQ + j); }
+        }
+#pragma unroll
+        for (int j = 0; j < RBL_NQ; ++j) {
+            if (!sp_mine<PART>(j)) continue;
+            float vv = sp_sat(v[j], j);
+            const bool over = q[j] > QHI[j], under = q[j] < QLO[j];
+            if (over) { q[j] = QHI[j]; vv = fminf(vv, 0.0f); }
+            if (under) { q[j] = QLO[j]; vv = fmaxf(vv, 0.0f); }
+            v[j] = vv;
+            ok = ok && !(over || under);
+        }
+    }
+    return ok;
+}
+
+// everything between the loaded rows and the row images of the results, for the wave that runs part PART
+template <int INTEG, int PART>
+__device__ __forceinline__ void split_wave(float *lds, int lane, int live, float act_scale, float h, int nsub, bool env_layer,
+                                           const rbe::EnvParams *ep) {
+    float *img = lds;
+    const int row = sp_opaque(lane < live ? lane : live - 1);
+    float q[RBL_NQ], v[RBL_NQ], spu[RBL_NT];
+    constexpr int OV = RBL_NQ * 64, OA = 2 * RBL_NQ * 64;
+#pragma unroll
+    for (int j = 0; j < RBL_NQ; ++j) { q[j] = img[row * RBL_NQ + j]; v[j] = img[OV + row * RBL_NQ + j]; }
+#pragma unroll
+    for (int k = 0; k < RBL_NT; ++k) {
+        const float a = img[OA + row * RBL_NT + k];
+        if (env_layer) {
+            // clamp to the action box, then slope * (x - in_high) + out_high with two roundings (roboy_env.py:157-158)
+            const float x = fminf(fmaxf(a, -1.0f), 1.0f);
+            spu[k] = rbe::mul_then_add(ep->slope, x - 1.0f, ep->act_hi) * KSG[k];
+        } else {
+            spu[k] = (a * act_scale) * KSG[k];
+        }
+    }
+    const SplitLds L{lds + (SP_WAVE_OFF + PART * SP_WAVE_SLOTS) * 64 + lane};
+    const bool ok = split_step<INTEG, PART>(L, lds + SP_X_OFF * 64, lane, spu, h, nsub, q, v);
+    // (the accelerations' barriers lie between every wave's reads of the input image above and these writes)
+    const int wl = sp_opaque(lane);
+#pragma unroll
+    for (int j = 0; j < RBL_NQ; ++j)
+        if (PART_OF_JOINT[j] == PART || (PART_OF_JOINT[j] < 0 && PART == 0)) { img[wl * RBL_NQ + j] = q[j]; img[OV + wl * RBL_NQ + j] = v[j]; }
+    lds[(SP_FLAG_OFF + PART) * 64 + lane] = ok ? 1.0f : 0.0f;
+}
+
+template <int INTEG, int PART>
+__device__ __forceinline__ void split_dispatch(int wave, float *lds, int lane, int live, float act_scale, float h, int nsub, bool env_layer,
+                                               const rbe::EnvParams *ep) {
+    if constexpr (PART < RBL_NPARTS) {
+        if (wave == PART) split_wave<INTEG, PART>(lds, lane, live, act_scale, h, nsub, env_layer, ep);
+        else split_dispatch<INTEG, PART + 1>(wave, lds, lane, live, act_scale, h, nsub, env_layer, ep);
+    }
+}
+
+// forward_step_command for a batch (the contract of tree_lane_step / tree_step_aba)
+template <int INTEG>
+__global__ void __launch_bounds__(64 * RBL_NPARTS)
+tree_split_step(float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas, const float *__restrict__ act,
+                float act_scale, float h, int nsub, long n) {
+    extern __shared__ float lds_split[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long env0 = long(blockIdx.x) * 64;
+    if (env0 >= n) return;                          // (the whole workgroup: no barrier is left behind)
+    const int live = n - env0 < 64 ? int(n - env0) : 64;
+    float *lds = lds_split;
+    sp_load_image<RBL_NQ>(q, env0, live, lds, wave, lane);
+    sp_load_image<RBL_NQ>(qd, env0, live, lds + RBL_NQ * 64, wave, lane);
+    sp_load_image<RBL_NT>(act, env0, live, lds + 2 * RBL_NQ * 64, wave, lane);
+    __syncthreads();
+    split_dispatch<INTEG, 0>(wave, lds, lane, live, act_scale, h, nsub, false, nullptr);
+    __syncthreads();
+    sp_store_image<RBL_NQ>(q, env0, live, lds, wave, lane);
+    sp_store_image<RBL_NQ>(qd, env0, live, lds + RBL_NQ * 64, wave, lane);
+    if (wave == 0 && lane < live) {
+        bool ok = true;
+#pragma unroll
+        for (int p = 0; p < RBL_NPARTS; ++p) ok = ok && lds[(SP_FLAG_OFF + p) * 64 + lane] != 0.0f;
+        feas[env0 + lane] = ok ? 1u : 0u;
+    }
+}
+
+}  // namespace RBL_NS

@@ -55,7 +55,10 @@ enum rb_kernel {
     RB_KERNEL_AUTO = 0,
     RB_KERNEL_ENV_PER_LANE = 1,    /* one env per lane: throughput form        */
     RB_KERNEL_TENDON_PER_LANE = 2, /* 8 lanes per env + DPP reductions: latency form */
-    RB_KERNEL_ENV_PER_WAVE = 3     /* generic joint-tree robots: a few envs per wave, eight lanes per link, LDS */
+    RB_KERNEL_ENV_PER_WAVE = 3,    /* generic joint-tree robots: a few envs per wave, eight lanes per link, LDS */
+    RB_KERNEL_ENV_PER_LANE_SPLIT = 4 /* joint trees, small batches: one env per lane, but several waves per group of 64
+                                      envs - one per set of branches of the tree - so that a step waits for a part of
+                                      the instruction stream only (plain step; the fused env layer keeps form 1) */
 };
 
 /* Robot description, format "roboy-tendon-robot/1" (Python
@@ -128,7 +131,10 @@ int rb_device_count(int *count);
  * The robot decides the kernels: one body on an x-y-z ball joint with 8 tendons
  * (MsjRobot) gets the specialised closed-form kernels; the same class with 1..16
  * tendons the closed form with a run-time tendon count (env-per-lane only); any
- * other joint tree (up to 32 joints / 64 tendons) the generic joint-tree kernel (articulated-body algorithm). */
+ * other joint tree (up to 32 joints / 64 tendons) the joint-tree kernels (articulated-body
+ * algorithm): one env per lane running code generated for the robot (the committed upper
+ * body ahead of time - with a several-waves-per-env-group form for small batches - any
+ * other robot through hiprtc) or, without such code, octets of lanes per link. */
 int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator,
               double step_size, int n_substeps, int device, uint64_t seed,
               int64_t env_id_offset, rb_sim **out);

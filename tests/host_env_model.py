@@ -18,7 +18,11 @@ class HipStepper:
         # form here so states can be compared bit for bit (the tendon-per-lane
         # form sums the 8 tendon torques in a different order)
         if robot.get_description().n_q == 3:
-            self.sim.select_kernel(1)   # joint-tree robots have a single kernel form
+            self.sim.select_kernel(1)
+        elif self.sim.info()["kernel"] == 4:
+            # joint trees: the fused env kernel is the one-wave env-per-lane form; the plain step of a small batch would
+            # take the split form on its own (other summation order at the trunk)
+            self.sim.select_kernel(1)
 
     def step(self, sp):
         return self.sim.forward_step_command(sp)

@@ -89,6 +89,38 @@ def test_random_tree_robot_env_per_lane_kernel_matches_oracle(seed):
     sim.close()
 
 
+@pytest.mark.parametrize("seed", [5, 9])        # 11 joints in 2 parts, 18 joints in 4 parts (several roots: no trunk)
+def test_random_tree_robot_split_form_matches_oracle(seed):
+    """The split form (several waves per group of 64 envs) of a random robot, built by hiprtc on request."""
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    from oracle.c_oracle import COracle
+    robot, desc = random_tree_robot(seed)
+    integrator = "rk4" if seed % 2 else "euler"
+    n = 130
+    q, qd, sp = random_states(desc, n, seed)
+    sim = HipBatchSimulation(robot, n, integrator=integrator, n_substeps=2 if seed == 5 else 1)
+    sim.select_kernel(4)
+    assert sim.info()["kernel"] == 4 and sim.specialization() == "jit"
+    sim.set_state(q, qd)
+    q1, qd1, f1 = sim.forward_step_command(sp)
+    qo, qdo, fo = COracle(desc, "f64").step(q, qd, sp, integrator=0 if integrator == "euler" else 1, n_substeps=2 if seed == 5 else 1)
+    tol = tolerance(desc, q, qd, sp)
+    assert np.all(np.abs(q1 - qo) < tol), (desc.n_q, desc.n_t, np.abs(q1 - qo).max())
+    assert np.all(np.abs(qd1 - qdo) < tol), (desc.n_q, desc.n_t, np.abs(qd1 - qdo).max())
+    near = np.minimum(np.abs(qo - desc.q_lo), np.abs(qo - desc.q_hi)).min(axis=1) < 1e-5
+    assert not np.any((f1 != fo) & ~near)
+    sim.close()
+
+
+def test_split_form_is_refused_where_the_tree_has_no_parts():
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    robot, _ = random_tree_robot(41, n_q=6, n_t=3, shape="chain")
+    sim = HipBatchSimulation(robot, 10)
+    with pytest.raises(Exception, match="no split form"):
+        sim.select_kernel(4)
+    sim.close()
+
+
 def test_library_builds_the_lane_kernels_on_its_own_only_where_they_fit():
     """The library's own choice at 16 384 envs: a robot whose generated code keeps few values alive gets the hiprtc-built
     env-per-lane kernels (and they match the oracle on a sample); a dense 22-joint robot whose live set exceeds a SIMD's

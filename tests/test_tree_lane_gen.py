@@ -177,3 +177,82 @@ def test_hiprtc_builds_the_kernels_of_a_random_robot():
         rc, log, size = _hiprtc_compile(src, "roboy_tree_lane_jit.hip", [kern])
         assert rc == 0, log[:2000]
         assert size > 10000
+
+
+def host_split_accel(desc, tag, max_parts=4):
+    """generate_split -> g++ -> ctypes; returns (accel(q, qd, sp) -> (qdd, trunk mismatches), info)."""
+    import gen_tree_lane_baked as gen
+    os.makedirs(BUILD, exist_ok=True)
+    hdr = os.path.join(BUILD, "lane_split_%s.hpp" % tag)
+    info = gen.generate_split(desc, hdr, max_parts)
+    so = os.path.join(BUILD, "liblane_split_%s.so" % tag)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", '-DRBL_GENERATED="%s"' % hdr,
+                           "-o", so, os.path.join(ROOT, "tests", "hostmath", "tree_lane_split_host.cpp")])
+    lib = ctypes.CDLL(so)
+    dims = (ctypes.c_int * 5)()
+    lib.tl_dims(dims)
+    assert (dims[0], dims[1], dims[2]) == (desc.n_q, desc.n_t, info["n_parts"])
+
+    def accel(q, qd, sp):
+        q = np.ascontiguousarray(q, np.float32); qd = np.ascontiguousarray(qd, np.float32)
+        sp = np.ascontiguousarray(sp, np.float32)
+        out = np.zeros_like(q)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        return out, lib.tl_accel(p(q), p(qd), p(sp), p(out), q.shape[0])
+    return accel, info
+
+
+def check_split(desc, tag, n=12, tol=2e-4, max_parts=4):
+    from oracle.physics_np import TendonRobotOracle
+    accel, info = host_split_accel(desc, tag, max_parts)
+    rng = np.random.default_rng(11)
+    q = rng.uniform(0.9 * desc.q_lo, 0.9 * desc.q_hi, (n, desc.n_q)).astype(np.float32)
+    qd = rng.uniform(-desc.qd_max, desc.qd_max, (n, desc.n_q)).astype(np.float32)
+    sp = rng.uniform(-0.3, 0.3, (n, desc.n_t)).astype(np.float32)
+    ref = TendonRobotOracle(desc).acceleration(q.astype(np.float64), qd.astype(np.float64), sp.astype(np.float64))
+    got, mismatches = accel(q, qd, sp)
+    assert mismatches == 0, "the trunk's accelerations differ between the parts"
+    scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))
+    err = np.abs(got - ref) / scale
+    assert np.isfinite(got).all() and err.max() < tol, err.max()
+    return info
+
+
+def test_upper_body_split_form_matches_oracle():
+    """Several waves per env group: trunk (spine) in every part, the arms and the neck in parts of their own."""
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    info = check_split(UpperBodyRobot().get_description(), "upper_body")
+    assert info["n_parts"] == 3 and info["part_of_joint"][:3] == [-1, -1, -1]
+    assert len({info["part_of_joint"][j] for j in range(6, 13)}) == 1 and len({info["part_of_joint"][j] for j in range(13, 20)}) == 1
+    assert info["max_stmt"] < 0.5 * 11408                     # a step waits for less than half the one-wave stream
+
+
+def test_upper_body_split_in_two_parts():
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    assert check_split(UpperBodyRobot().get_description(), "upper_body2", max_parts=2)["n_parts"] == 2
+
+
+@pytest.mark.parametrize("seed", [4, 5, 9, 10, 0])
+def test_random_robots_split_form(seed):
+    """Random trees: several roots (no trunk), branches tied together by tendons (merged into one part), trunks of several links."""
+    from gym_roboy_amd.envs.robots import RobotDescription
+    from random_robots import random_tree_spec
+    import gen_tree_lane_baked as gen
+    desc = RobotDescription(random_tree_spec(seed))
+    try:
+        check_split(desc, "random%d" % seed, n=6, tol=5e-4)
+    except RuntimeError as exc:                                # no split form for this robot: a chain, or everything tied into one group
+        assert "rb_gen_tree_lane_split failed" in str(exc)
+        pytest.skip("robot %d has no split form" % seed)
+
+
+def test_star_robot_splits_into_the_maximum_number_of_parts():
+    from gym_roboy_amd.envs.robots import RobotDescription
+    from random_robots import random_tree_spec
+    spec = random_tree_spec(77, n_q=9, n_t=8, shape="star")
+    for t in spec["tendons"]:                                  # tendons between the base and ONE link each: nothing ties branches together
+        link = t["via_points"][-1]["link"]
+        link = link if link >= 1 else 1
+        t["via_points"] = [{"link": -1, "pos": t["via_points"][0]["pos"]}, {"link": link, "pos": t["via_points"][-1]["pos"]}]
+    info = check_split(RobotDescription(spec), "star9", n=6, tol=5e-4)
+    assert info["n_parts"] == 4 and info["part_of_joint"][0] == -1

@@ -1,7 +1,8 @@
 """GPU parity of the joint-tree kernels against the fp64 oracle, on the synthetic 20-DOF / 38-tendon upper body
-(BASELINE.json configs[3]) and on MSJ variants that are not ball joints, in both kernel forms: env-per-lane
-(rb_kernel 1: code generated for the robot - compiled ahead of time for the upper body, by hiprtc otherwise) and
-octets (rb_kernel 3: two envs per wave, eight lanes per link, tables in LDS).
+(BASELINE.json configs[3]) and on MSJ variants that are not ball joints, in every kernel form: env-per-lane
+(rb_kernel 1: code generated for the robot - compiled ahead of time for the upper body, by hiprtc otherwise), its
+split form (rb_kernel 4: several waves per group of 64 envs, one per set of branches - the library's choice for the
+upper body up to 16 384 envs) and octets (rb_kernel 3: two envs per wave, eight lanes per link, tables in LDS).
 Tolerance 2e-5 on the state after one env step."""
 import numpy as np
 import pytest
@@ -24,7 +25,7 @@ def upper_oracle(upper_body):
     return COracle(upper_body.get_description(), "f64")
 
 
-LANE, OCTET = 1, 3      # rb_kernel: RB_KERNEL_ENV_PER_LANE, RB_KERNEL_ENV_PER_WAVE
+LANE, OCTET, SPLIT = 1, 3, 4      # rb_kernel: RB_KERNEL_ENV_PER_LANE, RB_KERNEL_ENV_PER_WAVE, RB_KERNEL_ENV_PER_LANE_SPLIT
 
 
 def _check(robot, oracle, n, integrator, nsub, seed, kernel=None, expect=OCTET):
@@ -50,21 +51,47 @@ def _check(robot, oracle, n, integrator, nsub, seed, kernel=None, expect=OCTET):
 @pytest.mark.parametrize("integrator", ["euler", "rk4"])
 @pytest.mark.parametrize("nsub", [1, 2])
 @pytest.mark.parametrize("n", [1, 257])
-@pytest.mark.parametrize("kernel", [None, OCTET])
+@pytest.mark.parametrize("kernel", [None, LANE, OCTET])
 def test_upper_body_step_matches_oracle(upper_body, upper_oracle, integrator, nsub, n, kernel):
-    # the library's choice for the committed upper body is the env-per-lane form compiled ahead of time
-    _check(upper_body, upper_oracle, n, integrator, nsub, seed=n + nsub, kernel=kernel, expect=LANE)
+    # the library's choice for the committed upper body at these batch sizes is the split form compiled ahead of time
+    _check(upper_body, upper_oracle, n, integrator, nsub, seed=n + nsub, kernel=kernel, expect=SPLIT)
+
+
+def test_kernel_forms_of_the_upper_body_agree_with_each_other(upper_body):
+    """Same states and set-points through all three forms: the differences are rounding (other summation orders at the
+    trunk, other instruction streams), far inside the tolerance against the oracle."""
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    desc = upper_body.get_description()
+    n = 300
+    q, qd, sp = random_states(desc, n, 21)
+    out = {}
+    for kernel in (LANE, SPLIT, OCTET):
+        for integ in ("euler", "rk4"):
+            sim = HipBatchSimulation(upper_body, n, integrator=integ)
+            sim.select_kernel(kernel)
+            sim.set_state(q, qd)
+            out[kernel, integ] = sim.forward_step_command(sp)
+            sim.close()
+    for integ in ("euler", "rk4"):
+        for kernel in (SPLIT, OCTET):
+            assert np.abs(out[kernel, integ][0] - out[LANE, integ][0]).max() < 5e-6
+            assert np.abs(out[kernel, integ][1] - out[LANE, integ][1]).max() < 5e-6
 
 
 def test_upper_body_specialization_is_the_ahead_of_time_table(upper_body):
     from gym_roboy_amd.envs.simulations import HipBatchSimulation
     sim = HipBatchSimulation(upper_body, 64)
-    assert sim.specialization() == "table"
+    assert sim.specialization() == "table" and sim.info()["kernel"] == SPLIT
     sim.select_kernel(OCTET)
     assert sim.specialization() == "kernarg" and sim.info()["kernel"] == OCTET
+    sim.select_kernel(LANE)
+    assert sim.specialization() == "table" and sim.info()["kernel"] == LANE
     sim.select_kernel(0)
-    assert sim.info()["kernel"] == LANE
+    assert sim.info()["kernel"] == SPLIT
     sim.close()
+    big = HipBatchSimulation(upper_body, 16384 + 64)          # beyond the split form's batch range: one wave per 64 envs
+    assert big.info()["kernel"] == LANE and big.specialization() == "table"
+    big.close()
 
 
 def test_upper_body_numpy_oracle_agrees_too(upper_body):

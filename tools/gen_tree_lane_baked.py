@@ -37,7 +37,23 @@ def generate(desc, path, lds_c=True):
     return slots.value, stmts.value, h.value, fl.value, live.value
 
 
+def generate_split(desc, path, max_parts=4):
+    """Write the split-form header (one function per wave) of `desc` to `path`; returns a dict of its figures."""
+    lib = load_generator()
+    c = ctypes
+    n_parts, part_lds, x_slots, max_stmt, n_stmt, h = c.c_int(0), c.c_int(0), c.c_int(0), c.c_int(0), c.c_int(0), c.c_ulonglong(0)
+    parts = (c.c_int * desc.n_q)()
+    rc = lib.rb_gen_tree_lane_split(c.byref(desc.as_c_struct()), int(max_parts), path.encode(), c.byref(n_parts), c.byref(part_lds),
+                                    c.byref(x_slots), c.byref(max_stmt), c.byref(n_stmt), parts, c.byref(h))
+    if rc:
+        raise RuntimeError("rb_gen_tree_lane_split failed: %d" % rc)
+    return {"n_parts": n_parts.value, "part_lds": part_lds.value, "x_slots": x_slots.value, "max_stmt": max_stmt.value,
+            "n_stmt": n_stmt.value, "part_of_joint": list(parts), "hash": h.value}
+
+
 if __name__ == "__main__":
     from gym_roboy_amd.envs.robots import UpperBodyRobot
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gym_roboy_amd", "csrc", "tree_lane_baked.hpp")
     print("wrote", out, generate(UpperBodyRobot().get_description(), out))
+    out = os.path.join(os.path.dirname(out), "tree_lane_split_baked.hpp")
+    print("wrote", out, generate_split(UpperBodyRobot().get_description(), out))
