@@ -381,7 +381,7 @@ struct rb_sim {
     // the split form of the same (tree_lane_split.hpp): several waves per group of 64 envs, for small batches
     rblg::SplitGenerated split_gen;
     bool split_ok = false, split_baked = false;
-    rblj::Kernel split_step_k;
+    rblj::Kernel split_step_k, split_env_k;
     GoalBox box;
     hipStream_t own_stream = nullptr, stream = nullptr;
     float *d_q = nullptr, *d_qd = nullptr;
@@ -443,15 +443,16 @@ bool tree_wants_split(const rb_sim *s) {
 }
 size_t split_lds_bytes(const rblg::SplitGenerated &g) {      // the formula of tree_lane_split.hpp: SP_LDS_BYTES
     const int img = 5 * g.n_q > 3 * g.n_q + g.n_t ? 5 * g.n_q : 3 * g.n_q + g.n_t;
-    return size_t(img + 2 * g.x_slots + g.n_parts * (g.part_lds + 2 * g.n_q) + 2 * g.n_parts + 2) * 64 * 4;
+    return size_t(img + 2 * g.x_slots + g.n_parts * (g.part_lds + 2 * g.n_q) + 3 * g.n_parts + 1) * 64 * 4;
 }
-// the hiprtc-built split step kernel of a robot without ahead-of-time instances (explicit choice only)
-bool build_split_kernel(rb_sim *s) {
-    rblj::Kernel &k = s->split_step_k;
+// the hiprtc-built split kernels of a robot without ahead-of-time instances (explicit choice only); kind: 0 = step, 1 = env step
+bool build_split_kernel(rb_sim *s, int kind = 0) {
+    rblj::Kernel &k = kind == 0 ? s->split_step_k : s->split_env_k;
     if (k.state != 0) return k.state == 1;
+    if (capturing(s)) return false;                      // try again outside the capture
     if (hipSetDevice(s->device) != hipSuccess) { k.state = -1; k.why = "hipSetDevice failed"; return false; }
     const std::string src = "#include \"tree_lane_defs.hpp\"\n#define RBL_NS rbl_jit_split\n" + s->split_gen.text + "#include \"tree_lane_split.hpp\"\n";
-    const std::string name = std::string("rbl_jit_split::tree_split_step<") + (s->integrator == RB_EULER ? "0>" : "1>");
+    const std::string name = std::string(kind == 0 ? "rbl_jit_split::tree_split_step<" : "rbl_jit_split::tree_split_env_step<") + (s->integrator == RB_EULER ? "0>" : "1>");
     const char *names[1] = {name.c_str()};
     hipFunction_t *slots[1] = {&k.fn};
     k.state = rbj::compile_and_load(src, "roboy_tree_split_jit.hip", names, 1, k.mod, slots, k.why) ? 1 : -1;
@@ -748,7 +749,10 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
         RB_TREE_ATTR((rbt::tree_step_aba<0, rbt::TREE_E, false>)); RB_TREE_ATTR((rbt::tree_step_aba<1, rbt::TREE_E, false>));
         RB_TREE_ATTR((rbt::tree_env_step_aba<0, rbt::TREE_E, true>)); RB_TREE_ATTR((rbt::tree_env_step_aba<1, rbt::TREE_E, true>));
         RB_TREE_ATTR((rbt::tree_env_step_aba<0, rbt::TREE_E, false>)); RB_TREE_ATTR((rbt::tree_env_step_aba<1, rbt::TREE_E, false>));
-        if (s->split_baked) { RB_TREE_ATTR(rbl_split_baked::tree_split_step<0>); RB_TREE_ATTR(rbl_split_baked::tree_split_step<1>); }
+        if (s->split_baked) {
+            RB_TREE_ATTR(rbl_split_baked::tree_split_step<0>); RB_TREE_ATTR(rbl_split_baked::tree_split_step<1>);
+            RB_TREE_ATTR(rbl_split_baked::tree_split_env_step<0>); RB_TREE_ATTR(rbl_split_baked::tree_split_env_step<1>);
+        }
 #undef RB_TREE_ATTR
     }
     RB_TRY(hipMemsetAsync(s->d_goal_count, 0, sizeof(uint32_t) * size_t(n_envs), s->stream));
@@ -770,7 +774,7 @@ void rb_destroy(rb_sim *s) {
     if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
     for (auto &kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     rbj::unload(s->jit);
-    rblj::unload(s->lane_step_k); rblj::unload(s->lane_env_k); rblj::unload(s->split_step_k);
+    rblj::unload(s->lane_step_k); rblj::unload(s->lane_env_k); rblj::unload(s->split_step_k); rblj::unload(s->split_env_k);
     (void)hipFree(s->d_q); (void)hipFree(s->d_qd); (void)hipFree(s->d_feas);
     (void)hipFree(s->d_goal_count); (void)hipFree(s->d_rows); (void)hipFree(s->d_u8); (void)hipFree(s->d_ten);
     (void)hipFree(s->d_tree_words);
@@ -1127,6 +1131,7 @@ int rb_env_configure(rb_sim *s, const rb_env_config *cfg) {
     // the run-time specialised kernels are built here, outside any capture a caller may wrap around its first step
     maybe_jit(s);
     if (s->tree && tree_wants_lane(s) && !s->lane_baked) (void)lane_kernel(s, 1);
+    if (s->tree && tree_wants_split(s) && !s->split_baked) (void)build_split_kernel(s, 1);
     return rb_env_reset_dev(s, nullptr);
 }
 
@@ -1166,6 +1171,33 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
     if (!s->env_ready) return fail(RB_EINVAL, "rb_env_configure has not been called");
     if (!s->tree && reinterpret_cast<uintptr_t>(d_act) % 16) return fail(RB_EINVAL, "action slab must be 16-byte aligned");
     const long n = s->n;
+    if (s->tree && tree_wants_split(s) && (s->split_baked || build_split_kernel(s, 1))) {
+        const unsigned groups = blocks_for(n, 64);
+        const size_t lds = split_lds_bytes(s->split_gen);
+        const float h = s->tree_host.dev.h;
+        const int nsub = s->tree_host.dev.nsub;
+        const unsigned threads = 64u * unsigned(s->split_gen.n_parts);
+#define RB_SPLIT_ENV_ARGS s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, s->d_ep_ret, s->d_goal_count, d_act, \
+                          d_obs, d_reward, d_done, s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, h, nsub, n, s->seed, uint64_t(s->env0)
+        if (s->split_baked) {
+            if (s->integrator == RB_EULER) hipLaunchKernelGGL(rbl_split_baked::tree_split_env_step<0>, dim3(groups), dim3(threads), lds, s->stream, RB_SPLIT_ENV_ARGS);
+            else hipLaunchKernelGGL(rbl_split_baked::tree_split_env_step<1>, dim3(groups), dim3(threads), lds, s->stream, RB_SPLIT_ENV_ARGS);
+        } else {
+            EnvParams ep = s->env;
+            GoalBox box = s->box;
+            float hh = h;
+            int ns = nsub;
+            long nn = n;
+            uint64_t seed = s->seed, env0 = uint64_t(s->env0);
+            void *args[] = {&ep, &box, &s->d_q, &s->d_qd, &s->d_feas, &s->d_goal, &s->d_step_num, &s->d_ep_ret, &s->d_goal_count, &d_act,
+                            &d_obs, &d_reward, &d_done, &s->d_ep_sum, &s->d_ep_cnt, &s->d_infeas_n, &hh, &ns, &nn, &seed, &env0};
+            RB_HIP(hipModuleLaunchKernel(s->split_env_k.fn, groups, 1, 1, threads, 1, 1, unsigned(lds), s->stream, args, nullptr));
+        }
+#undef RB_SPLIT_ENV_ARGS
+        RB_HIP(hipGetLastError());
+        s->env_steps += double(n);
+        return RB_OK;
+    }
     if (s->tree && tree_use_lane(s, 1)) {
         const unsigned waves = blocks_for(n, 64);
         const size_t lds = rblg::lane_lds_bytes_per_wave(s->lane_gen);

@@ -35,7 +35,7 @@ constexpr int SP_ACC_SLOT = RBL_PART_LDS;
 constexpr int SP_X_OFF = SP_IMG_SLOTS;
 constexpr int SP_WAVE_OFF = SP_X_OFF + 2 * RBL_X_SLOTS;
 constexpr int SP_FLAG_OFF = SP_WAVE_OFF + RBL_NPARTS * SP_WAVE_SLOTS;
-constexpr int SP_LDS_SLOTS = SP_FLAG_OFF + 2 * RBL_NPARTS + 2;
+constexpr int SP_LDS_SLOTS = SP_FLAG_OFF + 3 * RBL_NPARTS + 1;    // per part: limit flag, and (env layer) its joints' shares of |dq|^2, |qd|^2; then the "a goal changed" word
 constexpr int SP_LDS_BYTES = SP_LDS_SLOTS * 64 * 4;
 
 __device__ __forceinline__ int sp_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
@@ -161,6 +161,11 @@ __device__ __forceinline__ void split_wave(float *lds, int lane, int live, float
             spu[k] = (a * act_scale) * KSG[k];
         }
     }
+    // env layer: the goals of the joints this wave accounts for (it sums their squared distances), read before the image is reused
+    constexpr int OG = (2 * RBL_NQ + RBL_NT) * 64;
+    float gl[RBL_NQ];
+#pragma unroll
+    for (int j = 0; j < RBL_NQ; ++j) gl[j] = (env_layer && (PART_OF_JOINT[j] == PART || (PART_OF_JOINT[j] < 0 && PART == 0))) ? img[OG + row * RBL_NQ + j] : 0.0f;
     const SplitLds L{lds + (SP_WAVE_OFF + PART * SP_WAVE_SLOTS) * 64 + lane};
     const bool ok = split_step<INTEG, PART>(L, lds + SP_X_OFF * 64, lane, spu, h, nsub, q, v);
     // (the accelerations' barriers lie between every wave's reads of the input image above and these writes)
@@ -168,7 +173,15 @@ __device__ __forceinline__ void split_wave(float *lds, int lane, int live, float
 #pragma unroll
     for (int j = 0; j < RBL_NQ; ++j)
         if (PART_OF_JOINT[j] == PART || (PART_OF_JOINT[j] < 0 && PART == 0)) { img[wl * RBL_NQ + j] = q[j]; img[OV + wl * RBL_NQ + j] = v[j]; }
-    lds[(SP_FLAG_OFF + PART) * 64 + lane] = ok ? 1.0f : 0.0f;
+    lds[(SP_FLAG_OFF + 3 * PART) * 64 + lane] = ok ? 1.0f : 0.0f;
+    if (env_layer) {
+        float dq2 = 0.0f, dv2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < RBL_NQ; ++j)
+            if (PART_OF_JOINT[j] == PART || (PART_OF_JOINT[j] < 0 && PART == 0)) { const float dq = q[j] - gl[j]; dq2 += dq * dq; dv2 += v[j] * v[j]; }
+        lds[(SP_FLAG_OFF + 3 * PART + 1) * 64 + lane] = dq2;
+        lds[(SP_FLAG_OFF + 3 * PART + 2) * 64 + lane] = dv2;
+    }
 }
 
 template <int INTEG, int PART>
@@ -202,9 +215,121 @@ tree_split_step(float *__restrict__ q, float *__restrict__ qd, uint32_t *__restr
     if (wave == 0 && lane < live) {
         bool ok = true;
 #pragma unroll
-        for (int p = 0; p < RBL_NPARTS; ++p) ok = ok && lds[(SP_FLAG_OFF + p) * 64 + lane] != 0.0f;
+        for (int p = 0; p < RBL_NPARTS; ++p) ok = ok && lds[(SP_FLAG_OFF + 3 * p) * 64 + lane] != 0.0f;
         feas[env0 + lane] = ok ? 1u : 0u;
     }
+}
+
+// RoboyEnv.step fused around the split step (semantics of tree_lane_env_step / msj_env_step_kernel).  The waves
+// step their joints; wave 0 then is the envs' accountant (one env per lane): reward and done from the waves' partial sums,
+// goal redraw (and reset) on done, the observation rows; all waves write the row images back together.
+template <int INTEG>
+__global__ void __launch_bounds__(64 * RBL_NPARTS)
+tree_split_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__restrict__ q, float *__restrict__ qd,
+                    uint32_t *__restrict__ feas, float *__restrict__ goal, uint32_t *__restrict__ step_num,
+                    float *__restrict__ ep_ret, uint32_t *__restrict__ goal_count, const float *__restrict__ act,
+                    float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
+                    double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt, uint32_t *__restrict__ infeas_n,
+                    float h, int nsub, long n, uint64_t seed, uint64_t env_id0) {
+    extern __shared__ float lds_split[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long env0 = long(blockIdx.x) * 64;
+    if (env0 >= n) return;
+    const int live = n - env0 < 64 ? int(n - env0) : 64;
+    float *lds = lds_split;
+    constexpr int OV = RBL_NQ * 64, OA = 2 * RBL_NQ * 64, OG = (2 * RBL_NQ + RBL_NT) * 64;
+    constexpr int OO = 2 * RBL_NQ * 64;                    // the observation image takes the place of the action and goal images
+    sp_load_image<RBL_NQ>(q, env0, live, lds, wave, lane);
+    sp_load_image<RBL_NQ>(qd, env0, live, lds + OV, wave, lane);
+    sp_load_image<RBL_NT>(act, env0, live, lds + OA, wave, lane);
+    sp_load_image<RBL_NQ>(goal, env0, live, lds + OG, wave, lane);
+    // the accountant's counters, requested now (their latency passes behind the step)
+    const bool mine = wave == 0 && lane < live;
+    const long me = env0 + (lane < live ? lane : live - 1);
+    uint32_t sn_old = 0u;
+    float ret_old = 0.0f;
+    if (wave == 0) { sn_old = step_num[me]; ret_old = ep_ret[me]; }
+    __syncthreads();
+    // the old goal row of the accountant's env, for the observation (the image is overwritten below)
+    float gg[RBL_NQ];
+    if (wave == 0) {
+        const int row = sp_opaque(lane < live ? lane : live - 1);
+#pragma unroll
+        for (int j = 0; j < RBL_NQ; ++j) gg[j] = lds[OG + row * RBL_NQ + j];
+    }
+    split_dispatch<INTEG, 0>(wave, lds, lane, live, 1.0f, h, nsub, true, &ep);
+    __syncthreads();
+    if (wave == 0) {
+        const int wl = sp_opaque(lane);
+        bool ok = true;
+        float dq2 = 0.0f, dv2 = 0.0f;
+#pragma unroll
+        for (int p = 0; p < RBL_NPARTS; ++p) {
+            ok = ok && lds[(SP_FLAG_OFF + 3 * p) * 64 + lane] != 0.0f;
+            dq2 += lds[(SP_FLAG_OFF + 3 * p + 1) * 64 + lane];
+            dv2 += lds[(SP_FLAG_OFF + 3 * p + 2) * 64 + lane];
+        }
+        uint32_t sn = sn_old + 1u;
+        bool reached;
+        const float r = rbe::env_reward(ep, dq2, dv2, ok, reached);
+        const bool dn = reached || (sn > uint32_t(ep.max_len));
+        float ret = ret_old + r;
+        uint32_t fz = ok ? 1u : 0u;
+        float gn[RBL_NQ];
+#pragma unroll
+        for (int j = 0; j < RBL_NQ; ++j) gn[j] = gg[j];
+        if (dn) {
+            const uint64_t gid = env_id0 + uint64_t(me);
+            uint32_t draw = goal_count[me];
+            auto draw_goals = [&](uint32_t dnum) {
+#pragma unroll
+                for (int b = 0; 4 * b < RBL_NQ; ++b) {
+                    const rb::Philox4 rnd = rb::philox_draw(seed, gid, dnum, rb::STREAM_GOALS, uint32_t(b));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (4 * b + k < RBL_NQ) gn[4 * b + k] = rbe::goal_value(box.lo[4 * b + k], box.hi[4 * b + k], rnd.v[k]);
+                }
+            };
+            draw_goals(draw++);                            // RoboyEnv.step: _set_new_goal (:67-68), AFTER the observation was made (:60)
+            if (ep.auto_reset) {                           // VecEnv worker: env.reset() (:82-87): the reset observation replaces it
+                draw_goals(draw++);
+#pragma unroll
+                for (int j = 0; j < RBL_NQ; ++j) { lds[wl * RBL_NQ + j] = 0.0f; lds[OV + wl * RBL_NQ + j] = 0.0f; gg[j] = gn[j]; }
+            }
+            if (mine) {
+                ep_sum[me] += double(ret); ep_sum[n + me] += double(ret) * double(ret);
+                ep_cnt[me] += 1u; ep_cnt[n + me] += sn - 1u; ep_cnt[2 * n + me] += reached ? 1u : 0u;
+                goal_count[me] = draw;
+            }
+            if (ep.auto_reset) { sn = 1u; fz = 1u; }
+            ret = 0.0f;
+        }
+        // observation row [q | qd | goal as observed] and the goal row after the step (a second image behind the rows' own)
+#pragma unroll
+        for (int j = 0; j < RBL_NQ; ++j) {
+            const float oq = lds[wl * RBL_NQ + j], ov = lds[OV + wl * RBL_NQ + j];
+            lds[OO + wl * (3 * RBL_NQ) + j] = oq;
+            lds[OO + wl * (3 * RBL_NQ) + RBL_NQ + j] = ov;
+            lds[OO + wl * (3 * RBL_NQ) + 2 * RBL_NQ + j] = gg[j];
+        }
+        const bool any = __builtin_amdgcn_ballot_w64(dn && mine) != 0ull;
+        if (lane == 0) lds[(SP_FLAG_OFF + 3 * RBL_NPARTS) * 64] = any ? 1.0f : 0.0f;
+        if (any) {
+            // the new goal rows go out from the accountant's registers through its own parking region (free now)
+            float *gimg = lds + (SP_WAVE_OFF) * 64;
+#pragma unroll
+            for (int j = 0; j < RBL_NQ; ++j) gimg[wl * RBL_NQ + j] = gn[j];
+        }
+        if (mine) {
+            feas[me] = fz; step_num[me] = sn; ep_ret[me] = ret; reward[me] = r; done[me] = dn ? 1u : 0u;
+            if (!ok) infeas_n[me] += 1u;
+        }
+    }
+    __syncthreads();
+    sp_store_image<RBL_NQ>(q, env0, live, lds, wave, lane);
+    sp_store_image<RBL_NQ>(qd, env0, live, lds + OV, wave, lane);
+    sp_store_image<3 * RBL_NQ>(obs, env0, live, lds + OO, wave, lane);
+    if (lds[(SP_FLAG_OFF + 3 * RBL_NPARTS) * 64] != 0.0f) sp_store_image<RBL_NQ>(goal, env0, live, lds + SP_WAVE_OFF * 64, wave, lane);
 }
 
 }  // namespace RBL_NS

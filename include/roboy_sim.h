@@ -58,7 +58,7 @@ enum rb_kernel {
     RB_KERNEL_ENV_PER_WAVE = 3,    /* generic joint-tree robots: a few envs per wave, eight lanes per link, LDS */
     RB_KERNEL_ENV_PER_LANE_SPLIT = 4 /* joint trees, small batches: one env per lane, but several waves per group of 64
                                       envs - one per set of branches of the tree - so that a step waits for a part of
-                                      the instruction stream only (plain step; the fused env layer keeps form 1) */
+                                      the instruction stream only */
 };
 
 /* Robot description, format "roboy-tendon-robot/1" (Python

@@ -19,10 +19,7 @@ class HipStepper:
         # form sums the 8 tendon torques in a different order)
         if robot.get_description().n_q == 3:
             self.sim.select_kernel(1)
-        elif self.sim.info()["kernel"] == 4:
-            # joint trees: the fused env kernel is the one-wave env-per-lane form; the plain step of a small batch would
-            # take the split form on its own (other summation order at the trunk)
-            self.sim.select_kernel(1)
+        # (joint trees: the plain step and the fused env kernel take the same form on their own - the batch size decides)
 
     def step(self, sp):
         return self.sim.forward_step_command(sp)

@@ -183,8 +183,9 @@ def test_tree_kernel_on_the_msj_robot_equals_the_closed_form(msj_robot, msj_orac
     _check(Msj4(), COracle(desc, "f64"), 65, "euler", 1, seed=8)
 
 
+@pytest.mark.parametrize("kernel", [None, LANE, OCTET])      # None: the library's choice for 130 envs, the split form
 @pytest.mark.parametrize("auto_reset,integrator", [(True, "euler"), (False, "euler"), (True, "rk4")])
-def test_fused_env_layer_on_the_upper_body_matches_host_replay(upper_body, auto_reset, integrator):
+def test_fused_env_layer_on_the_upper_body_matches_host_replay(upper_body, auto_reset, integrator, kernel):
     """RoboyVecEnv over the joint-tree kernel: same replay check as for MsjRobot
     (tests/test_env_layer_gpu.py): states and goals bit for bit against the plain
     tree kernel + numpy Philox, reward/done against reward.py in float64."""
@@ -195,8 +196,11 @@ def test_fused_env_layer_on_the_upper_body_matches_host_replay(upper_body, auto_
     n, seed, max_len = 130, 3, 9
     vec = RoboyVecEnv(upper_body, n, seed=seed, auto_reset=auto_reset, max_episode_length=max_len, joint_vel_penalty=True,
                       integrator=integrator)
-    host = HostEnvModel(upper_body, HipStepper(upper_body, n, seed, integrator=integrator), n, seed, max_len, True, True,
-                        auto_reset)
+    stepper = HipStepper(upper_body, n, seed, integrator=integrator)
+    if kernel is not None:                                # the fused kernel and the plain step it is replayed with, in the same form
+        vec.sim.select_kernel(kernel); stepper.sim.select_kernel(kernel)
+    assert vec.sim.info()["kernel"] == (kernel or SPLIT) == stepper.sim.info()["kernel"]
+    host = HostEnvModel(upper_body, stepper, n, seed, max_len, True, True, auto_reset)
     obs0 = vec.reset()
     host.goal = host.draw(np.ones(n, bool))
     assert obs0.shape == (n, 60) and not obs0[:, :40].any() and np.array_equal(obs0[:, 40:], host.goal)
