@@ -18,7 +18,8 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "gym_roboy_amd", "csrc")
 DEFAULT = [r"msj_step_env_per_lane.*Li1ELi256ELi4ELb1E", r"msj_step_env_per_lane.*Li0ELi256ELi4ELb1E",
-           r"tree_lane_stepILi0E", r"tree_lane_stepILi1E", r"tree_lane_env_stepILi0E", r"tree_step_abaILi0ELi2ELb1E"]
+           r"tree_lane_stepILi0E", r"tree_lane_stepILi1E", r"tree_lane_env_stepILi0E", r"tree_split_stepILi0E", r"tree_split_stepILi1E",
+           r"tree_step_abaILi0ELi2ELb1E"]
 TRANS = ("v_exp_f32", "v_log_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32")
 
 

@@ -20,7 +20,7 @@ SRC = os.path.join(ROOT, "gpurun_out", tag)
 DST = os.path.join(ROOT, "profiles", tag)
 os.makedirs(DST, exist_ok=True)
 STEP_KERNELS = ("msj_step_env_per_lane", "msj_step_tendon_per_lane", "tree_step_aba", "msj_env_step_kernel",
-                "tree_lane_step", "tree_lane_env_step", "tree_env_step_aba")
+                "tree_lane_step", "tree_lane_env_step", "tree_env_step_aba", "tree_split_step", "tree_split_env_step")
 
 
 def counters(dirname):
@@ -38,7 +38,8 @@ def mean_tail(v, skip=10):
     return sum(v) / len(v), len(v)
 
 
-for name in ("bench_unprofiled.json", "bench_under_rocprof.json", "bench_2rank_gloo.json"):
+for name in ("bench_unprofiled.json", "bench_under_rocprof.json", "bench_2rank_gloo.json", "train_rollout_world1.json",
+             "train_rollout_world2.json", "ppo_update_kernel_stats.txt"):
     p = os.path.join(SRC, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(DST, name))
@@ -67,7 +68,7 @@ if by_grid:
             v = by_grid[key]
             tail = v[10:] if len(v) > 20 else v
             # threads per env: 8 in the tendon-per-lane form, 32 in the octet kernels (2 envs per wave), 1 otherwise
-            per_env = 8 if "tendon_per_lane" in key[0] else (32 if "_aba" in key[0] else 1)
+            per_env = 8 if "tendon_per_lane" in key[0] else (32 if "_aba" in key[0] else (key[2] // 64 if "tree_split" in key[0] else 1))
             w.writerow([key[0], key[1], key[2], key[1] // per_env, len(v), "%.1f" % (sum(tail) / len(tail)), min(tail), max(tail)] + list(meta[key]))
 
 traffic = {}
