@@ -29,6 +29,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -731,13 +732,13 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
     // ---- phase 1 of every part: trunk forward, own branches forward + tendons + backward, exports ----
     struct Export { int link, r, c; bool is_const; double cval; int slot; };   // c < 0: bias-force component r
     std::vector<Gen> gens(K);
-    std::vector<Aba *> abas(K, nullptr);
+    std::vector<std::unique_ptr<Aba>> abas(K);
     std::vector<std::vector<Export>> exports(K);
     std::vector<std::vector<Val>> export_vals(K);           // the part's own values, in export order (used in place of reading them back)
     std::vector<int> x_off(K + 1, 0);
     for (int q = 0; q < K; ++q) {
         Gen &g = gens[q];
-        abas[q] = new Aba(rob, g, true);
+        abas[q].reset(new Aba(rob, g, true));
         Aba &A = *abas[q];
         auto tendons_after = [&](int link) { for (int k = 0; k < nt; ++k) if (part_of_tendon[k] == q && rob.t_last[k] == link) A.tendon(k); };
         tendons_after(-1);
@@ -836,7 +837,6 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
         if (n_stmt > out.max_stmt) out.max_stmt = n_stmt;
         if (g.n_lds > out.part_lds) out.part_lds = g.n_lds;
     }
-    for (Aba *a : abas) delete a;
 
     // ---- the header ----
     std::string t;

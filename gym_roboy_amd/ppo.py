@@ -10,19 +10,21 @@ Hyper-parameters default to stable_baselines PPO2's (n_steps 128, 4 minibatches,
 0.5) with the reference's ``ent_coef = 0.1``.  With several ranks (one per GPU)
 gradients are averaged with ``torch.distributed.all_reduce`` (RCCL over xGMI).
 
-``use_graphs=True`` (one rank, device env) captures a whole rollout - policy forward,
-sampling, the fused env kernel launched through the C ABI, GAE - in one HIP graph and
-replays it, instead of launching ~30 small kernels per env step from Python: at 4 096
-envs 375 -> 102 us per vectorised step (``tools/ppo_profile.py``).
+``use_graphs=True`` (device env) captures a whole rollout - policy forward, sampling, the fused
+env kernel launched through the C ABI, GAE - in one HIP graph and replays it, on every rank of a
+multi-rank run (the rollout is rank-local), instead of launching ~30 small kernels per env step
+from Python: at 4 096 envs 375 -> 102 us per vectorised step (``tools/ppo_profile.py``).
 
-``fused_policy=True`` / ``fused_update=True`` replace the torch kernels of the policy by the
-matrix-core kernels of ``include/roboy_policy.h`` (exact f32): the policy step and GAE of the
-rollout (``FusedPolicyStep``, ``gae_fused``) and the minibatch gradient of the update
-(``FusedPolicyGrad``; optimiser, gradient clipping and the cross-rank average stay torch's).
-At 262 144 envs a PPO iteration goes from 49 ms + 1.06 s (rollout + update, torch: ~40
-memory-bound passes over [8.4 M x 64] activations per minibatch) to 11 ms + 0.13 s
-(``tools/policy_bench.py``).  The torch path stays the default of this class and is what the
-fused kernels are tested against; ``train_parallel.py`` selects the fused ones.
+On a GPU the policy's work runs in the kernels of ``include/roboy_policy.h`` by default (exact f32
+on the matrix cores): the policy step and GAE of the rollout (``FusedPolicyStep``, ``gae_fused``),
+the minibatch gradient (``FusedPolicyGrad``) and the rest of the update - the epoch's sample order
+as a keyed bijection evaluated on the device, the minibatch's advantage statistics applied inside
+the gradient kernel, ``clip_grad_norm_`` + ``Adam.step`` as one launch over a flat parameter buffer
+the module's parameters are views of (``FusedAdam``); with several ranks that flat gradient vector
+is all-reduced once per minibatch.  At 262 144 envs a PPO iteration goes from 49 ms + 1.06 s
+(rollout + update, torch: ~40 memory-bound passes over [8.4 M x 64] activations per minibatch) to
+11 ms + 0.11 s.  ``fused_policy=False, fused_update=False`` select the torch path, which is what
+the kernels are tested against.
 """
 import math
 
@@ -95,7 +97,7 @@ def gae_fused(rewards, values, dones, last_value, gamma, lam, adv_out=None, ret_
 class FusedPolicyStep:
     """``MlpPolicy.act`` as one kernel on the matrix cores (include/roboy_policy.h, csrc/mlp_policy.hip): observation
     -> action sample, log-probability, value, written straight into the rollout buffers.  The parameters stay torch
-    tensors (the optimiser updates them in place); ``pack()`` is one device-side gather into the operand order the
+    tensors (the optimiser - torch's or ``FusedAdam`` - updates them in place); ``pack()`` is one device-side gather into the operand order the
     kernel reads (the gather map depends on the dimensions only and is built once on the host).  Exploration noise is
     the library's Philox stream keyed (seed; sample, step), not torch's generator."""
 
