@@ -15,6 +15,7 @@
 // once at the end.  Each wave writes its partial gradient (torch parameter order); a second kernel sums the waves.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/roboy_policy.h"
@@ -42,6 +43,18 @@ __device__ __forceinline__ f32x16 transpose_tile(const f32x16 &d, float *T, int 
     return o;
 }
 
+// One dword per lane from this lane's global address straight into LDS at (wave-uniform byte address) + 4 * lane: no
+// register destination, so a tile's inputs can be in flight under the previous tile's arithmetic in a kernel that has no
+// registers to spare.  hipcc does not count it: the consumer waits with wait_dma() (vmcnt covers loads in issue order).
+__device__ __forceinline__ void dma_dword(const float *gsrc, const float *lds_dst) {
+    const unsigned at = __builtin_amdgcn_readfirstlane(unsigned(reinterpret_cast<uintptr_t>(lds_dst)));   // LDS aperture: low 32 bits
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(at) : "memory");
+}
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+constexpr int PFS = 65;                                   // row stride of the prefetched inputs: [row][sample], conflict-free both ways
+
 struct TrainArgs {
     const float *packed;                                  // rp_pack_train blob
     const float *obs, *act, *adv, *logp_old, *val_old, *ret;
@@ -56,9 +69,13 @@ struct TrainArgs {
 
 // KX: 32-column tiles of [obs | 1] (obs_dim + 1 <= 32 KX);  NJ: compile-time bound of the outputs (n_out <= NJ,
 // a multiple of 8): the per-sample arrays of the loss derivative are NJ registers each
-template <int NET, int KX, int NJ>
+// PF (KX == 1 only): the tile's rows (observation, action, advantage, old log-probability | old value, return) arrive by
+// LDS-DMA one tile ahead, double-buffered per wave; without it they are loaded when the tile starts (the indexed minibatch
+// of 8 388 608 samples: 4.4 ms against 3.5 contiguous, 29 % of the wave cycles waiting)
+template <int NET, int KX, int NJ, bool PF>
 __global__ void __launch_bounds__(256, 1)
 mlp_grad_kernel(const TrainArgs a) {
+    static_assert(!PF || KX == 1, "the prefetching form is the small instance's");
     constexpr int OT = (NJ + 31) / 32;                     // 32-row tiles of the outputs
     extern __shared__ float4 lds4[];
     float *lds = reinterpret_cast<float *>(lds4);
@@ -84,10 +101,14 @@ mlp_grad_kernel(const TrainArgs a) {
     L.o_l3t[NET] = stage(G.o_l3t[NET], HT * G.k3s[NET] * 64);
     L.o_l2t[NET] = stage(G.o_l2t[NET], HT * HT * 16 * 64);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: the tile arithmetic stays in scalar registers
     const int col = lane & 31, half = lane >> 5;
     constexpr int S3S = NJ + 1;                            // row stride of the delta3 staging (odd)
-    constexpr int XSN = KX == 1 ? 64 * 33 : 0;             // KX == 1: the tile's observations [64 samples][33], staged once
+    // KX == 1: the tile's observations [64 samples][33], staged once - or (PF) two buffers of pf_rows rows of the tile's inputs:
+    // rows [0, obs_dim) observation columns, then NET 0: act_dim action columns, advantage, old log-probability; NET 1: old value, return;
+    const int pf_rows = obs_dim + (NET == 0 ? act_dim + 2 : 2) + 2;   // (+ 2: the next tile's row index, low and high words)
+    const int XSN = PF ? 2 * pf_rows * PFS : (KX == 1 ? 64 * 33 : 0);
     float *T = lds + lds_used + wave * (32 * 33 + 64 * S3S + XSN);   // transpose scratch, the delta3 staging [64][S3S], observations
     float *S3 = T + 32 * 33;
     float *XS = S3 + 64 * S3S;
@@ -98,7 +119,8 @@ mlp_grad_kernel(const TrainArgs a) {
     const int k3s = L.k3s[NET];
 
     // gradient accumulators, alive across the wave's tiles
-    f32x16 G1[HT][KX], G2[HT][HT], G3[OT][HT], db2[HT];
+    f32x16 G1[HT][KX], G2[HT][HT], G3[OT][HT];
+    float db2[HT];                                          // bias 2: this lane's unit (col) of tile o, summed over its half's samples
     float db3[NJ], gls[NJ];
     float acc3[HT][16];                                     // value net: per-lane sums of dW3 (see the forward pass)
 #pragma unroll
@@ -108,7 +130,7 @@ mlp_grad_kernel(const TrainArgs a) {
     float loss_sum = 0.0f;
 #pragma unroll
     for (int o = 0; o < HT; ++o) {
-        db2[o] = zero;
+        db2[o] = 0.0f;
 #pragma unroll
         for (int k = 0; k < KX; ++k) G1[o][k] = zero;
 #pragma unroll
@@ -121,13 +143,68 @@ mlp_grad_kernel(const TrainArgs a) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) { db3[j] = 0.0f; gls[j] = 0.0f; }
 
-    for (long tile = long(blockIdx.x) * nw + wave; tile < n_tiles; tile += long(gridDim.x) * nw) {
+    const long tile0 = long(blockIdx.x) * nw + wave, tstep = long(gridDim.x) * nw;
+    // (PF) this lane's sample of tile t: position in the minibatch and row in the rollout tensors
+    auto pos_of = [&](long t) { const long p = t * 64 + lane; return p < B ? p : B - 1; };
+    auto row_of = [&](long t) { const long p = pos_of(t); return a.index ? long(a.index[p]) : p; };
+    auto prefetch = [&](long t, long row, int buf) {        // tile t's rows (this lane's sample at `row`) + the sample order of the tile after it
+        float *dst = XS + buf * pf_rows * PFS;
+        const float *xr = a.obs + row * obs_dim;
+        for (int k = 0; k < obs_dim; ++k) dma_dword(xr + k, dst + k * PFS);
+        dst += obs_dim * PFS;
+        if (NET == 0) {
+            const float *ar = a.act + row * act_dim;
+            for (int j = 0; j < act_dim; ++j) dma_dword(ar + j, dst + j * PFS);
+            dma_dword(a.adv + (a.adv_stats ? row : pos_of(t)), dst + act_dim * PFS);
+            dma_dword(a.logp_old + row, dst + (act_dim + 1) * PFS);
+            dst += (act_dim + 2) * PFS;
+        } else {
+            dma_dword(a.val_old + row, dst);
+            dma_dword(a.ret + row, dst + PFS);
+            dst += 2 * PFS;
+        }
+        // the next tile's row index travels the same way (two rows: low and high words): an ordinary load in this loop
+        // would have the compiler wait - vmcnt(0) - behind the DMAs wherever it moves the loaded register
+        if (a.index && t + tstep < n_tiles) {
+            const float *ip = reinterpret_cast<const float *>(a.index + pos_of(t + tstep));
+            dma_dword(ip, dst);
+            dma_dword(ip + 1, dst + PFS);
+        }
+    };
+    // the minibatch's advantage statistics, read once (uniform: scalar registers)
+    float adv_mean = 0.0f, adv_istd = 1.0f;
+    if (NET == 0 && a.adv_stats) {
+        adv_mean = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(a.adv_stats[0])));
+        adv_istd = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(a.adv_stats[1])));
+    }
+    int buf = 0;
+    if (PF && tile0 < n_tiles) prefetch(tile0, row_of(tile0), 0);
+    const int lane_id = lane;
+    for (long tile = tile0; tile < n_tiles; tile += tstep, buf ^= 1) {
+        // the lane-derived indices are recomputed per tile from an opaque copy of the lane id: hoisted out of the loop they
+        // are a dozen registers the allocator spills, and a scratch reload waits for every DMA issued before it
+        int lane = lane_id;
+        asm volatile("" : "+v"(lane));
+        const int col = lane & 31, half = lane >> 5;
+        const float onehot = half ? 0.0f : 1.0f;
+        const float *PB = XS + buf * pf_rows * PFS;         // (PF) this tile's inputs
+        if (PF) {
+            wait_dma();                                     // this tile's rows have landed (issued one tile ago)
+            if (tile + tstep < n_tiles) {                   // the next tile's go out now and have this tile's arithmetic to arrive
+                long row_n = pos_of(tile + tstep);
+                if (a.index) {
+                    const unsigned lo = __float_as_uint(PB[(pf_rows - 2) * PFS + lane]), hi = __float_as_uint(PB[(pf_rows - 1) * PFS + lane]);
+                    row_n = long((static_cast<unsigned long long>(hi) << 32) | lo);
+                }
+                prefetch(tile + tstep, row_n, buf ^ 1);
+            }
+        }
         // ================= forward =================
         long s0 = tile * 64 + col, s1 = s0 + 32;
         s0 = s0 < B ? s0 : B - 1; s1 = s1 < B ? s1 : B - 1;
-        if (a.index) { s0 = a.index[s0]; s1 = a.index[s1]; }
+        if (!PF && a.index) { s0 = a.index[s0]; s1 = a.index[s1]; }
         const float *x0 = a.obs + s0 * obs_dim, *x1 = a.obs + s1 * obs_dim;
-        if (KX == 1) {
+        if (KX == 1 && !PF) {
             // the tile's observation rows (gathered when indexed) go to LDS once: lane = sample reads its whole row with
             // all loads in flight together; the K loop of layer 1 and the dW1 operands then come from LDS instead of
             // one dependent global load per step (the indexed minibatch cost 10.4 ms against 7.6 contiguous before)
@@ -152,7 +229,12 @@ mlp_grad_kernel(const TrainArgs a) {
         for (int s = 0; s < L.k1s; ++s) {
             const int k = 2 * s + half;
             float b0, b1;
-            if (KX == 1) { b0 = XS[col * 33 + k]; b1 = XS[(32 + col) * 33 + k]; }
+            if (PF) {
+                const int kk = k < obs_dim ? k : obs_dim - 1;
+                const float v0 = PB[kk * PFS + col], v1 = PB[kk * PFS + 32 + col];
+                const float pad = k == obs_dim ? 1.0f : 0.0f;
+                b0 = k < obs_dim ? v0 : pad; b1 = k < obs_dim ? v1 : pad;
+            } else if (KX == 1) { b0 = XS[col * 33 + k]; b1 = XS[(32 + col) * 33 + k]; }
             else {
                 b0 = k < obs_dim ? x0[k] : (k == obs_dim ? 1.0f : 0.0f);
                 b1 = k < obs_dim ? x1[k] : (k == obs_dim ? 1.0f : 0.0f);
@@ -216,7 +298,7 @@ mlp_grad_kernel(const TrainArgs a) {
         const long i = tile * 64 + lane;
         const bool live = i < B;
         const long im = live ? i : B - 1;                    // position in the minibatch
-        const long ii = a.index ? long(a.index[im]) : im;     // row in the rollout tensors
+        const long ii = PF ? im : (a.index ? long(a.index[im]) : im);     // row in the rollout tensors (PF: the inputs are in PB)
         float d3[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) d3[j] = 0.0f;
@@ -229,12 +311,13 @@ mlp_grad_kernel(const TrainArgs a) {
                 if (j < act_dim) {
                     const float ls = lds[L.o_logstd + j];
                     iv[j] = __expf(-2.0f * ls);
-                    z[j] = a.act[ii * act_dim + j] - out[j];
+                    z[j] = (PF ? PB[(obs_dim + j) * PFS + lane] : a.act[ii * act_dim + j]) - out[j];
                     lp -= 0.5f * z[j] * z[j] * iv[j] + ls;
                 }
             }
-            const float A = a.adv_stats ? (a.adv[ii] - a.adv_stats[0]) * a.adv_stats[1] : a.adv[im];
-            const float ratio = __expf(lp - a.logp_old[ii]);
+            const float araw = PF ? PB[(obs_dim + act_dim) * PFS + lane] : (a.adv_stats ? a.adv[ii] : a.adv[im]);
+            const float A = (araw - adv_mean) * adv_istd;
+            const float ratio = __expf(lp - (PF ? PB[(obs_dim + act_dim + 1) * PFS + lane] : a.logp_old[ii]));
             const float rc = __builtin_amdgcn_fmed3f(ratio, 1.0f - a.cliprange, 1.0f + a.cliprange);
             const float t1 = -A * ratio, t2 = -A * rc;
             const float g = live ? (t1 >= t2 ? -A : 0.0f) * ratio * a.inv_B : 0.0f;      // dL / dlogp
@@ -246,7 +329,7 @@ mlp_grad_kernel(const TrainArgs a) {
                     gls[j] += g * (z[j] * z[j] * iv[j] - 1.0f);
                 }
         } else {
-            const float v = out[0], vo = a.val_old[ii], R = a.ret[ii];
+            const float v = out[0], vo = PF ? PB[obs_dim * PFS + lane] : a.val_old[ii], R = PF ? PB[(obs_dim + 1) * PFS + lane] : a.ret[ii];
             const float dv = v - vo, vc = vo + __builtin_amdgcn_fmed3f(dv, -a.cliprange, a.cliprange);
             const float e1 = (v - R) * (v - R), e2 = (vc - R) * (vc - R);
             const float dvl = e1 >= e2 ? (v - R) : (fabsf(dv) < a.cliprange ? (vc - R) : 0.0f);
@@ -329,12 +412,19 @@ mlp_grad_kernel(const TrainArgs a) {
         }
         // ================= dW2 += delta2 h1^T, db2, dW1 += delta1 [obs | 1]^T =================
 #pragma unroll
-        for (int o = 0; o < HT; ++o) db2[o] += d2[o][0] + d2[o][1];
-#pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x16 h1T[HT], dT[HT];
 #pragma unroll
             for (int m = 0; m < HT; ++m) { h1T[m] = transpose_tile(h1[m][t], T, col, half); dT[m] = transpose_tile(d2[m][t], T, col, half); }
+            // bias 2 from the transposed delta2 (units on the lanes, samples in the registers): one accumulator per row tile
+            // instead of a 16-register tile of per-sample sums
+#pragma unroll
+            for (int m = 0; m < HT; ++m) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += dT[m][r];
+                db2[m] += sum;
+            }
 #pragma unroll
             for (int o = 0; o < HT; ++o)
 #pragma unroll
@@ -347,12 +437,17 @@ mlp_grad_kernel(const TrainArgs a) {
             for (int r = 0; r < 16; ++r) {
                 long sn = tile * 64 + 32 * t + unit_of(r) + 4 * half;          // sample of this K slot
                 sn = sn < B ? sn : B - 1;
-                if (a.index) sn = a.index[sn];
+                if (KX != 1 && a.index) sn = a.index[sn];
 #pragma unroll
                 for (int kx = 0; kx < KX; ++kx) {
                     const int k = 32 * kx + col;
-                    const float xv = KX == 1 ? XS[(32 * t + unit_of(r) + 4 * half) * 33 + col]
-                                             : (k < obs_dim ? a.obs[sn * obs_dim + k] : (k == obs_dim ? 1.0f : 0.0f));
+                    float xv;
+                    if (PF) {
+                        const float v = PB[(col < obs_dim ? col : obs_dim - 1) * PFS + 32 * t + unit_of(r) + 4 * half];
+                        xv = col < obs_dim ? v : (col == obs_dim ? 1.0f : 0.0f);
+                    } else
+                        xv = KX == 1 ? XS[(32 * t + unit_of(r) + 4 * half) * 33 + col]
+                                     : (k < obs_dim ? a.obs[sn * obs_dim + k] : (k == obs_dim ? 1.0f : 0.0f));
 #pragma unroll
                     for (int o = 0; o < HT; ++o) G1[o][kx] = mfma(dT[o][r], xv, G1[o][kx]);
                 }
@@ -378,12 +473,12 @@ mlp_grad_kernel(const TrainArgs a) {
                 if (k < obs_dim) P[g.w1 + row * obs_dim + k] = G1[o][kx][r];
                 else if (k == obs_dim) P[g.b1 + row] = G1[o][kx][r];
             }
-            // bias 2: sum of this register over the 32 lanes of the half-wave (all hold different samples)
-            float v = db2[o][r];
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (col == 0) P[g.b2 + row] = v;
         }
+#pragma unroll
+    for (int o = 0; o < HT; ++o) {                                       // bias 2: unit 32 o + col, the two halves' samples
+        const float v = db2[o] + __shfl_xor(db2[o], 32, 64);
+        if (half == 0) P[g.b2 + 32 * o + col] = v;
+    }
     if (NET == 1) {
 #pragma unroll
         for (int m = 0; m < HT; ++m)
@@ -472,11 +567,13 @@ long grad_blocks(long B) {
 }
 
 // dynamic LDS of one gradient-kernel instance: the staged operand blocks of one net + per-wave scratch
-size_t grad_lds_bytes(const Layout &L, int net, int nj, int kx_inst) {
+// (pf_rows > 0: the prefetching form's two input buffers per wave instead of the observation staging)
+size_t grad_lds_bytes(const Layout &L, int net, int nj, int kx_inst, int pf_rows = 0) {
     const int ot = net == 0 ? L.ot_pi : 1;
     const size_t w = size_t(HT) * L.k1s * 64 + 2 * size_t(HT * HT * 16 * 64) + HT * 64 + size_t(ot) * (HT * 16 * 64 + 64) + 64 +
                      size_t(HT) * L.k3s[net] * 64;
-    return sizeof(float) * (w + WAVES_PER_BLOCK * (32 * 33 + 64 * (nj + 1) + (kx_inst == 1 ? 64 * 33 : 0)));
+    const size_t xs = pf_rows > 0 ? size_t(2) * pf_rows * PFS : (kx_inst == 1 ? 64 * 33 : 0);
+    return sizeof(float) * (w + WAVES_PER_BLOCK * (32 * 33 + 64 * (nj + 1) + xs));
 }
 // the instance pair rp_ppo_grad_dev picks: the reference's robot class (obs <= 31, up to 8 actions) or the general
 // one (obs <= 63, up to 64 actions); false if the general instance of the action net does not fit the 160 KB of LDS
@@ -486,12 +583,12 @@ bool grad_fits(int obs_dim, int act_dim) {
     return grad_lds_bytes(L, 0, small ? 8 : 64, small ? 1 : 2) <= 160 * 1024;
 }
 
-template <int NET, int KX, int NJ>
+template <int NET, int KX, int NJ, bool PF = false>
 int launch_grad(const TrainArgs &a, long blocks, size_t lds, int dev, hipStream_t stream) {
     // the opt-in above 64 KB of dynamic LDS is per kernel AND per device (mlp_common.hpp: grant_lds)
-    constexpr int kernel_id = 1 + NET * 2 + (KX - 1);
-    if (int rc = grant_lds(reinterpret_cast<const void *>(&mlp_grad_kernel<NET, KX, NJ>), kernel_id, dev, lds)) return rc;
-    hipLaunchKernelGGL((mlp_grad_kernel<NET, KX, NJ>), dim3(unsigned(blocks)), dim3(64 * WAVES_PER_BLOCK), lds, stream, a);
+    constexpr int kernel_id = 1 + NET * 2 + (KX - 1) + (PF ? 4 : 0);
+    if (int rc = grant_lds(reinterpret_cast<const void *>(&mlp_grad_kernel<NET, KX, NJ, PF>), kernel_id, dev, lds)) return rc;
+    hipLaunchKernelGGL((mlp_grad_kernel<NET, KX, NJ, PF>), dim3(unsigned(blocks)), dim3(64 * WAVES_PER_BLOCK), lds, stream, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RP_EHIP, std::string("mlp_grad_kernel: ") + hipGetErrorString(e));
     return RP_OK;
@@ -571,7 +668,7 @@ int rp_ppo_grad_dev(const float *d_packed_train, const float *d_obs, const float
     const Layout L = layout_of(obs_dim, act_dim);
     const int gs = gstride_of(obs_dim, act_dim);
     const long blocks = grad_blocks(batch), waves = blocks * WAVES_PER_BLOCK;
-    auto lds_of = [&](int net, int nj, int kx_inst) { return grad_lds_bytes(L, net, nj, kx_inst); };
+    auto lds_of = [&](int net, int nj, int kx_inst, int pf_rows = 0) { return grad_lds_bytes(L, net, nj, kx_inst, pf_rows); };
     hipStream_t st = static_cast<hipStream_t>(stream);
     TrainArgs a;
     a.packed = d_packed_train; a.obs = d_obs; a.act = d_act; a.adv = d_adv; a.adv_stats = d_adv_stats; a.logp_old = d_logp_old; a.val_old = d_val_old;
@@ -580,14 +677,20 @@ int rp_ppo_grad_dev(const float *d_packed_train, const float *d_obs, const float
     const int kx = (obs_dim + 1 + 31) / 32;
     int rc;
     a.partials = d_workspace;
-    // instances: the reference's robot class (obs <= 31, up to 8 actions) and the general one (obs <= 63, 64 actions)
-    // instances: the reference's robot class (obs <= 31, up to 8 actions) and the general one (obs <= 63, 64 actions)
+    // instances: the reference's robot class (obs <= 31, up to 8 actions; its inputs prefetched by LDS-DMA when the two
+    // buffers per wave fit beside the operands - ROBOY_POLICY_PREFETCH=0 keeps the loads at the start of each tile) and the
+    // general one (obs <= 63, 64 actions)
     const bool small = kx == 1 && act_dim <= 8;
-    if (small) rc = launch_grad<0, 1, 8>(a, blocks, lds_of(0, 8, 1), dev, st);
+    static const bool prefetch_off = [] { const char *e = getenv("ROBOY_POLICY_PREFETCH"); return e && e[0] == '0'; }();
+    const int pf0 = obs_dim + act_dim + 4, pf1 = obs_dim + 4;       // rows of one input buffer (mlp_grad_kernel: pf_rows)
+    const bool pf = small && !prefetch_off && lds_of(0, 8, 1, pf0) <= 160 * 1024 && lds_of(1, 8, 1, pf1) <= 160 * 1024;
+    if (pf) rc = launch_grad<0, 1, 8, true>(a, blocks, lds_of(0, 8, 1, pf0), dev, st);
+    else if (small) rc = launch_grad<0, 1, 8>(a, blocks, lds_of(0, 8, 1), dev, st);
     else rc = launch_grad<0, 2, 64>(a, blocks, lds_of(0, 64, 2), dev, st);
     if (rc) return rc;
     a.partials = d_workspace + waves * gs;
-    if (small) rc = launch_grad<1, 1, 8>(a, blocks, lds_of(1, 8, 1), dev, st);
+    if (pf) rc = launch_grad<1, 1, 8, true>(a, blocks, lds_of(1, 8, 1, pf1), dev, st);
+    else if (small) rc = launch_grad<1, 1, 8>(a, blocks, lds_of(1, 8, 1), dev, st);
     else rc = launch_grad<1, 2, 8>(a, blocks, lds_of(1, 8, 2), dev, st);
     if (rc) return rc;
     for (int net = 0; net < 2; ++net) {
