@@ -36,6 +36,7 @@ SIGNATURES = {
     "rp_clip_adam_dev": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_float] * 4 +
                                         [ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
     "rp_debug_lds_grant_needed": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
+    "rp_grad_form": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "rp_act_dev": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
                                   ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
 }

@@ -645,6 +645,18 @@ int rp_gae_dev(const float *d_rew, const float *d_val, const float *d_done, cons
     return RP_OK;
 }
 
+// instances: the reference's robot class (obs <= 31, up to 8 actions; its inputs prefetched by LDS-DMA when the two
+// buffers per wave fit beside the operands - ROBOY_POLICY_PREFETCH=0 keeps the loads at the start of each tile) and the
+// general one (obs <= 63, 64 actions)
+int rp_grad_form(int obs_dim, int act_dim) {
+    if (rp_train_packed_floats(obs_dim, act_dim) < 0) return RP_EUNSUPPORTED;
+    const Layout L = layout_of(obs_dim, act_dim);
+    if (!((obs_dim + 1 + 31) / 32 == 1 && act_dim <= 8)) return 0;
+    static const bool prefetch_off = [] { const char *e = getenv("ROBOY_POLICY_PREFETCH"); return e && e[0] == '0'; }();
+    const bool fits = grad_lds_bytes(L, 0, 8, 1, obs_dim + act_dim + 4) <= 160 * 1024 && grad_lds_bytes(L, 1, 8, 1, obs_dim + 4) <= 160 * 1024;
+    return !prefetch_off && fits ? 2 : 1;
+}
+
 int64_t rp_grad_floats(int obs_dim, int act_dim) {
     if (rp_train_packed_floats(obs_dim, act_dim) < 0) return RP_EUNSUPPORTED;
     return 2 * int64_t(gstride_of(obs_dim, act_dim));
@@ -677,13 +689,9 @@ int rp_ppo_grad_dev(const float *d_packed_train, const float *d_obs, const float
     const int kx = (obs_dim + 1 + 31) / 32;
     int rc;
     a.partials = d_workspace;
-    // instances: the reference's robot class (obs <= 31, up to 8 actions; its inputs prefetched by LDS-DMA when the two
-    // buffers per wave fit beside the operands - ROBOY_POLICY_PREFETCH=0 keeps the loads at the start of each tile) and the
-    // general one (obs <= 63, 64 actions)
-    const bool small = kx == 1 && act_dim <= 8;
-    static const bool prefetch_off = [] { const char *e = getenv("ROBOY_POLICY_PREFETCH"); return e && e[0] == '0'; }();
-    const int pf0 = obs_dim + act_dim + 4, pf1 = obs_dim + 4;       // rows of one input buffer (mlp_grad_kernel: pf_rows)
-    const bool pf = small && !prefetch_off && lds_of(0, 8, 1, pf0) <= 160 * 1024 && lds_of(1, 8, 1, pf1) <= 160 * 1024;
+    const int form = rp_grad_form(obs_dim, act_dim);                     // 2: small + prefetch, 1: small, 0: general
+    const bool small = form >= 1, pf = form == 2;
+    const int pf0 = obs_dim + act_dim + 4, pf1 = obs_dim + 4;           // rows of one input buffer (mlp_grad_kernel: pf_rows)
     if (pf) rc = launch_grad<0, 1, 8, true>(a, blocks, lds_of(0, 8, 1, pf0), dev, st);
     else if (small) rc = launch_grad<0, 1, 8>(a, blocks, lds_of(0, 8, 1), dev, st);
     else rc = launch_grad<0, 2, 64>(a, blocks, lds_of(0, 64, 2), dev, st);

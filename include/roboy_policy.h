@@ -114,6 +114,10 @@ int rp_clip_adam_dev(float *d_params, const float *d_grad, float *d_m, float *d_
                      void *stream);
 /* test hook: would a grant of lds_bytes of dynamic LDS be issued for (kernel id, device) now?  Records it. */
 int rp_debug_lds_grant_needed(int kernel_id, int dev, int64_t lds_bytes);
+/* which form of the gradient kernels rp_ppo_grad_dev launches for this policy: 2 = the small instance (obs_dim <= 31, up to 8
+ * actions) with its inputs prefetched by LDS-DMA, 1 = the small instance loading at the start of each tile (the two input
+ * buffers per wave do not fit beside the operands, or ROBOY_POLICY_PREFETCH=0), 0 = the general instance; < 0: unsupported */
+int rp_grad_form(int obs_dim, int act_dim);
 
 #ifdef __cplusplus
 }
