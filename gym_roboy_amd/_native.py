@@ -62,6 +62,7 @@ SIGNATURES = {
     "rb_info": (ctypes.c_int, [_sim, ctypes.POINTER(SimInfo)]),
     "rb_select_kernel": (ctypes.c_int, [_sim, ctypes.c_int]),
     "rb_specialization": (ctypes.c_int, [_sim]),
+    "rb_jit_cache_stats": (None, [ctypes.POINTER(ctypes.c_int64)] * 3),
     "rb_set_stream": (ctypes.c_int, [_sim, _vp]),
     "rb_synchronize": (ctypes.c_int, [_sim]),
     "rb_reset": (ctypes.c_int, [_sim, _u8p]),

@@ -11,8 +11,14 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -96,18 +102,115 @@ inline bool enabled() {
     return !(e && e[0] == '0');
 }
 
+// ---- code-object cache: a robot's specialised kernels are compiled once per (source text, library build, device arch) ----
+// The generated joint-tree source of a 20-joint robot takes hiprtc 10-80 s; the code object (a few hundred KB) is kept under
+// ROBOY_SIM_JIT_CACHE (default $XDG_CACHE_HOME/gym_roboy_amd or ~/.cache/gym_roboy_amd; "0" switches the cache off) as
+// <key>.rbjc = magic, the lowered kernel names, the code.  The key covers everything that decides the code: the source text
+// (robot constants included), the options, the architecture, and this library's file size + modification time (the kernel
+// headers the source includes travel with the library and change only when it is rebuilt).  Written to a temporary name
+// and renamed, so concurrent ranks never see half a file; anything unreadable or inconsistent is ignored and rebuilt.
+struct CacheStats { std::atomic<long long> hits{0}, compiles{0}, stores{0}; };
+inline CacheStats &cache_stats() { static CacheStats s; return s; }
+
+inline std::string cache_dir() {
+    const char *e = std::getenv("ROBOY_SIM_JIT_CACHE");
+    std::string d;
+    if (e) {
+        if (!e[0] || (e[0] == '0' && !e[1])) return "";
+        d = e;
+    } else {
+        const char *x = std::getenv("XDG_CACHE_HOME"), *h = std::getenv("HOME");
+        if (x && x[0]) d = std::string(x) + "/gym_roboy_amd";
+        else if (h && h[0]) { (void)mkdir((std::string(h) + "/.cache").c_str(), 0777); d = std::string(h) + "/.cache/gym_roboy_amd"; }
+        else return "";
+    }
+    (void)mkdir(d.c_str(), 0777);
+    struct stat st;
+    return stat(d.c_str(), &st) == 0 && S_ISDIR(st.st_mode) ? d : "";
+}
+
+inline uint64_t fnv1a64(const void *data, size_t n, uint64_t h = 1469598103934665603ull) {
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    for (size_t k = 0; k < n; ++k) { h ^= p[k]; h *= 1099511628211ull; }
+    return h;
+}
+
+inline std::string cache_key(const std::string &src, const std::string &arch, const char *const *names, int nk) {
+    uint64_t h = fnv1a64(src.data(), src.size());
+    h = fnv1a64(arch.data(), arch.size(), h);
+    for (int k = 0; k < nk; ++k) h = fnv1a64(names[k], std::strlen(names[k]) + 1, h);
+    Dl_info info;
+    struct stat st;
+    if (dladdr(reinterpret_cast<const void *>(&cache_dir), &info) && info.dli_fname && stat(info.dli_fname, &st) == 0) {
+        const long long stamp[3] = {static_cast<long long>(st.st_size), static_cast<long long>(st.st_mtim.tv_sec), static_cast<long long>(st.st_mtim.tv_nsec)};
+        h = fnv1a64(stamp, sizeof stamp, h);
+    }
+    char buf[40];
+    std::snprintf(buf, sizeof buf, "%016llx-%zu", static_cast<unsigned long long>(h), src.size());
+    return buf;
+}
+
+constexpr char CACHE_MAGIC[8] = {'R', 'B', 'J', 'C', '0', '0', '1', '\n'};
+
+inline bool cache_load(const std::string &path, int nk, std::vector<std::string> &lowered, std::string &code) {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    bool ok = false;
+    char magic[8];
+    uint64_t n_names = 0, n_code = 0;
+    if (std::fread(magic, 1, 8, f) == 8 && !std::memcmp(magic, CACHE_MAGIC, 8) && std::fread(&n_names, 8, 1, f) == 1 && n_names == uint64_t(nk)) {
+        ok = true;
+        lowered.assign(nk, "");
+        for (int k = 0; k < nk && ok; ++k) {
+            uint64_t len = 0;
+            ok = std::fread(&len, 8, 1, f) == 1 && len > 0 && len < 4096;
+            if (ok) { lowered[k].resize(len); ok = std::fread(&lowered[k][0], 1, len, f) == len; }
+        }
+        ok = ok && std::fread(&n_code, 8, 1, f) == 1 && n_code > 0 && n_code < (1ull << 30);
+        if (ok) {
+            code.resize(n_code);
+            uint64_t sum = 0;
+            ok = std::fread(&code[0], 1, n_code, f) == n_code && std::fread(&sum, 8, 1, f) == 1 && sum == fnv1a64(code.data(), code.size());
+        }
+    }
+    std::fclose(f);
+    return ok;
+}
+
+inline void cache_store(const std::string &path, const std::vector<std::string> &lowered, const std::string &code) {
+    const std::string tmp = path + ".tmp." + std::to_string(static_cast<long long>(getpid()));
+    FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const uint64_t n_names = lowered.size(), n_code = code.size(), sum = fnv1a64(code.data(), code.size());
+    bool ok = std::fwrite(CACHE_MAGIC, 1, 8, f) == 8 && std::fwrite(&n_names, 8, 1, f) == 1;
+    for (const std::string &l : lowered) {
+        const uint64_t len = l.size();
+        ok = ok && std::fwrite(&len, 8, 1, f) == 1 && std::fwrite(l.data(), 1, len, f) == len;
+    }
+    ok = ok && std::fwrite(&n_code, 8, 1, f) == 1 && std::fwrite(code.data(), 1, n_code, f) == n_code && std::fwrite(&sum, 8, 1, f) == 1;
+    ok = (std::fclose(f) == 0) && ok;
+    if (ok && std::rename(tmp.c_str(), path.c_str()) == 0) cache_stats().stores++;
+    else (void)std::remove(tmp.c_str());
+}
+
+inline bool load_code(const std::string &code, const std::vector<std::string> &lowered, int nk, hipModule_t &mod, hipFunction_t **slots, std::string &why) {
+    if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { why = "hipModuleLoadData failed"; mod = nullptr; return false; }
+    for (int k = 0; k < nk; ++k)
+        if (hipModuleGetFunction(slots[k], mod, lowered[k].c_str()) != hipSuccess) {
+            why = "hipModuleGetFunction failed for " + lowered[k];
+            (void)hipModuleUnload(mod);
+            mod = nullptr;
+            return false;
+        }
+    return true;
+}
+
 // Compile `src` with hiprtc for the current device, load the code object and look up the kernels `names`
 // (C++ name expressions, e.g. template instances); false (with a message) if anything along the way is not
 // available.  A failed compilation also prints the head of the hiprtc log to stderr, once per process: a lost
 // specialisation must not go unnoticed in a bench run.
 inline bool compile_and_load(const std::string &src, const char *file_name, const char *const *names, int nk,
                              hipModule_t &mod, hipFunction_t **slots, std::string &why) {
-    const Rtc &r = rtc();
-    if (!r.ok) { why = "hiprtc is not available"; return false; }
-    hiprtcProgram prog = nullptr;
-    if (r.create(&prog, src.c_str(), file_name, 0, nullptr, nullptr) != HIPRTC_SUCCESS) { why = "hiprtcCreateProgram failed"; return false; }
-    for (int k = 0; k < nk; ++k) r.add_name(prog, names[k]);
-    const std::string inc = "-I" + library_dir();
     int dev = 0;
     hipDeviceProp_t prop;
     std::string arch = "--offload-arch=gfx950";
@@ -115,6 +218,20 @@ inline bool compile_and_load(const std::string &src, const char *file_name, cons
         std::string a = prop.gcnArchName;                 // "gfx950:sramecc+:xnack-"
         arch = "--offload-arch=" + a.substr(0, a.find(':'));
     }
+    const std::string dir = cache_dir();
+    const std::string cached = dir.empty() ? "" : dir + "/" + cache_key(src, arch, names, nk) + ".rbjc";
+    if (!cached.empty()) {
+        std::vector<std::string> lowered;
+        std::string code;
+        if (cache_load(cached, nk, lowered, code) && load_code(code, lowered, nk, mod, slots, why)) { cache_stats().hits++; return true; }
+    }
+    const Rtc &r = rtc();
+    if (!r.ok) { why = "hiprtc is not available"; return false; }
+    hiprtcProgram prog = nullptr;
+    if (r.create(&prog, src.c_str(), file_name, 0, nullptr, nullptr) != HIPRTC_SUCCESS) { why = "hiprtcCreateProgram failed"; return false; }
+    for (int k = 0; k < nk; ++k) r.add_name(prog, names[k]);
+    const std::string inc = "-I" + library_dir();
+    cache_stats().compiles++;
     const char *opts[] = {arch.c_str(), "-O3", "-std=c++17", "-fno-slp-vectorize", inc.c_str()};
     const hiprtcResult rc = r.compile(prog, 5, opts);
     if (rc != HIPRTC_SUCCESS) {
@@ -139,14 +256,8 @@ inline bool compile_and_load(const std::string &src, const char *file_name, cons
         lowered[k] = low;
     }
     r.destroy(&prog);
-    if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { why = "hipModuleLoadData failed"; mod = nullptr; return false; }
-    for (int k = 0; k < nk; ++k)
-        if (hipModuleGetFunction(slots[k], mod, lowered[k].c_str()) != hipSuccess) {
-            why = "hipModuleGetFunction failed for " + lowered[k];
-            (void)hipModuleUnload(mod);
-            mod = nullptr;
-            return false;
-        }
+    if (!load_code(code, lowered, nk, mod, slots, why)) return false;
+    if (!cached.empty()) cache_store(cached, lowered, code);
     return true;
 }
 

@@ -827,6 +827,13 @@ int rb_debug_tree_fetch(rb_sim *s, float *out, int n_floats, rbt::TreeDev *dev_o
 }
 #endif
 
+void rb_jit_cache_stats(int64_t *hits, int64_t *compiles, int64_t *stores) {
+    rbj::CacheStats &c = rbj::cache_stats();
+    if (hits) *hits = c.hits.load();
+    if (compiles) *compiles = c.compiles.load();
+    if (stores) *stores = c.stores.load();
+}
+
 int rb_specialization(rb_sim *s) {
     if (check(s)) return -1;
     if (s->tree) {

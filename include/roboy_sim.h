@@ -149,6 +149,11 @@ int rb_select_kernel(rb_sim *sim, int kernel);
  * the specialised ones run ~6 % faster.  Returns -1 for a null handle; after RB_SPEC_NONE rb_last_error() says why. */
 enum { RB_SPEC_NONE = 0, RB_SPEC_TABLE = 1, RB_SPEC_JIT = 2 };
 int rb_specialization(rb_sim *sim);
+/* The code objects hiprtc builds are kept on disk (ROBOY_SIM_JIT_CACHE = a directory; default $XDG_CACHE_HOME/gym_roboy_amd or
+ * ~/.cache/gym_roboy_amd; "0" = no cache), keyed by source text (robot constants included), architecture and library build:
+ * a second process on the same robot loads in milliseconds what took hiprtc 1-80 s.  Process-wide counts since load:
+ * hits = builds served from the cache, compiles = hiprtc compilations, stores = files written.  Any pointer may be NULL. */
+void rb_jit_cache_stats(int64_t *hits, int64_t *compiles, int64_t *stores);
 /* The stream every launch, copy and synchronisation of this handle uses.  NULL = the
  * handle's own (non-blocking) stream; RB_STREAM_DEVICE_DEFAULT = the device's default
  * (null) stream, which is what a framework's "current stream" is unless the caller made

@@ -112,6 +112,54 @@ def test_random_tree_robot_split_form_matches_oracle(seed):
     sim.close()
 
 
+def _cache_stats():
+    import ctypes
+    from gym_roboy_amd import _native
+    v = [ctypes.c_int64(0) for _ in range(3)]
+    _native.load().rb_jit_cache_stats(*[ctypes.byref(x) for x in v])
+    return tuple(x.value for x in v)                           # hits, compiles, stores
+
+
+def test_hiprtc_code_objects_are_cached_on_disk_and_a_damaged_file_is_rebuilt(tmp_path, monkeypatch):
+    """ROBOY_SIM_JIT_CACHE: the first handle compiles and stores, the second loads the stored code object (same results bit
+    for bit), a truncated file is ignored and replaced, and "0" switches the cache off."""
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    monkeypatch.setenv("ROBOY_SIM_JIT_CACHE", str(tmp_path))
+    robot, desc = random_tree_robot(3)
+    n = 70
+    q, qd, sp = random_states(desc, n, 3)
+
+    def run():
+        sim = HipBatchSimulation(robot, n)
+        sim.select_kernel(1)
+        assert sim.specialization() == "jit"
+        sim.set_state(q, qd)
+        out = sim.forward_step_command(sp)
+        sim.close()
+        return out
+
+    h0, c0, s0 = _cache_stats()
+    first = run()
+    h1, c1, s1 = _cache_stats()
+    files = sorted(tmp_path.glob("*.rbjc"))
+    assert (h1 - h0, c1 - c0, s1 - s0) == (0, 1, 1) and len(files) == 1 and files[0].stat().st_size > 10000
+    second = run()
+    h2, c2, s2 = _cache_stats()
+    assert (h2 - h1, c2 - c1, s2 - s1) == (1, 0, 0)
+    assert all(np.array_equal(a, b) for a, b in zip(first, second))
+    data = files[0].read_bytes()
+    files[0].write_bytes(data[:len(data) // 2])                 # a half-written or damaged file: ignored, rebuilt, replaced
+    third = run()
+    h3, c3, s3 = _cache_stats()
+    assert (h3 - h2, c3 - c2, s3 - s2) == (0, 1, 1) and files[0].read_bytes() == data
+    assert all(np.array_equal(a, b) for a, b in zip(first, third))
+    monkeypatch.setenv("ROBOY_SIM_JIT_CACHE", "0")
+    run()
+    h4, c4, s4 = _cache_stats()
+    assert (h4 - h3, c4 - c3, s4 - s3) == (0, 1, 0)
+    assert not list(tmp_path.glob("*.tmp.*"))
+
+
 def test_split_form_is_refused_where_the_tree_has_no_parts():
     from gym_roboy_amd.envs.simulations import HipBatchSimulation
     robot, _ = random_tree_robot(41, n_q=6, n_t=3, shape="chain")
