@@ -78,10 +78,22 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #ifndef RB_BIG_UNROLL_RK4
 #define RB_BIG_UNROLL_RK4 2
 #endif
-// kernels instantiated on MsjRobot's baked constant table (msj_baked.hpp) unroll the tendon loop by this much
-// (U = 2 / 4 / 8: RK4 16.96 / 16.63 / 16.77 us, Euler 2M 36.9 / 35.2 / 35.3 us)
-#ifndef RB_BAKED_UNROLL
-#define RB_BAKED_UNROLL 4
+// kernels instantiated on MsjRobot's baked constant table (msj_baked.hpp) unroll the tendon loop by this much, per integrator
+// (round 2, U = 2 / 4 / 8: RK4 16.96 / 16.63 / 16.77 us, Euler 2M 36.9 / 35.2 / 35.3 us; round 3, U = 4 / 8: RK4 262 144 envs
+// 16.58 / 16.92 us and 2 M envs 97.8 / 110.9 us, Euler 262 144 envs 7.01 / 6.88 us and 2 M envs 35.29 / 34.63 us - fully
+// unrolled, the robot's constants are literals instead of scalar-register operands, which issue at half rate (profiles/r3_a:
+// issue_forms_probe.log); RK4 pays more for the registers of the longer body than it gains)
+#ifndef RB_BAKED_UNROLL_EULER
+#define RB_BAKED_UNROLL_EULER 8
+#endif
+#ifndef RB_BAKED_UNROLL_RK4
+#define RB_BAKED_UNROLL_RK4 4
+#endif
+// (the fused open-loop rollout keeps its state in registers across steps and loses more to the registers of the unrolled
+// body than it gains: 2 M envs Euler 8.6e10 env-steps/s at U = 4, 7.4e10 at U = 8; the unroll factor does not change the
+// arithmetic, so its results stay bit-identical to single steps - tests/test_physics_gpu.py)
+#ifndef RB_BAKED_UNROLL_ROLLOUT_EULER
+#define RB_BAKED_UNROLL_ROLLOUT_EULER 4
 #endif
 // joint-tree robots without ahead-of-time instances: AUTO builds the env-per-lane kernels with hiprtc (~10 s each)
 // from this many envs on (ROBOY_SIM_JIT=2: at any batch size, =0: never); below it the octet kernels run
@@ -583,8 +595,8 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale) {
         if (s->baked) { if (s->integrator == RB_EULER) RB_STEP_LAUNCH_BK(0, 64, 8); else RB_STEP_LAUNCH_BK(1, 64, 8); }
         else          { if (s->integrator == RB_EULER) RB_STEP_LAUNCH(0, 64, 8); else RB_STEP_LAUNCH(1, 64, 8); }
     } else if (s->baked) {
-        if (s->integrator == RB_EULER) RB_STEP_LAUNCH_BK(0, RB_BIG_BLOCK_EULER, RB_BAKED_UNROLL);
-        else RB_STEP_LAUNCH_BK(1, RB_BIG_BLOCK_RK4, RB_BAKED_UNROLL);
+        if (s->integrator == RB_EULER) RB_STEP_LAUNCH_BK(0, RB_BIG_BLOCK_EULER, RB_BAKED_UNROLL_EULER);
+        else RB_STEP_LAUNCH_BK(1, RB_BIG_BLOCK_RK4, RB_BAKED_UNROLL_RK4);
     } else if (s->jit_state == 1) {
         // msj_step_env_per_lane<INTEG, 256, 4, true> of this robot's own module; same parameter list
         Const8 c8 = s->c8;
@@ -1076,7 +1088,7 @@ int rb_rollout_fused_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, 
     } else
     if (s->baked) {
         if (n <= RB_SMALL_BATCH) { if (euler) RB_FUSED_LAUNCH_BK(0, 64, 8); else RB_FUSED_LAUNCH_BK(1, 64, 8); }
-        else                     { if (euler) RB_FUSED_LAUNCH_BK(0, RB_BIG_BLOCK_EULER, RB_BAKED_UNROLL); else RB_FUSED_LAUNCH_BK(1, RB_BIG_BLOCK_RK4, RB_BAKED_UNROLL); }
+        else                     { if (euler) RB_FUSED_LAUNCH_BK(0, RB_BIG_BLOCK_EULER, RB_BAKED_UNROLL_ROLLOUT_EULER); else RB_FUSED_LAUNCH_BK(1, RB_BIG_BLOCK_RK4, RB_BAKED_UNROLL_RK4); }
     } else
     if (n <= RB_SMALL_BATCH) { if (euler) RB_FUSED_LAUNCH(0, 64, 8); else RB_FUSED_LAUNCH(1, 64, 8); }
     else                     { if (euler) RB_FUSED_LAUNCH(0, RB_BIG_BLOCK_EULER, RB_BIG_UNROLL_EULER); else RB_FUSED_LAUNCH(1, RB_BIG_BLOCK_RK4, RB_BIG_UNROLL_RK4); }
@@ -1279,7 +1291,7 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
     } else
     if (s->baked) {
         if (n <= RB_SMALL_BATCH) { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_BK(0, 64, 8); else RB_ENV_LAUNCH_BK(1, 64, 8); }
-        else                     { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_BK(0, RB_BIG_BLOCK_EULER, RB_BAKED_UNROLL); else RB_ENV_LAUNCH_BK(1, RB_BIG_BLOCK_RK4, RB_BAKED_UNROLL); }
+        else                     { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_BK(0, RB_BIG_BLOCK_EULER, RB_BAKED_UNROLL_EULER); else RB_ENV_LAUNCH_BK(1, RB_BIG_BLOCK_RK4, RB_BAKED_UNROLL_RK4); }
     } else
     if (s->ntx) {
         if (n <= RB_SMALL_BATCH) { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_NT(0, 64); else RB_ENV_LAUNCH_NT(1, 64); }
