@@ -7,11 +7,12 @@
 
 #include "tree_lane_gen.hpp"
 
+// lds_c: bit 0 - park the velocity-product accelerations in LDS; bit 1 - do NOT write structurally identical subtrees as pair values
 extern "C" int rb_gen_tree_lane(const rb_robot_desc *d, int lds_c, const char *path, int *lds_slots, int *n_stmt,
                                 unsigned long long *hash, int *flops, int *max_live) {
     rblg::Generated g;
     std::string err;
-    const int rc = rblg::generate(d, lds_c != 0, g, err);
+    const int rc = rblg::generate(d, (lds_c & 1) != 0, g, err, (lds_c & 2) == 0);
     if (rc) { std::fprintf(stderr, "rb_gen_tree_lane: %s\n", err.c_str()); return rc; }
     FILE *f = std::fopen(path, "w");
     if (!f) return RB_EINVAL;
@@ -24,6 +25,18 @@ extern "C" int rb_gen_tree_lane(const rb_robot_desc *d, int lds_c, const char *p
     if (hash) *hash = g.hash;
     if (flops) *flops = g.flops;
     if (max_live) *max_live = g.max_live;
+    return RB_OK;
+}
+
+// mates of the links and tendons (-1: none, -2: is some link's / tendon's mate), as generate() pairs them
+extern "C" int rb_gen_tree_lane_mates(const rb_robot_desc *d, int *mate, int *tmate) {
+    rblg::Robot rob;
+    std::string err;
+    if (int rc = rblg::build_robot(d, rob, err)) return rc;
+    std::vector<int> m, tm;
+    rblg::find_mates(rob, m, tm);
+    for (int i = 0; i < rob.nq; ++i) mate[i] = m[i];
+    for (int k = 0; k < rob.nt; ++k) tmate[k] = tm[k];
     return RB_OK;
 }
 

@@ -89,12 +89,9 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #ifndef RB_BAKED_UNROLL_RK4
 #define RB_BAKED_UNROLL_RK4 4
 #endif
-// (the fused open-loop rollout keeps its state in registers across steps and loses more to the registers of the unrolled
-// body than it gains: 2 M envs Euler 8.6e10 env-steps/s at U = 4, 7.4e10 at U = 8; the unroll factor does not change the
-// arithmetic, so its results stay bit-identical to single steps - tests/test_physics_gpu.py)
-#ifndef RB_BAKED_UNROLL_ROLLOUT_EULER
-#define RB_BAKED_UNROLL_ROLLOUT_EULER 4
-#endif
+// (the fused open-loop rollout is instantiated with the SAME unroll factor as the step kernel - its results are bit-identical to
+// single steps only then: the fully unrolled body contracts its products differently - although it loses to it: it keeps its
+// state in registers across steps, 2 M envs Euler 8.6e10 env-steps/s at U = 4, 7.4e10 at U = 8)
 // joint-tree robots without ahead-of-time instances: AUTO builds the env-per-lane kernels with hiprtc (~10 s each)
 // from this many envs on (ROBOY_SIM_JIT=2: at any batch size, =0: never); below it the octet kernels run
 #ifndef RB_TREE_JIT_BATCH
@@ -1088,7 +1085,7 @@ int rb_rollout_fused_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, 
     } else
     if (s->baked) {
         if (n <= RB_SMALL_BATCH) { if (euler) RB_FUSED_LAUNCH_BK(0, 64, 8); else RB_FUSED_LAUNCH_BK(1, 64, 8); }
-        else                     { if (euler) RB_FUSED_LAUNCH_BK(0, RB_BIG_BLOCK_EULER, RB_BAKED_UNROLL_ROLLOUT_EULER); else RB_FUSED_LAUNCH_BK(1, RB_BIG_BLOCK_RK4, RB_BAKED_UNROLL_RK4); }
+        else                     { if (euler) RB_FUSED_LAUNCH_BK(0, RB_BIG_BLOCK_EULER, RB_BAKED_UNROLL_EULER); else RB_FUSED_LAUNCH_BK(1, RB_BIG_BLOCK_RK4, RB_BAKED_UNROLL_RK4); }
     } else
     if (n <= RB_SMALL_BATCH) { if (euler) RB_FUSED_LAUNCH(0, 64, 8); else RB_FUSED_LAUNCH(1, 64, 8); }
     else                     { if (euler) RB_FUSED_LAUNCH(0, RB_BIG_BLOCK_EULER, RB_BIG_UNROLL_EULER); else RB_FUSED_LAUNCH(1, RB_BIG_BLOCK_RK4, RB_BIG_UNROLL_RK4); }

@@ -20,3 +20,20 @@ RBL_FN float rbl_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 RBL_FN float rbl_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 RBL_FN float rbl_med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 RBL_FN float rbl_max(float a, float b) { return fmaxf(a, b); }
+
+// Pair values (tree_lane_gen.hpp: Val::pair - a subtree and its structurally identical mate, e.g. the two arms, written
+// as ONE instruction stream): arithmetic on rbl_f2 becomes v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, a plain float
+// operand is broadcast through op_sel (no move); the transcendentals and min / max have no packed form and run per half.
+typedef float rbl_f2 __attribute__((ext_vector_type(2)));
+#define RBL_K2(a, b) (rbl_f2{a, b})
+#define RBL_MK2(a, b) (rbl_f2{a, b})
+RBL_FN float rbl_lo(rbl_f2 v) { return v.x; }
+RBL_FN float rbl_hi(rbl_f2 v) { return v.y; }
+RBL_FN float rbl_hsum(rbl_f2 v) { return v.x + v.y; }
+RBL_FN rbl_f2 rbl_sin(rbl_f2 v) { return rbl_f2{rbl_sin(v.x), rbl_sin(v.y)}; }
+RBL_FN rbl_f2 rbl_cos(rbl_f2 v) { return rbl_f2{rbl_cos(v.x), rbl_cos(v.y)}; }
+RBL_FN rbl_f2 rbl_rsq(rbl_f2 v) { return rbl_f2{rbl_rsq(v.x), rbl_rsq(v.y)}; }
+RBL_FN rbl_f2 rbl_rcp(rbl_f2 v) { return rbl_f2{rbl_rcp(v.x), rbl_rcp(v.y)}; }
+RBL_FN rbl_f2 rbl_exp2(rbl_f2 v) { return rbl_f2{rbl_exp2(v.x), rbl_exp2(v.y)}; }
+RBL_FN rbl_f2 rbl_med3(rbl_f2 v, float lo, float hi) { return rbl_f2{rbl_med3(v.x, lo, hi), rbl_med3(v.y, lo, hi)}; }
+RBL_FN rbl_f2 rbl_max(rbl_f2 a, float b) { return rbl_f2{rbl_max(a.x, b), rbl_max(a.y, b)}; }

@@ -28,6 +28,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -40,9 +41,14 @@ namespace rblg {
 
 struct Val {
     bool k = true;       // a compile-time constant (c) / a named value (name, possibly negated)
-    double c = 0.0;
+    double c = 0.0, c1 = 0.0;   // (c1: the constant of the MATE - see `pair`; = c for a plain constant)
     std::string name;
     bool neg = false;
+    // A value of two structurally identical subtrees at once (generate(): the two arms of a humanoid): a constant whose two
+    // floats differ, or a temporary of type rbl_f2 (lane x = the subtree with the lower indices, y = its mate).  hipcc turns
+    // rbl_f2 arithmetic into v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two links or tendons per issue slot - and a SIMD's
+    // only wave pays per instruction, not per flop (profiles/r3_a: issue_forms_probe).
+    bool pair = false;
 };
 
 using V3 = std::array<Val, 3>;
@@ -69,8 +75,9 @@ class Gen {
     std::vector<Stmt> stmts;
     int n_tmp = 0, n_lds = 0;
 
-    static Val K(double c) { Val v; v.k = true; v.c = c; return v; }
-    static Val named(const std::string &n) { Val v; v.k = false; v.name = n; return v; }
+    static Val K(double c) { Val v; v.k = true; v.c = c; v.c1 = c; return v; }
+    static Val K2(double c0, double c1) { Val v; v.k = true; v.c = c0; v.c1 = c1; v.pair = float(c0) != float(c1); return v; }
+    static Val named(const std::string &n, bool pair = false) { Val v; v.k = false; v.name = n; v.pair = pair; return v; }
     static std::string lit(double c) {
         char buf[64];
         const float f = float(c);
@@ -78,20 +85,35 @@ class Gen {
         std::snprintf(buf, sizeof buf, "%af", double(f < 0 ? -f : f));
         return std::string(f < 0 ? "-" : "") + buf;
     }
-    static bool is0(const Val &v) { return v.k && float(v.c) == 0.0f; }
-    static bool is1(const Val &v) { return v.k && v.c == 1.0; }
-    static bool ism1(const Val &v) { return v.k && v.c == -1.0; }
+    static bool is0(const Val &v) { return v.k && !v.pair && float(v.c) == 0.0f; }
+    static bool is1(const Val &v) { return v.k && !v.pair && v.c == 1.0; }
+    static bool ism1(const Val &v) { return v.k && !v.pair && v.c == -1.0; }
     // operand text
     static std::string S(const Val &v) {
+        if (v.k && v.pair) return "RBL_K2(" + lit(v.c) + ", " + lit(v.c1) + ")";
         if (v.k) { const std::string l = lit(v.c); return l[0] == '-' ? "(" + l + ")" : l; }
         return v.neg ? "(-" + v.name + ")" : v.name;
     }
-    Val emit(const std::string &expr) {
+    Val emit(const std::string &expr, bool pair = false) {
         const std::string n = "t" + std::to_string(n_tmp++);
-        stmts.push_back({n, "    const float " + n + " = " + expr + ";\n"});
-        return named(n);
+        stmts.push_back({n, std::string("    const ") + (pair ? "rbl_f2 " : "float ") + n + " = " + expr + ";\n"});
+        return named(n, pair);
     }
     void store(const std::string &lhs, const Val &v) { stmts.push_back({"", "    " + lhs + " = " + S(v) + ";\n"}); }
+    // a value of a subtree and its mate to two places
+    void store2(const std::string &lo, const std::string &hi, const Val &v) {
+        if (!v.pair) { store(lo, v); store(hi, v); return; }
+        stmts.push_back({"", "    " + lo + " = rbl_lo(" + S(v) + ");\n"});
+        stmts.push_back({"", "    " + hi + " = rbl_hi(" + S(v) + ");\n"});
+    }
+    // the sum over a subtree and its mate of a value that stands for both
+    Val hsum(const Val &v) {
+        if (v.k) return K(v.c + v.c1);
+        if (!v.pair) return mul(v, K(2.0));
+        Val r = emit("rbl_hsum(" + v.name + ")");
+        r.neg = v.neg;
+        return r;
+    }
     void comment(const std::string &s) { stmts.push_back({"//", "    // " + s + "\n"}); }
     // the instruction scheduler must not move work across this point: the text is written in an order that keeps
     // few values alive (a link's frame dies as soon as its children and tendons are done), and the kernel has no
@@ -135,13 +157,18 @@ class Gen {
                 names_in(stmts[k].text, ns);
                 for (const std::string &n : ns) last_use[n] = k;
             }
+            // (a pair temporary occupies two registers)
+            auto is_pair = [&](size_t k) { return stmts[k].text.compare(0, 17, "    const rbl_f2 ") == 0; };
+            std::map<std::string, int> weight;
+            for (size_t k = 0; k < stmts.size(); ++k)
+                if (keep[k] && !stmts[k].target.empty() && stmts[k].target != "//") weight[stmts[k].target] = is_pair(k) ? 2 : 1;
             std::vector<int> dies(stmts.size() + 1, 0);
-            for (const auto &kv : last_use) ++dies[kv.second];
+            for (const auto &kv : last_use) { const auto w = weight.find(kv.first); if (w != weight.end()) dies[kv.second] += w->second; }
             int live = 0;
             max_live = 0;
             for (size_t k = 0; k < stmts.size(); ++k) {
                 if (!keep[k] || stmts[k].target == "//") continue;
-                if (!stmts[k].target.empty()) ++live;
+                if (!stmts[k].target.empty()) live += is_pair(k) ? 2 : 1;
                 if (live > max_live) max_live = live;
                 live -= dies[k];
             }
@@ -154,42 +181,50 @@ class Gen {
                 if (stmts[k].target == "//") continue;
                 ++n_stmt;
                 // arithmetic = a kept temporary that is not an LDS read-back
-                if (!stmts[k].target.empty() && stmts[k].text.find("RBL_LDS(") == std::string::npos) ++flops;
+                if (!stmts[k].target.empty() && stmts[k].text.find("RBL_LDS(") == std::string::npos)
+                    flops += stmts[k].text.compare(0, 17, "    const rbl_f2 ") == 0 ? 2 : 1;
             }
         return out;
     }
     static Val negv(Val a) {
-        if (a.k) { a.c = -a.c; return a; }
+        if (a.k) { a.c = -a.c; a.c1 = -a.c1; return a; }
         a.neg = !a.neg;
         return a;
     }
     Val add(const Val &a, const Val &b) {
-        if (a.k && b.k) return K(a.c + b.c);
+        if (a.k && b.k) return K2(a.c + b.c, a.c1 + b.c1);
         if (is0(a)) return b;
         if (is0(b)) return a;
         if (a.k) return add(b, a);                       // named first
+        const bool pr = a.pair || b.pair;
         if (b.k) {                                       // named + constant
-            if (!a.neg) return emit(a.name + (b.c < 0 ? " - " + lit(-b.c) : " + " + lit(b.c)));
-            return emit(lit(b.c) + " - " + a.name);
+            if (b.pair) return a.neg ? emit(S(b) + " - " + a.name, true) : emit(a.name + " + " + S(b), true);
+            if (!a.neg) return emit(a.name + (b.c < 0 ? " - " + lit(-b.c) : " + " + lit(b.c)), pr);
+            return emit(lit(b.c) + " - " + a.name, pr);
         }
-        if (!a.neg && !b.neg) return emit(a.name + " + " + b.name);
-        if (!a.neg && b.neg) return emit(a.name + " - " + b.name);
-        if (a.neg && !b.neg) return emit(b.name + " - " + a.name);
-        return negv(emit(a.name + " + " + b.name));
+        if (!a.neg && !b.neg) return emit(a.name + " + " + b.name, pr);
+        if (!a.neg && b.neg) return emit(a.name + " - " + b.name, pr);
+        if (a.neg && !b.neg) return emit(b.name + " - " + a.name, pr);
+        return negv(emit(a.name + " + " + b.name, pr));
     }
     Val sub(const Val &a, const Val &b) { return add(a, negv(b)); }
     Val mul(const Val &a, const Val &b) {
-        if (a.k && b.k) return K(a.c * b.c);
+        if (a.k && b.k) return K2(a.c * b.c, a.c1 * b.c1);
         if (is0(a) || is0(b)) return K(0.0);
         if (a.k) return mul(b, a);
         if (b.k) {
             if (is1(b)) return a;
             if (ism1(b)) return negv(a);
-            Val r = emit(a.name + " * " + lit(std::fabs(b.c)));
+            if (b.pair) {                                // (the two signs may differ: they stay in the constants)
+                Val r = emit(a.name + " * " + S(b), true);
+                r.neg = a.neg;
+                return r;
+            }
+            Val r = emit(a.name + " * " + lit(std::fabs(b.c)), a.pair);
             r.neg = a.neg != (b.c < 0);
             return r;
         }
-        Val r = emit(a.name + " * " + b.name);
+        Val r = emit(a.name + " * " + b.name, a.pair || b.pair);
         r.neg = a.neg != b.neg;
         return r;
     }
@@ -200,18 +235,24 @@ class Gen {
         for (const auto &t : terms) acc = fma(t.first, t.second, acc);
         return acc;
     }
-    Val call1(const char *fn, const Val &a) { return emit(std::string(fn) + "(" + S(a) + ")"); }
-    Val call2(const char *fn, const Val &a, const Val &b) { return emit(std::string(fn) + "(" + S(a) + ", " + S(b) + ")"); }
+    // (a pair's functions are those of its two floats; rbl_f2 overloads take plain floats for the other arguments)
+    Val call1(const char *fn, const Val &a) { return emit(std::string(fn) + "(" + S(a) + ")", a.pair); }
+    Val call2(const char *fn, const Val &a, const Val &b) { return emit(std::string(fn) + "(" + S(a) + ", " + S(b) + ")", a.pair || b.pair); }
     Val call3(const char *fn, const Val &a, const Val &b, const Val &c) {
-        return emit(std::string(fn) + "(" + S(a) + ", " + S(b) + ", " + S(c) + ")");
+        return emit(std::string(fn) + "(" + S(a) + ", " + S(b) + ", " + S(c) + ")", a.pair || b.pair || c.pair);
     }
     // a value that is used again much later: to a lane-private LDS slot and back
-    int lds_store(const Val &v) {
-        const int slot = n_lds++;
-        store("RBL_LDS(" + std::to_string(slot) + ")", v);
+    int lds_store(const Val &v) {                        // (a pair takes two slots)
+        const int slot = n_lds;
+        n_lds += v.pair ? 2 : 1;
+        if (v.pair) store2("RBL_LDS(" + std::to_string(slot) + ")", "RBL_LDS(" + std::to_string(slot + 1) + ")", v);
+        else store("RBL_LDS(" + std::to_string(slot) + ")", v);
         return slot;
     }
-    Val lds_load(int slot) { return emit("RBL_LDS(" + std::to_string(slot) + ")"); }
+    Val lds_load(int slot, bool pair = false) {
+        if (pair) return emit("RBL_MK2(RBL_LDS(" + std::to_string(slot) + "), RBL_LDS(" + std::to_string(slot + 1) + "))", true);
+        return emit("RBL_LDS(" + std::to_string(slot) + ")");
+    }
 
     // ---- small vector algebra on symbolic values ----
     V3 vadd(const V3 &a, const V3 &b) { return {add(a[0], b[0]), add(a[1], b[1]), add(a[2], b[2])}; }
@@ -243,6 +284,7 @@ class Gen {
         return o;
     }
     static V3 KV(const double *p) { return {K(p[0]), K(p[1]), K(p[2])}; }
+    static V3 KV2(const double *p, const double *m) { return {K2(p[0], m[0]), K2(p[1], m[1]), K2(p[2], m[2])}; }
     static V3 zero3() { return {K(0.0), K(0.0), K(0.0)}; }
 };
 
@@ -343,21 +385,53 @@ class Aba {
     std::vector<V3> p, w, vo, z, sl;
     std::vector<std::array<Val, 6>> cacc, bown, pT, pA, U, acc, cpre;
     std::vector<std::array<int, 6>> cslot;
+    std::vector<std::array<char, 6>> cpair;
     // the link's own spatial inertia about the world origin and its bias force v x* (I v), evaluated while the frame
     // and the velocity are at hand: from here to the backward pass a massive link is carried as I_o (6), h (3) and
     // a bias force (6, which also collects the tendon wrenches) instead of R, p, w, vO and its wrenches (24)
     std::vector<Sym6> Iown, IA;
     std::vector<Val> invD, uu;
     std::vector<char> cpre_ok;
-    std::map<std::pair<int, int>, std::array<Val, 6>> pair_sum;      // sum of F (m ; u) over the crossings la -> lb
+    // sum of F (m ; u) over the crossings la -> lb - of plain tendons (key.second = 0) and of tendons with a mate (1: pair
+    // values that stand for two tendons; kept apart so that a plain link can take their two halves without counting the
+    // plain tendons twice)
+    typedef std::pair<std::pair<int, int>, int> SumKey;
+    std::map<SumKey, std::array<Val, 6>> pair_sum;
     std::map<std::pair<int, int>, std::pair<V3, V3>> pair_vel;       // (w_b - w_a, vO_b - vO_a)
-    std::vector<std::pair<int, int>> pair_order;
+    std::vector<SumKey> pair_order;
+
+    // Mates (generate(): find_mates): mate[i] >= 0 - link i is written together with link mate[i] as ONE stream of pair
+    // values (i the x lane, mate[i] the y lane); mate[i] == SKIP - link i is some link's mate and is never visited itself;
+    // -1: a plain link.  tmate: the same for tendons.  Every per-link / per-tendon constant and input below goes through
+    // CL / CT / in_l / in_t, which return the pair where there is a mate.
+    enum { SKIP = -2 };
+    std::vector<int> mate, tmate;
+    bool skip_link(int i) const { return mate[i] == SKIP; }
+    bool skip_tendon(int k) const { return tmate[k] == SKIP; }
+    Val CL(const double *arr, int stride, int i, int off = 0) const {
+        return mate[i] >= 0 ? Gen::K2(arr[stride * i + off], arr[stride * mate[i] + off]) : Gen::K(arr[stride * i + off]);
+    }
+    V3 CL3(const double *arr, int i) const { return {CL(arr, 3, i, 0), CL(arr, 3, i, 1), CL(arr, 3, i, 2)}; }
+    Val CT(const double *arr, int k) const { return tmate[k] >= 0 ? Gen::K2(arr[k], arr[tmate[k]]) : Gen::K(arr[k]); }
+    Val in_l(const char *nm, int i) {
+        const std::string a = std::string(nm) + "[" + std::to_string(i) + "]";
+        if (mate[i] < 0) return Gen::named(a);
+        return g.emit("RBL_MK2(" + a + ", " + nm + "[" + std::to_string(mate[i]) + "])", true);
+    }
+    Val in_t(const char *nm, int k) {
+        const std::string a = std::string(nm) + "[" + std::to_string(k) + "]";
+        if (tmate[k] < 0) return Gen::named(a);
+        return g.emit("RBL_MK2(" + a + ", " + nm + "[" + std::to_string(tmate[k]) + "])", true);
+    }
+    // a contribution of link `from` (and of its mate, if it has one) arriving at link `to`
+    Val arrive(const Val &v, int from, int to) { return (mate[from] >= 0 && (to < 0 || mate[to] < 0)) ? g.hsum(v) : v; }
 
     Aba(const Robot &r, Gen &gen, bool park_c) : rob(r), g(gen), lds_c(park_c) {
         const int nq = r.nq;
+        mate.assign(nq, -1); tmate.assign(r.nt, -1);
         R.resize(nq); p.resize(nq); w.resize(nq); vo.resize(nq); z.resize(nq); sl.resize(nq);
         cacc.resize(nq); bown.resize(nq); pT.resize(nq); pA.resize(nq); U.resize(nq); acc.resize(nq); cpre.resize(nq);
-        cslot.resize(nq); Iown.resize(nq); IA.resize(nq); invD.resize(nq); uu.resize(nq); cpre_ok.assign(nq, 0);
+        cslot.resize(nq); cpair.resize(nq); Iown.resize(nq); IA.resize(nq); invD.resize(nq); uu.resize(nq); cpre_ok.assign(nq, 0);
     }
     static Val K(double c) { return Gen::K(c); }
     V3 link_w(int l) const { return l < 0 ? Gen::zero3() : w[l]; }
@@ -369,17 +443,21 @@ class Aba {
         const rb_robot_desc *d = rob.d;
         g.comment("tendon " + std::to_string(k));
         Val len = K(0.0), ldot = K(0.0);
-        struct Unit { std::pair<int, int> pr; V3 m, u; };
+        struct Unit { SumKey key; V3 m, u; };
         std::vector<Unit> units;
-        for (const Crossing &cr : rob.t_cross[k]) {
+        const int mated = tmate[k] >= 0 ? 1 : 0;
+        for (size_t ci = 0; ci < rob.t_cross[k].size(); ++ci) {
+            const Crossing &cr = rob.t_cross[k][ci];
+            const Crossing &cm = tmate[k] >= 0 ? rob.t_cross[tmate[k]][ci] : cr;       // the mate's crossing: same links up to mating
             const std::pair<int, int> pr(cr.la, cr.lb);
-            if (!pair_vel.count(pr)) {
-                pair_vel[pr] = {g.vsub(link_w(cr.lb), link_w(cr.la)), g.vsub(link_vo(cr.lb), link_vo(cr.la))};
-                pair_sum[pr] = {K(0), K(0), K(0), K(0), K(0), K(0)};
-                pair_order.push_back(pr);
+            const SumKey key(pr, mated);
+            if (!pair_vel.count(pr)) pair_vel[pr] = {g.vsub(link_w(cr.lb), link_w(cr.la)), g.vsub(link_vo(cr.lb), link_vo(cr.la))};
+            if (!pair_sum.count(key)) {
+                pair_sum[key] = {K(0), K(0), K(0), K(0), K(0), K(0)};
+                pair_order.push_back(key);
             }
-            const V3 xa = cr.la < 0 ? Gen::KV(cr.ra) : g.vadd(p[cr.la], g.matvec(R[cr.la], Gen::KV(cr.ra)));
-            const V3 xb = cr.lb < 0 ? Gen::KV(cr.rb) : g.vadd(p[cr.lb], g.matvec(R[cr.lb], Gen::KV(cr.rb)));
+            const V3 xa = cr.la < 0 ? Gen::KV2(cr.ra, cm.ra) : g.vadd(p[cr.la], g.matvec(R[cr.la], Gen::KV2(cr.ra, cm.ra)));
+            const V3 xb = cr.lb < 0 ? Gen::KV2(cr.rb, cm.rb) : g.vadd(p[cr.lb], g.matvec(R[cr.lb], Gen::KV2(cr.rb, cm.rb)));
             const V3 dd = g.vsub(xb, xa);
             const Val d2 = g.vdot(dd, dd), inv = g.call1("rbl_rsq", d2);
             const V3 u = g.vscale(dd, inv);
@@ -388,21 +466,22 @@ class Aba {
             const Val ldl = g.vdot(u, pair_vel[pr].second);
             const Val lda = g.vdot(m, pair_vel[pr].first);
             ldot = g.add(ldot, g.add(ldl, lda));
-            units.push_back({pr, m, u});
+            units.push_back({key, m, u});
         }
         // Hill-type force, scaled forms as in tree_aba.hpp p2_tendon / msj_math.hpp
-        const Val es = g.fma(len, K(rob.il0s[k]), K(rob.elcs[k]));
-        const Val act = g.call3("rbl_med3", g.sub(g.mul(es, K(rob.kps)), Gen::named("spu[" + std::to_string(k) + "]")), K(0.0), K(1.0));
+        const Val es = g.fma(len, CT(rob.il0s.data(), k), CT(rob.elcs.data(), k));
+        const Val spu = in_t("spu", k);
+        const Val act = g.call3("rbl_med3", g.sub(g.mul(es, K(rob.kps)), spu), K(0.0), K(1.0));
         const Val fl = g.call1("rbl_exp2", Gen::negv(g.mul(es, es)));
-        const Val v = g.mul(ldot, K(rob.inv_vl0[k]));
+        const Val v = g.mul(ldot, CT(rob.inv_vl0.data(), k));
         const Val vp = g.call2("rbl_max", v, K(0.0)), pq = g.call3("rbl_med3", g.add(v, K(1.0)), K(0.0), K(1.0));
         const Val num = g.fma(vp, K(rob.fv_c1l), pq), den = g.fma(vp, K(rob.fv_c2l), g.fma(pq, K(rob.fv_c2s), K(rob.fv_k)));
         const Val fpe = g.call2("rbl_max", g.sub(g.mul(g.call1("rbl_exp2", g.mul(es, K(rob.pe_k2s))), K(rob.inv_pe_den)), K(rob.inv_pe_den)), K(0.0));
         const Val afn = g.mul(g.mul(act, fl), num);
         const Val rden = g.call1("rbl_rcp", den);
-        const Val F = g.mul(g.fma(afn, rden, fpe), K(d->f_max[k]));
+        const Val F = g.mul(g.fma(afn, rden, fpe), CT(d->f_max, k));
         for (const Unit &un : units) {
-            auto &s = pair_sum[un.pr];
+            auto &s = pair_sum[un.key];
             for (int a = 0; a < 3; ++a) { s[a] = g.fma(un.m[a], F, s[a]); s[3 + a] = g.fma(un.u[a], F, s[3 + a]); }
         }
     }
@@ -415,7 +494,7 @@ class Aba {
         const int par = rob.parent[i];
         const M3 &Rp = par < 0 ? ident : R[par];
         const V3 pp = par < 0 ? Gen::zero3() : p[par], wp = par < 0 ? Gen::zero3() : w[par], vop = par < 0 ? Gen::zero3() : vo[par];
-        const Val qi = Gen::named("q[" + std::to_string(i) + "]"), qdi = Gen::named("qd[" + std::to_string(i) + "]");
+        const Val qi = in_l("q", i), qdi = in_l("qd", i);
         const Val sn = g.call1("rbl_sin", qi), cs = g.call1("rbl_cos", qi);
         const double *ax = d->axis + 3 * i;
         const Val oc = g.sub(K(1.0), cs);
@@ -431,7 +510,7 @@ class Aba {
                 rot[3 * r + c] = g.add(sk, ok);
             }
         R[i] = g.matmul(Rp, rot);
-        p[i] = g.vadd(pp, g.matvec(Rp, Gen::KV(d->origin + 3 * i)));
+        p[i] = g.vadd(pp, g.matvec(Rp, CL3(d->origin, i)));
         z[i] = g.matvec(Rp, Gen::KV(ax));
         sl[i] = g.cross(p[i], z[i]);
         w[i] = g.vfma(z[i], qdi, wp);
@@ -441,7 +520,10 @@ class Aba {
         const V3 voxz = g.cross(vo[i], z[i]);
         const V3 cl = g.vscale(g.vadd(wxsl, voxz), qdi);
         for (int a = 0; a < 3; ++a) { cacc[i][a] = ca[a]; cacc[i][3 + a] = cl[a]; }
-        for (int a = 0; a < 6; ++a) cslot[i][a] = (lds_c && !cacc[i][a].k) ? g.lds_store(cacc[i][a]) : -1;
+        for (int a = 0; a < 6; ++a) {
+            cpair[i][a] = cacc[i][a].pair;
+            cslot[i][a] = (lds_c && !cacc[i][a].k) ? g.lds_store(cacc[i][a]) : -1;
+        }
         for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) Iown[i].m[r][c] = K(0.0);
         bown[i] = {K(0), K(0), K(0), K(0), K(0), K(0)};
         const double mass = d->mass[i];
@@ -450,10 +532,12 @@ class Aba {
         for (int a = 0; a < 6; ++a) massless = massless && I6[a] == 0.0;
         if (!massless) {
             Sym6 &I = Iown[i];
-            const V3 cw = g.vadd(p[i], g.matvec(R[i], Gen::KV(d->com + 3 * i)));
-            const V3 h = g.vscale(cw, K(mass));
+            const Val km = CL(d->mass, 1, i);
+            const V3 cw = g.vadd(p[i], g.matvec(R[i], CL3(d->com, i)));
+            const V3 h = g.vscale(cw, km);
             // I_w = R I_c R^T (I_c symmetric: xx,yy,zz,xy,xz,yz)
-            const M3 Ic = {K(I6[0]), K(I6[3]), K(I6[4]), K(I6[3]), K(I6[1]), K(I6[5]), K(I6[4]), K(I6[5]), K(I6[2])};
+            auto I6k = [&](int a) { return CL(d->inertia, 6, i, a); };
+            const M3 Ic = {I6k(0), I6k(3), I6k(4), I6k(3), I6k(1), I6k(5), I6k(4), I6k(5), I6k(2)};
             const M3 T = g.matmul(R[i], Ic);
             Val Io[3][3];
             for (int r = 0; r < 3; ++r)
@@ -471,14 +555,14 @@ class Aba {
             for (int r = 0; r < 3; ++r) for (int c = r; c < 3; ++c) I.m[r][c] = Io[r][c];
             const Val hx[3][3] = {{K(0), Gen::negv(h[2]), h[1]}, {h[2], K(0), Gen::negv(h[0])}, {Gen::negv(h[1]), h[0], K(0)}};
             for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) I.m[r][3 + c] = hx[r][c];
-            for (int r = 0; r < 3; ++r) I.m[3 + r][3 + r] = K(mass);
+            for (int r = 0; r < 3; ++r) I.m[3 + r][3 + r] = km;
             // bias force v x* (I v)
             const V3 Iow = {g.dot({{Io[0][0], w[i][0]}, {Io[0][1], w[i][1]}, {Io[0][2], w[i][2]}}),
                             g.dot({{Io[1][0], w[i][0]}, {Io[1][1], w[i][1]}, {Io[1][2], w[i][2]}}),
                             g.dot({{Io[2][0], w[i][0]}, {Io[2][1], w[i][1]}, {Io[2][2], w[i][2]}})};
             const V3 hxvo = g.cross(h, vo[i]);
             const V3 Iva = g.vadd(Iow, hxvo);
-            const V3 mvo = g.vscale(vo[i], K(mass));
+            const V3 mvo = g.vscale(vo[i], km);
             const V3 hxw = g.cross(h, w[i]);
             const V3 Ivl = g.vsub(mvo, hxw);
             const V3 wxIa = g.cross(w[i], Iva);
@@ -491,7 +575,7 @@ class Aba {
 
     std::array<Val, 6> load_c(int i) {
         std::array<Val, 6> c = cacc[i];
-        for (int a = 0; a < 6; ++a) if (cslot[i][a] >= 0) c[a] = g.lds_load(cslot[i][a]);
+        for (int a = 0; a < 6; ++a) if (cslot[i][a] >= 0) c[a] = g.lds_load(cslot[i][a], cpair[i][a] != 0);
         return c;
     }
     // the parked c of a link is requested one link ahead of its use: a wave is alone on its SIMD, so an LDS latency
@@ -502,17 +586,21 @@ class Aba {
     // pT = -f_ext of the tendons written so far: the crossing la -> lb pulls la towards lb (f_ext_la += W, f_ext_lb -= W)
     void wrenches_to_links() {
         for (int i = 0; i < rob.nq; ++i) pT[i] = {K(0), K(0), K(0), K(0), K(0), K(0)};
-        for (const auto &pr : pair_order) {
-            const auto &s = pair_sum[pr];
+        for (const SumKey &key : pair_order) {
+            const auto &s = pair_sum[key];
+            const std::pair<int, int> &pr = key.first;
+            // (the crossings of a tendon with a mate stand for two crossings each: a plain link gets both)
+            const bool dbl = key.second != 0;
             for (int a = 0; a < 6; ++a) {
-                if (pr.first >= 0) pT[pr.first][a] = g.sub(pT[pr.first][a], s[a]);
-                if (pr.second >= 0) pT[pr.second][a] = g.add(pT[pr.second][a], s[a]);
+                if (pr.first >= 0) pT[pr.first][a] = g.sub(pT[pr.first][a], dbl && mate[pr.first] < 0 ? g.hsum(s[a]) : s[a]);
+                if (pr.second >= 0) pT[pr.second][a] = g.add(pT[pr.second][a], dbl && mate[pr.second] < 0 ? g.hsum(s[a]) : s[a]);
             }
         }
     }
     // accumulators of the backward pass: no children yet, bias force = own bias + tendon wrenches
     void init_backward() {
         for (int i = 0; i < rob.nq; ++i) {
+            if (skip_link(i)) continue;
             for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) IA[i].m[r][c] = K(0.0);
             for (int a = 0; a < 6; ++a) pA[i][a] = g.add(bown[i][a], pT[i][a]);
         }
@@ -531,9 +619,9 @@ class Aba {
         }
         std::vector<std::pair<Val, Val>> sU, sP;
         for (int r = 0; r < 6; ++r) { sU.push_back({s[r], U[i][r]}); sP.push_back({s[r], pA[i][r]}); }
-        const Val D = g.add(g.dot(sU), K(d->armature[i]));
+        const Val D = g.add(g.dot(sU), CL(d->armature, 1, i));
         invD[i] = g.call1("rbl_rcp", D);
-        const Val dqd = g.mul(Gen::named("qd[" + std::to_string(i) + "]"), K(d->damping[i]));
+        const Val dqd = g.mul(in_l("qd", i), CL(d->damping, 1, i));
         const Val spa = g.dot(sP);
         uu[i] = Gen::negv(g.add(dqd, spa));
         if (par_I) {
@@ -549,9 +637,10 @@ class Aba {
                 for (int cc = 0; cc < 6; ++cc) terms.push_back({Ia.at(r, cc), c[cc]});
                 const Val pu = g.fma(U[i][r], ud, pA[i][r]);
                 const Val pa = g.add(pu, g.dot(terms));
-                (*par_p)[r] = g.add((*par_p)[r], pa);
+                (*par_p)[r] = g.add((*par_p)[r], arrive(pa, i, rob.parent[i]));
             }
-            for (int r = 0; r < 6; ++r) for (int cc = r; cc < 6; ++cc) par_I->m[r][cc] = g.add(par_I->m[r][cc], Ia.m[r][cc]);
+            for (int r = 0; r < 6; ++r)
+                for (int cc = r; cc < 6; ++cc) par_I->m[r][cc] = g.add(par_I->m[r][cc], arrive(Ia.m[r][cc], i, rob.parent[i]));
         }
     }
     // ---- forward accelerations of one link; qdd goes to `qdd[slot]` ----
@@ -565,7 +654,8 @@ class Aba {
         std::vector<std::pair<Val, Val>> terms;
         for (int r = 0; r < 6; ++r) terms.push_back({U[i][r], ap[r]});
         const Val qdd = g.mul(g.sub(uu[i], g.dot(terms)), invD[i]);
-        g.store("qdd[" + std::to_string(slot) + "]", qdd);
+        if (mate[i] >= 0) g.store2("qdd[" + std::to_string(slot) + "]", "qdd[" + std::to_string(slot + (mate[i] - i)) + "]", qdd);
+        else g.store("qdd[" + std::to_string(slot) + "]", qdd);
         if (!rob.children[i].empty()) {
             const std::array<Val, 6> s = {z[i][0], z[i][1], z[i][2], sl[i][0], sl[i][1], sl[i][2]};
             for (int r = 0; r < 6; ++r) acc[i][r] = g.fma(s[r], qdd, ap[r]);
@@ -586,27 +676,91 @@ inline void write_tables(std::string &t, const Robot &rob) {
     table("VMAX", rob.nq, [&](int k) { return d->qd_max[k]; });
 }
 
-// Write the header for robot `d`: ONE function for the whole robot, links in index order.
-// lds_c: keep the velocity-product accelerations in LDS between the sweeps.
-inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::string &err) {
+// Mates: pairs of sibling subtrees with the same structure - joint for joint the same axis, the same massless links, the
+// same children in the same order, and tendon for tendon the same crossings between corresponding links (or between a
+// link of the subtree and one outside both) - whatever their constants.  The two arms of the upper body are such a pair:
+// 7 links and 13 tendons each.  generate() writes mates as one stream of pair values (Val::pair).
+inline void find_mates(const Robot &rob, std::vector<int> &mate, std::vector<int> &tmate) {
+    const rb_robot_desc *d = rob.d;
+    const int nq = rob.nq, nt = rob.nt;
+    mate.assign(nq, -1); tmate.assign(nt, -1);
+    auto massless = [&](int i) {
+        bool m = d->mass[i] == 0.0;
+        for (int a = 0; a < 6; ++a) m = m && d->inertia[6 * i + a] == 0.0;
+        return m;
+    };
+    // links of the two subtrees in corresponding order, or false
+    std::function<bool(int, int, std::vector<std::pair<int, int>> &)> iso = [&](int a, int b, std::vector<std::pair<int, int>> &m) {
+        for (int x = 0; x < 3; ++x) if (d->axis[3 * a + x] != d->axis[3 * b + x]) return false;
+        if (massless(a) != massless(b) || rob.children[a].size() != rob.children[b].size()) return false;
+        m.push_back({a, b});
+        for (size_t c = 0; c < rob.children[a].size(); ++c) if (!iso(rob.children[a][c], rob.children[b][c], m)) return false;
+        return true;
+    };
+    auto try_match = [&](int a, int b) {
+        std::vector<std::pair<int, int>> m;
+        if (!iso(a, b, m)) return false;
+        std::vector<int> to(nq, -1), side(nq, 0);          // side: 1 = in the first subtree, 2 = in the second
+        for (const auto &ab : m) { to[ab.first] = ab.second; side[ab.first] = 1; side[ab.second] = 2; }
+        auto touches = [&](int k, int sd) { for (const Crossing &c : rob.t_cross[k]) if ((c.la >= 0 && side[c.la] == sd) || (c.lb >= 0 && side[c.lb] == sd)) return true; return false; };
+        std::vector<int> tm(nt, -1);
+        std::vector<char> used(nt, 0);
+        for (int k = 0; k < nt; ++k) {
+            if (!touches(k, 1)) continue;
+            if (touches(k, 2) || tmate[k] != -1) return false;
+            int found = -1;
+            for (int k2 = 0; k2 < nt && found < 0; ++k2) {
+                if (used[k2] || tmate[k2] != -1 || !touches(k2, 2) || touches(k2, 1) || rob.t_cross[k2].size() != rob.t_cross[k].size()) continue;
+                bool same = true;
+                for (size_t c = 0; c < rob.t_cross[k].size() && same; ++c) {
+                    const Crossing &x = rob.t_cross[k][c], &y = rob.t_cross[k2][c];
+                    auto image = [&](int l) { return l >= 0 && side[l] == 1 ? to[l] : l; };
+                    same = image(x.la) == y.la && image(x.lb) == y.lb;
+                }
+                if (same) found = k2;
+            }
+            if (found < 0) return false;
+            tm[k] = found; used[found] = 1;
+        }
+        for (int k2 = 0; k2 < nt; ++k2) if (touches(k2, 2) && !used[k2]) return false;
+        for (const auto &ab : m) { mate[ab.first] = ab.second; mate[ab.second] = Aba::SKIP; }
+        for (int k = 0; k < nt; ++k) if (tm[k] >= 0) { tmate[k] = tm[k]; tmate[tm[k]] = Aba::SKIP; }
+        return true;
+    };
+    for (int par = -1; par < nq; ++par) {
+        std::vector<int> kids;
+        if (par < 0) { for (int i = 0; i < nq; ++i) if (rob.parent[i] < 0) kids.push_back(i); }
+        else kids = rob.children[par];
+        for (size_t x = 0; x < kids.size(); ++x)
+            for (size_t y = x + 1; y < kids.size(); ++y)
+                if (mate[kids[x]] == -1 && mate[kids[y]] == -1 && try_match(kids[x], kids[y])) break;
+    }
+}
+
+// Write the header for robot `d`: ONE function for the whole robot, links in index order (mates together).
+// lds_c: keep the velocity-product accelerations in LDS between the sweeps.  pack: write mates as pair values.
+inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::string &err, bool pack = true) {
     Robot rob;
     if (int rc = build_robot(d, rob, err)) return rc;
     const int nq = rob.nq, nt = rob.nt;
     Gen g;
     Aba A(rob, g, lds_c);
+    if (pack) find_mates(rob, A.mate, A.tmate);
     // ---------------- sweep 1: frames, joint axes, velocities, velocity-product accelerations; tendons ----------------
-    for (int k = 0; k < nt; ++k) if (rob.t_last[k] < 0) A.tendon(k);      // (tendons that touch no moving link)
+    for (int k = 0; k < nt; ++k) if (rob.t_last[k] < 0 && !A.skip_tendon(k)) A.tendon(k);      // (tendons that touch no moving link)
     for (int i = 0; i < nq; ++i) {
+        if (A.skip_link(i)) continue;
         A.forward(i);
-        for (int k = 0; k < nt; ++k) if (rob.t_last[k] == i) A.tendon(k);
+        for (int k = 0; k < nt; ++k) if (rob.t_last[k] == i && !A.skip_tendon(k)) A.tendon(k);
         g.barrier();
     }
     A.wrenches_to_links();
     // ---------------- sweep 2: articulated inertias and bias forces, leaves to root ----------------
     A.init_backward();
-    auto next_user = [&](int i) { int n = i - 1; while (n >= 0 && rob.parent[n] < 0) --n; return n; };   // (a root's backward step uses no c)
+    auto next_user = [&](int i) { int n = i - 1; while (n >= 0 && (rob.parent[n] < 0 || A.skip_link(n))) --n; return n; };   // (a root's backward step uses no c)
     A.prefetch_c(next_user(nq));
     for (int i = nq - 1; i >= 0; --i) {
+        if (A.skip_link(i)) continue;
         g.comment("link " + std::to_string(i) + ": backward pass");
         A.prefetch_c(next_user(i));
         const int par = rob.parent[i];
@@ -615,10 +769,12 @@ inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::str
     }
     // ---------------- sweep 3: accelerations, root to leaves ----------------
     for (int i = 0; i < nq; ++i) A.cpre_ok[i] = 0;
-    A.prefetch_c(0);
+    auto next_link = [&](int i) { int n = i + 1; while (n < nq && A.skip_link(n)) ++n; return n; };
+    A.prefetch_c(next_link(-1));
     for (int i = 0; i < nq; ++i) {
+        if (A.skip_link(i)) continue;
         g.comment("link " + std::to_string(i) + ": acceleration");
-        A.prefetch_c(i + 1);
+        A.prefetch_c(next_link(i));
         A.accel(i, i);
         g.barrier();
     }

@@ -60,6 +60,67 @@ def random_tree_spec(seed, n_q=None, n_t=None, shape=None, p_massless=0.25):
                        "fv_a": 0.25, "fv_n": 1.5}}
 
 
+def random_mirrored_spec(seed, n_branch=4, n_t_branch=5, extra_cross=False):
+    """A trunk of two joints carrying TWO structurally identical branches (same axes, same massless links, same tendon
+    routing) whose constants differ - what the lane-kernel generator writes as one stream of pair values - plus a plain
+    third branch and a few trunk tendons.  extra_cross: one tendon runs from the first branch to the second (no pairing then)."""
+    base = random_tree_spec(seed, n_q=2 + n_branch, n_t=1, shape="chain")
+    rng = np.random.default_rng(7000 + seed)
+    joints = base["joints"][:2]
+    branch = base["joints"][2:]
+    first = len(joints)
+
+    def jitter(x, rel=0.2):
+        return float(x * (1.0 + rng.uniform(-rel, rel)))
+
+    for copy in range(2):
+        off = len(joints) - 2
+        for j, src in enumerate(branch):
+            jj = dict(src)
+            jj["name"] = "b%d_%d" % (copy, j)
+            jj["parent"] = 1 if j == 0 else src["parent"] + off
+            if copy == 1:                                   # the same structure, other numbers (zeros stay zeros: massless links)
+                jj["origin"] = [jitter(x) for x in src["origin"]]
+                jj["com"] = [jitter(x) for x in src["com"]]
+                jj["mass"] = jitter(src["mass"])
+                jj["inertia"] = [jitter(x, 0.05) for x in src["inertia"]]
+                jj["armature"], jj["damping"] = jitter(src["armature"]), jitter(src["damping"])
+                jj["limit"] = [jitter(src["limit"][0]), jitter(src["limit"][1])]
+            joints.append(jj)
+    second = first + n_branch
+    third = len(joints)
+    extra = random_tree_spec(seed + 50, n_q=3, n_t=1, shape="chain")["joints"]
+    for j, src in enumerate(extra):
+        jj = dict(src)
+        jj["name"] = "c%d" % j
+        jj["parent"] = 1 if j == 0 else third + j - 1
+        joints.append(jj)
+    tendons = []
+    for k in range(n_t_branch):                              # routed over the trunk (or the base) and the first branch; mirrored
+        n_vp = int(rng.integers(2, 5))
+        links, pts = [], []
+        for v in range(n_vp):
+            links.append(int(rng.choice([-1, 0, 1] + list(range(first, first + n_branch)))))
+            pts.append(rng.uniform(-0.06, 0.06, 3))
+        if all(l < first for l in links):
+            links[-1] = first + int(rng.integers(0, n_branch))
+        f = float(rng.uniform(4.0, 25.0))
+        tendons.append({"name": "a%d" % k, "f_max": f, "via_points": [{"link": l, "pos": [float(x) for x in p]} for l, p in zip(links, pts)]})
+        tendons.append({"name": "b%d" % k, "f_max": jitter(f), "via_points": [{"link": l + n_branch if l >= first else l, "pos": [jitter(x) for x in p]}
+                                                                                for l, p in zip(links, pts)]})
+    for k in range(3):                                       # plain tendons: trunk, base, third branch
+        links = [int(rng.choice([-1, 0, 1, third, third + 1, third + 2])) for _ in range(3)]
+        tendons.append({"name": "p%d" % k, "f_max": float(rng.uniform(4.0, 25.0)),
+                        "via_points": [{"link": l, "pos": [float(x) for x in rng.uniform(-0.06, 0.06, 3)]} for l in links]})
+    if extra_cross:
+        tendons.append({"name": "x", "f_max": 10.0, "via_points": [{"link": first, "pos": [0.01, 0.02, 0.03]}, {"link": second, "pos": [0.02, -0.01, 0.03]}]})
+    rng.shuffle(tendons)
+    spec = dict(base)
+    spec["name"] = "mirrored%d" % seed
+    spec["joints"], spec["tendons"] = joints, tendons
+    return spec
+
+
 def random_ball_joint_spec(seed, n_t=8):
     """One rigid body on an x-y-z ball joint at the base origin (the class msj_math.hpp closes in closed form) with
     everything else random: tendon routing (1-3 base via-points, 1-2 body via-points), inertia with products,
@@ -129,3 +190,8 @@ def random_ball_joint_robot(seed, n_t=8):
 def random_tree_robot(seed, **kw):
     """(robot object, description) of random_tree_spec(seed)."""
     return _robot_of(random_tree_spec(seed, **kw))
+
+
+def random_mirrored_robot(seed, **kw):
+    """(robot object, description) of random_mirrored_spec(seed)."""
+    return _robot_of(random_mirrored_spec(seed, **kw))

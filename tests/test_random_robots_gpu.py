@@ -89,6 +89,31 @@ def test_random_tree_robot_env_per_lane_kernel_matches_oracle(seed):
     sim.close()
 
 
+@pytest.mark.parametrize("seed", [0, 2])
+def test_robot_with_two_identical_branches_runs_them_as_pair_values(seed):
+    """The env-per-lane form of a robot with two structurally identical branches (the generator writes them as one stream of
+    pair values: v_pk_* instructions), built by hiprtc, against the oracle and the octets."""
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    from oracle.c_oracle import COracle
+    from random_robots import random_mirrored_robot
+    robot, desc = random_mirrored_robot(seed, n_branch=3 + seed, n_t_branch=3 + seed)
+    integrator = "rk4" if seed else "euler"
+    n = 70
+    q, qd, sp = random_states(desc, n, seed)
+    sim = HipBatchSimulation(robot, n, integrator=integrator)
+    sim.set_state(q, qd)
+    qa, qda, fa = sim.forward_step_command(sp)                 # octets
+    sim.select_kernel(1)
+    assert sim.info()["kernel"] == 1 and sim.specialization() == "jit"
+    sim.set_state(q, qd)
+    q1, qd1, f1 = sim.forward_step_command(sp)
+    qo, qdo, fo = COracle(desc, "f64").step(q, qd, sp, integrator=0 if integrator == "euler" else 1)
+    tol = tolerance(desc, q, qd, sp)
+    assert np.all(np.abs(q1 - qo) < tol) and np.all(np.abs(qd1 - qdo) < tol), (np.abs(q1 - qo).max(), np.abs(qd1 - qdo).max())
+    assert np.all(np.abs(q1 - qa) < 2 * tol) and np.all(np.abs(qd1 - qda) < 2 * tol)
+    sim.close()
+
+
 @pytest.mark.parametrize("seed", [5, 9])        # 11 joints in 2 parts, 18 joints in 4 parts (several roots: no trunk)
 def test_random_tree_robot_split_form_matches_oracle(seed):
     """The split form (several waves per group of 64 envs) of a random robot, built by hiprtc on request."""

@@ -19,12 +19,12 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 BUILD = os.path.join(ROOT, "tests", "_build")
 
 
-def host_accel(desc, tag, lds_c=True):
+def host_accel(desc, tag, lds_c=True, pack=True):
     """generate -> g++ -> ctypes; returns (accel(q, qd, sp) -> qdd, (lds_slots, statements))."""
     import gen_tree_lane_baked as gen
     os.makedirs(BUILD, exist_ok=True)
     hdr = os.path.join(BUILD, "lane_%s.hpp" % tag)
-    info = gen.generate(desc, hdr, lds_c)
+    info = gen.generate(desc, hdr, lds_c, pack)
     so = os.path.join(BUILD, "liblane_%s.so" % tag)
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", '-DRBL_GENERATED="%s"' % hdr,
                            "-o", so, os.path.join(ROOT, "tests", "hostmath", "tree_lane_host.cpp")])
@@ -43,9 +43,9 @@ def host_accel(desc, tag, lds_c=True):
     return accel, info
 
 
-def check(desc, tag, n=24, tol=2e-4, lds_c=True):
+def check(desc, tag, n=24, tol=2e-4, lds_c=True, pack=True):
     from oracle.physics_np import TendonRobotOracle
-    accel, info = host_accel(desc, tag, lds_c)
+    accel, info = host_accel(desc, tag, lds_c, pack)
     rng = np.random.default_rng(7)
     q = rng.uniform(0.9 * desc.q_lo, 0.9 * desc.q_hi, (n, desc.n_q)).astype(np.float32)
     qd = rng.uniform(-desc.qd_max, desc.qd_max, (n, desc.n_q)).astype(np.float32)
@@ -74,6 +74,44 @@ def test_upper_body_generated_acceleration_matches_oracle():
 def test_upper_body_without_lds_parking_is_the_same_function():
     from gym_roboy_amd.envs.robots import UpperBodyRobot
     check(UpperBodyRobot().get_description(), "upper_body_nolds", lds_c=False)
+
+
+def test_the_two_arms_of_the_upper_body_are_written_as_one_stream_of_pair_values():
+    """Mates: the arms (7 links, 13 tendons each) pair up; the statements drop by a third against the unpaired text, which
+    computes the same function."""
+    import gen_tree_lane_baked as gen
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    desc = UpperBodyRobot().get_description()
+    mate, tmate = gen.mates(desc)
+    assert mate[6:13] == list(range(13, 20)) and mate[13:20] == [-2] * 7 and mate[:6] == [-1] * 6
+    assert tmate[12:25] == list(range(25, 38)) and tmate[25:38] == [-2] * 13 and tmate[:12] == [-1] * 12
+    _, stmts_plain, _, flops_plain, _ = check(desc, "upper_body_unpaired", pack=False)
+    hdr = os.path.join(BUILD, "lane_upper_body_paired.hpp")
+    _, stmts, _, flops, _ = gen.generate(desc, hdr)
+    assert stmts < 0.68 * stmts_plain and abs(flops - flops_plain) < 0.02 * flops_plain
+    text = open(hdr).read()
+    assert text.count("const rbl_f2 ") > 4000 and "RBL_K2(" in text and "rbl_hsum(" in text
+    assert "rbl_f2" not in open(os.path.join(BUILD, "lane_upper_body_unpaired.hpp")).read()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_robots_with_two_structurally_identical_branches(seed):
+    """Random trunk + two branches of the same structure and different constants (+ a third, plain branch): paired text and
+    unpaired text against the oracle; a tendon from one branch to the other forbids the pairing."""
+    import gen_tree_lane_baked as gen
+    from gym_roboy_amd.envs.robots.description import RobotDescription
+    from random_robots import random_mirrored_spec
+    nb = 3 + seed
+    desc = RobotDescription(random_mirrored_spec(seed, n_branch=nb, n_t_branch=3 + seed))
+    mate, tmate = gen.mates(desc)
+    assert mate[2:2 + nb] == list(range(2 + nb, 2 + 2 * nb)) and mate[2 + nb:2 + 2 * nb] == [-2] * nb and all(m == -1 for m in mate[2 + 2 * nb:])
+    assert sum(1 for m in tmate if m >= 0) == 3 + seed == sum(1 for m in tmate if m == -2)
+    check(desc, "mirrored%d" % seed, tol=5e-4)
+    check(desc, "mirrored%d_plain" % seed, tol=5e-4, pack=False)
+    crossed = RobotDescription(random_mirrored_spec(seed, n_branch=nb, n_t_branch=3 + seed, extra_cross=True))
+    mate, tmate = gen.mates(crossed)
+    assert all(m == -1 for m in mate) and all(m == -1 for m in tmate)
+    check(crossed, "mirrored%d_crossed" % seed, tol=5e-4)
 
 
 def test_msj_as_a_joint_tree():

@@ -25,16 +25,26 @@ def load_generator():
     return ctypes.CDLL(so)
 
 
-def generate(desc, path, lds_c=True):
+def generate(desc, path, lds_c=True, pack=True):
     """Write the generated header of `desc` to `path`; returns (lds_slots, statements, hash, flops of one acceleration, most
-    temporaries alive at once)."""
+    temporaries alive at once).  pack: write structurally identical subtrees (the two arms) as one stream of pair values."""
     lib = load_generator()
     slots, stmts, h, fl, live = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_ulonglong(0), ctypes.c_int(0), ctypes.c_int(0)
-    rc = lib.rb_gen_tree_lane(ctypes.byref(desc.as_c_struct()), int(lds_c), path.encode(), ctypes.byref(slots),
+    rc = lib.rb_gen_tree_lane(ctypes.byref(desc.as_c_struct()), int(lds_c) | (0 if pack else 2), path.encode(), ctypes.byref(slots),
                               ctypes.byref(stmts), ctypes.byref(h), ctypes.byref(fl), ctypes.byref(live))
     if rc:
         raise RuntimeError("rb_gen_tree_lane failed: %d" % rc)
     return slots.value, stmts.value, h.value, fl.value, live.value
+
+
+def mates(desc):
+    """(mate of every link, mate of every tendon) as the generator pairs them: -1 none, -2 is a mate."""
+    lib = load_generator()
+    m, tm = (ctypes.c_int * desc.n_q)(), (ctypes.c_int * desc.n_t)()
+    rc = lib.rb_gen_tree_lane_mates(ctypes.byref(desc.as_c_struct()), m, tm)
+    if rc:
+        raise RuntimeError("rb_gen_tree_lane_mates failed: %d" % rc)
+    return list(m), list(tm)
 
 
 def generate_split(desc, path, max_parts=4):
