@@ -592,8 +592,10 @@ class Aba {
             // (the crossings of a tendon with a mate stand for two crossings each: a plain link gets both)
             const bool dbl = key.second != 0;
             for (int a = 0; a < 6; ++a) {
-                if (pr.first >= 0) pT[pr.first][a] = g.sub(pT[pr.first][a], dbl && mate[pr.first] < 0 ? g.hsum(s[a]) : s[a]);
-                if (pr.second >= 0) pT[pr.second][a] = g.add(pT[pr.second][a], dbl && mate[pr.second] < 0 ? g.hsum(s[a]) : s[a]);
+                const bool h1 = pr.first >= 0 && dbl && mate[pr.first] < 0, h2 = pr.second >= 0 && dbl && mate[pr.second] < 0;
+                const Val both = (h1 || h2) ? g.hsum(s[a]) : s[a];
+                if (pr.first >= 0) pT[pr.first][a] = g.sub(pT[pr.first][a], h1 ? both : s[a]);
+                if (pr.second >= 0) pT[pr.second][a] = g.add(pT[pr.second][a], h2 ? both : s[a]);
             }
         }
     }
@@ -737,6 +739,28 @@ inline void find_mates(const Robot &rob, std::vector<int> &mate, std::vector<int
     }
 }
 
+// Parallel tendons: two tendons that cross between the same links in the same order (the six muscles around a shoulder,
+// the three of an elbow) differ in their constants only - via-points, rest length, strength - so they, too, are written as
+// ONE stream of pair values: the link frames are plain values broadcast to both halves, the via-points constant pairs, and
+// the links take both halves of the wrench sum (Aba::wrenches_to_links).  Pairs up what find_mates() left alone, within one
+// part (`part`: the wave that evaluates each tendon in the split form; empty: one function).
+inline void pair_parallel_tendons(const Robot &rob, std::vector<int> &tmate, const std::vector<int> &part = std::vector<int>()) {
+    const int nt = rob.nt;
+    for (int k = 0; k < nt; ++k) {
+        if (tmate[k] != -1) continue;
+        for (int k2 = k + 1; k2 < nt; ++k2) {
+            if (tmate[k2] != -1 || rob.t_cross[k2].size() != rob.t_cross[k].size() || rob.t_cross[k].empty()) continue;
+            if (!part.empty() && part[k] != part[k2]) continue;
+            bool same = true;
+            for (size_t c = 0; c < rob.t_cross[k].size() && same; ++c)
+                same = rob.t_cross[k][c].la == rob.t_cross[k2][c].la && rob.t_cross[k][c].lb == rob.t_cross[k2][c].lb;
+            if (!same) continue;
+            tmate[k] = k2; tmate[k2] = Aba::SKIP;
+            break;
+        }
+    }
+}
+
 // Write the header for robot `d`: ONE function for the whole robot, links in index order (mates together).
 // lds_c: keep the velocity-product accelerations in LDS between the sweeps.  pack: write mates as pair values.
 inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::string &err, bool pack = true) {
@@ -745,6 +769,8 @@ inline int generate(const rb_robot_desc *d, bool lds_c, Generated &out, std::str
     const int nq = rob.nq, nt = rob.nt;
     Gen g;
     Aba A(rob, g, lds_c);
+    // (parallel tendons are NOT paired here: with the arms as pair values the one-wave form is at the edge of its 512 registers,
+    // and the 250 vector instructions the pairing saves come back as scalar moves of constant pairs and AGPR moves - 14.75 vs 14.73 us)
     if (pack) find_mates(rob, A.mate, A.tmate);
     // ---------------- sweep 1: frames, joint axes, velocities, velocity-product accelerations; tendons ----------------
     for (int k = 0; k < nt; ++k) if (rob.t_last[k] < 0 && !A.skip_tendon(k)) A.tendon(k);      // (tendons that touch no moving link)
@@ -896,7 +922,8 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
         Gen &g = gens[q];
         abas[q].reset(new Aba(rob, g, true));
         Aba &A = *abas[q];
-        auto tendons_after = [&](int link) { for (int k = 0; k < nt; ++k) if (part_of_tendon[k] == q && rob.t_last[k] == link) A.tendon(k); };
+        pair_parallel_tendons(rob, A.tmate, part_of_tendon);
+        auto tendons_after = [&](int link) { for (int k = 0; k < nt; ++k) if (part_of_tendon[k] == q && rob.t_last[k] == link && !A.skip_tendon(k)) A.tendon(k); };
         tendons_after(-1);
         for (int j : trunk) { A.forward(j); tendons_after(j); g.barrier(); }
         std::vector<int> own;

@@ -28,6 +28,8 @@ inline float rbl_exp2(float x) { return std::exp2(x); }
 inline float rbl_med3(float x, float lo, float hi) { return std::fmin(std::fmax(x, lo), hi); }
 inline float rbl_max(float a, float b) { return std::fmax(a, b); }
 
+#include "rbl_pair_host.hpp"
+
 #include RBL_GENERATED
 
 extern "C" int tl_dims(int *out) { out[0] = RBL_NQ; out[1] = RBL_NT; out[2] = RBL_NPARTS; out[3] = RBL_PART_LDS; out[4] = RBL_X_SLOTS; return 0; }
