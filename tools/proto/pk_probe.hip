@@ -10,6 +10,7 @@ __global__ void __launch_bounds__(64) k(float *out, int iters, float sb) {
 #pragma unroll
     for (int i = 0; i < CH; ++i) { a[i] = f2{float(threadIdx.x + i) * 1e-3f, 1e-3f}; b[i] = f2{1.0001f, 0.9999f}; c[i] = f2{1e-6f, 2e-6f}; x[i] = i * 1e-3f; }
     unsigned s0 = __float_as_uint(sb), s1 = s0 + 1;
+    const unsigned long long sp = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(s1)) << 32) | __builtin_amdgcn_readfirstlane(s0);
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -25,6 +26,9 @@ __global__ void __launch_bounds__(64) k(float *out, int iters, float sb) {
                 if (FORM == 7) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(a[i]) : "v"(b[i]), "v"(c[i]));
                 if (FORM == 8) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(a[i]) : "v"(b[i]), "v"(c[i]));
                 if (FORM == 9) asm volatile("v_accvgpr_write_b32 a0, %0" :: "v"(x[i]) : "a0");
+                if (FORM == 10) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(sp), "v"(c[i]));        // one SGPR-pair source
+                if (FORM == 11) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[i]) : "s"(sp));
+                if (FORM == 12) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,1]" : "+v"(a[i]) : "v"(b[i]), "v"(c[i]));   // broadcast of a low half
             }
     }
     float s = 0;
@@ -36,7 +40,7 @@ template <int FORM>
 void run(float *out, const char *name) {
     const int iters = 1000;
     printf("%-58s", name);
-    for (int w : {1, 2, 4}) {
+    for (int w : {1, 2, 4, 8}) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(k<FORM>, dim3(1024 * w), dim3(64), 0, 0, out, iters, 1.0001f);
         hipEventRecord(e0);
@@ -58,6 +62,9 @@ int main() {
     run<2>(out, "v_pk_add_f32");
     run<8>(out, "v_pk_mov_b32");
     run<9>(out, "v_accvgpr_write_b32");
+    run<10>(out, "v_pk_fma_f32 with one SGPR-pair source");
+    run<11>(out, "v_pk_mul_f32 with an SGPR-pair source");
+    run<12>(out, "v_pk_fma_f32 with a broadcast source (op_sel_hi)");
     run<3>(out, "v_fmac_f32 + 1 s_mov_b32");
     run<4>(out, "v_fmac_f32 + 2 s_mov_b32");
     run<6>(out, "2 s_mov_b32 + v_pk_fma_f32");
