@@ -53,6 +53,11 @@ __device__ __forceinline__ void dma_dword(const float *gsrc, const float *lds_ds
                  : "=&s"(keep) : "v"(gsrc), "s"(at) : "memory");
 }
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// A value read from a clamped address and then selected (`in range ? value : constant`) is what keeps an MFMA stage free of
+// branches - but hipcc sinks such a read back under the condition: an EXEC-masked block per element (s_and_saveexec, address
+// arithmetic, ds_read, s_or, s_waitcnt lgkmcnt(0)), i.e. one exposed LDS latency per MFMA pair and no scheduling across them.
+// Passing the value through an empty asm statement pins the read where it is written.
+__device__ __forceinline__ float pinned(float v) { asm volatile("" : "+v"(v)); return v; }
 constexpr int PFS = 65;                                   // row stride of the prefetched inputs: [row][sample], conflict-free both ways
 
 struct TrainArgs {
@@ -231,7 +236,7 @@ mlp_grad_kernel(const TrainArgs a) {
             float b0, b1;
             if (PF) {
                 const int kk = k < obs_dim ? k : obs_dim - 1;
-                const float v0 = PB[kk * PFS + col], v1 = PB[kk * PFS + 32 + col];
+                const float v0 = pinned(PB[kk * PFS + col]), v1 = pinned(PB[kk * PFS + 32 + col]);
                 const float pad = k == obs_dim ? 1.0f : 0.0f;
                 b0 = k < obs_dim ? v0 : pad; b1 = k < obs_dim ? v1 : pad;
             } else if (KX == 1) { b0 = XS[col * 33 + k]; b1 = XS[(32 + col) * 33 + k]; }
@@ -389,9 +394,12 @@ mlp_grad_kernel(const TrainArgs a) {
 #pragma unroll
             for (int q = 0; q < OT; ++q) {
                 const int j = 32 * q + col;                  // row on this lane
+                const int jj = j < n_out ? j : 0;            // (an unconditional read + select: a guarded read is a branch per element,
+                                                             //  32 basic blocks that the MFMAs cannot be scheduled across)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float d3t = j < n_out ? S3[(32 * t + unit_of(r) + 4 * half) * S3S + j] : 0.0f;
+                    const float d3raw = pinned(S3[(32 * t + unit_of(r) + 4 * half) * S3S + jj]);
+                    const float d3t = j < n_out ? d3raw : 0.0f;
 #pragma unroll
                     for (int m = 0; m < HT; ++m) G3[q][m] = mfma(d3t, h2T[m][r], G3[q][m]);
                 }
@@ -443,7 +451,7 @@ mlp_grad_kernel(const TrainArgs a) {
                     const int k = 32 * kx + col;
                     float xv;
                     if (PF) {
-                        const float v = PB[(col < obs_dim ? col : obs_dim - 1) * PFS + 32 * t + unit_of(r) + 4 * half];
+                        const float v = pinned(PB[(col < obs_dim ? col : obs_dim - 1) * PFS + 32 * t + unit_of(r) + 4 * half]);
                         xv = col < obs_dim ? v : (col == obs_dim ? 1.0f : 0.0f);
                     } else
                         xv = KX == 1 ? XS[(32 * t + unit_of(r) + 4 * half) * 33 + col]
