@@ -105,9 +105,11 @@ def flops_per_env_step(robot_name, integrator, substeps, kernel=None):
         return None
 
 
-def roofline(robot_name, integrator, substeps, n_envs, bytes_per_env_step, launch_s, workload=None, kernel=None):
-    """Both candidate roofs for one launch of the step kernel; ``bound`` names the one
-    the kernel sits closer to (the larger fraction)."""
+def roofline(robot_name, integrator, substeps, n_envs, bytes_per_env_step, launch_s, workload=None, kernel=None, chains=1):
+    """Both candidate roofs for one STEP of the step kernel over the batch (``launch_s`` = timed region / steps); ``bound``
+    names the one the kernel sits closer to (the larger fraction).  chains = 2: a step is two concurrent launches over half
+    the batch each (rb_rollout_dev's graphs, large ball-joint batches); rocprofv3 then lists half-batch launches whose own
+    durations overlap - the per-step time, not a kernel's duration, is what the fractions are computed from."""
     nbytes = bytes_per_env_step * n_envs
     gbps = nbytes / launch_s / 1e9
     hbm = {"achieved": gbps, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": gbps * 1e9 / HBM_PEAK,
@@ -125,7 +127,8 @@ def roofline(robot_name, integrator, substeps, n_envs, bytes_per_env_step, launc
     traffic, src = pmc_traffic(workload) if workload else (None, None)
     return {"bound": "valu" if top is valu else "hbm", "achieved": top["achieved"], "peak": top["peak"],
             "unit": top["unit"], "frac": top["frac"], "traffic": traffic, "traffic_source": src,
-            "launch_us_events": launch_s * 1e6, "hbm": hbm, "valu": valu}
+            "launch_us_events": launch_s * 1e6, "launches_per_step": chains, "envs_per_launch": n_envs // chains if chains > 1 else n_envs,
+            "hbm": hbm, "valu": valu}
 
 
 def parse():
@@ -283,6 +286,7 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
                       "n_env_steps_allreduced": last[6], "expected": expected,
                       "ok": last[6] == expected and dist.get_world_size() == world}
     stats = [float(x) for x in state["last"].cpu()]
+    chains = sim.rollout_chains() if use_graph else 1
     sim.close()
     robot_name = type(robot).__name__
     kernel_name = (TREE_KERNEL_NAMES if robot_name == "UpperBodyRobot" else KERNEL_NAMES)[info["kernel"]]
@@ -294,7 +298,7 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
         "timed_device_ms": sum(devs) * 1e3,
         "launch_us_events": launch_s * 1e6,
         "roofline": roofline(robot_name, integrator, nsub, n_envs, info["bytes_per_env_step"], launch_s,
-                             name if envs is None and substeps is None else None, kernel_name),
+                             name if envs is None and substeps is None else None, kernel_name, chains),
         "kernel": kernel_name,
         "stats": stats, "collective": collective,
         "finite": bool(np.isfinite(q).all() and np.isfinite(qd).all()),

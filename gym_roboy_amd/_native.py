@@ -73,6 +73,7 @@ SIGNATURES = {
     "rb_state_ptrs": (ctypes.c_int, [_sim, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "rb_step_dev": (ctypes.c_int, [_sim, _vp, ctypes.c_float]),
     "rb_rollout_dev": (ctypes.c_int, [_sim, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]),
+    "rb_rollout_chains": (ctypes.c_int, [_sim]),
     "rb_rollout_fused_dev": (ctypes.c_int, [_sim, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float]),
     "rb_fill_actions_dev": (ctypes.c_int, [_sim, _vp, ctypes.c_uint32]),
     "rb_sample_goals_dev": (ctypes.c_int, [_sim, _vp, _vp]),

@@ -56,10 +56,13 @@ struct Scale8 { float v[NT8]; };
 template <int INTEG, int BLOCK, int UNROLL, bool BK = false>
 __global__ void __launch_bounds__(BLOCK)
 msj_step_env_per_lane(const Const8 c_arg, float *__restrict__ q, float *__restrict__ qd,
-                      uint32_t *__restrict__ feas, const float *__restrict__ act, const Scale8 us, long n) {
+                      uint32_t *__restrict__ feas, const float *__restrict__ act, const Scale8 us, long n, long cnt) {
+    // n: the handle's envs = the stride of the state planes; cnt: the envs of THIS launch - all of them, or one of the two
+    // halves that rb_rollout_dev steps as two independent chains of launches (roboy_sim.hip: chains; the pointers then
+    // point at the half's first env)
     const Const8 &c = robot_consts<BK>(c_arg);
     const long i = long(blockIdx.x) * BLOCK + threadIdx.x;
-    if (i >= n) return;
+    if (i >= cnt) return;
     float qq[3], vv[3], sp[NT8];
     const float4 a0 = reinterpret_cast<const float4 *>(act)[2 * i];
     const float4 a1 = reinterpret_cast<const float4 *>(act)[2 * i + 1];

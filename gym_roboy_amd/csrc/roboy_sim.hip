@@ -393,6 +393,8 @@ struct rb_sim {
     rblj::Kernel split_step_k, split_env_k;
     GoalBox box;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t chain_stream = nullptr;                    // the second chain of rb_rollout_dev (created on first use)
+    hipEvent_t chain_fork = nullptr, chain_join = nullptr;
     float *d_q = nullptr, *d_qd = nullptr;
     uint32_t *d_feas = nullptr, *d_goal_count = nullptr;
     // fused env layer (rb_env_*)
@@ -505,20 +507,53 @@ void maybe_jit(rb_sim *s) {
     if (rbj::build(s->c8, s->jit, s->jit_why)) s->jit_state = 1;
 }
 
-int launch_step(rb_sim *s, const float *d_act, float act_scale) {
+// Chains: rb_rollout_dev steps large ball-joint batches as TWO independent chains of half-batch launches on two streams
+// (two parallel branches of its graph).  One launch per step leaves 1.8 us between launches and ~1.1 us of load / store
+// phases that nothing overlaps (profiles/r3_a/headline_stamps.log: one generation of waves); with two chains one half's
+// gaps lie under the other half's arithmetic: RK4 at 262 144 envs 15.7 -> 12.6 us per step, 524 288 envs 27.7 -> 22.8,
+// 2 M envs 96.7 -> 89.7; Euler 524 288 envs 10.0 -> 7.3, 2 M envs 32.0 -> 29.0 - and slower below (Euler at 262 144 envs
+// 5.8 -> 7.3 us: a chain cannot step faster than ~3.6 us per launch), hence the thresholds (tools/proto/two_chain_probe.hip).
+// Envs are independent, so the results are those of one launch per step, bit for bit.  ROBOY_SIM_CHAINS=1 switches it off.
+#ifndef RB_CHAIN_BATCH_RK4
+#define RB_CHAIN_BATCH_RK4 196608
+#endif
+#ifndef RB_CHAIN_BATCH_EULER
+#define RB_CHAIN_BATCH_EULER 393216
+#endif
+bool chainable(const rb_sim *s) {
+    return !s->tree && !s->ntx && s->kernel != RB_KERNEL_TENDON_PER_LANE && s->n > RB_SMALL_BATCH;
+}
+int rollout_chains(const rb_sim *s) {
+    static const int forced = [] { const char *e = getenv("ROBOY_SIM_CHAINS"); return e ? atoi(e) : 0; }();
+    if (!chainable(s)) return 1;
+    if (forced == 1 || forced == 2) return forced;
+    return s->n >= (s->integrator == RB_EULER ? RB_CHAIN_BATCH_EULER : RB_CHAIN_BATCH_RK4) ? 2 : 1;
+}
+
+// envs [i0, i1) on `stream` (i1 < 0: the whole batch on the handle's stream).  Only the env-per-lane kernels of the ball-joint class
+// take a sub-range (rb_rollout_dev's chains ask for nothing else).
+int launch_step(rb_sim *s, const float *d_act, float act_scale, long i0 = 0, long i1 = -1, hipStream_t stream = nullptr) {
     const long n = s->n;
+    const bool whole = i1 < 0;
+    if (whole) { i0 = 0; i1 = n; stream = s->stream; }
+    const long cnt = i1 - i0;
     // Small batches are latency-bound (a few waves per CU): one wave per
     // workgroup spread over the CUs, tendon loop fully unrolled for ILP.
     // Large batches are VALU-issue-bound: rolled tendon loop (one 16-dword
     // scalar load per trip, 53 VGPRs, 8 waves/SIMD).  Measured: DESIGN.md §7.
     Scale8 us;
     for (int k = 0; k < NT8; ++k) us.v[k] = act_scale * s->c8.ten[k].ksg;
+    // (a sub-range is addressed by shifted pointers: the planes keep their stride n)
+    float *const rq = s->d_q + i0, *const rqd = s->d_qd + i0;
+    uint32_t *const rfeas = s->d_feas + i0;
+    const float *const ract = d_act + size_t(i0) * NT8;
 #define RB_STEP_LAUNCH(INTEG, B, U)                                                                   \
-    hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U>), dim3(blocks_for(n, B)), dim3(B), 0,      \
-                       s->stream, s->c8, s->d_q, s->d_qd, s->d_feas, d_act, us, n)
+    hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U>), dim3(blocks_for(cnt, B)), dim3(B), 0,    \
+                       stream, s->c8, rq, rqd, rfeas, ract, us, n, cnt)
 #define RB_STEP_LAUNCH_BK(INTEG, B, U)                                                                \
-    hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U, true>), dim3(blocks_for(n, B)), dim3(B), 0, \
-                       s->stream, s->c8, s->d_q, s->d_qd, s->d_feas, d_act, us, n)
+    hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U, true>), dim3(blocks_for(cnt, B)), dim3(B), 0, \
+                       stream, s->c8, rq, rqd, rfeas, ract, us, n, cnt)
+    if (!whole && !chainable(s)) return fail(RB_EINVAL, "this kernel form steps whole batches only");
     if (s->tree && tree_wants_split(s) && (s->split_baked || s->split_step_k.state == 1)) {
         // one workgroup of n_parts waves per 64 envs
         const unsigned groups = blocks_for(n, 64);
@@ -597,12 +632,13 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale) {
     } else if (s->jit_state == 1) {
         // msj_step_env_per_lane<INTEG, 256, 4, true> of this robot's own module; same parameter list
         Const8 c8 = s->c8;
-        float *q = s->d_q, *qd = s->d_qd;
-        uint32_t *feas = s->d_feas;
-        long nn = n;
-        void *args[] = {&c8, &q, &qd, &feas, &d_act, &us, &nn};
-        RB_HIP(hipModuleLaunchKernel(s->jit.step[s->integrator == RB_EULER ? 0 : 1], blocks_for(n, 256), 1, 1, 256, 1, 1, 0,
-                                     s->stream, args, nullptr));
+        float *q = rq, *qd = rqd;
+        uint32_t *feas = rfeas;
+        const float *a = ract;
+        long nn = n, cc = cnt;
+        void *args[] = {&c8, &q, &qd, &feas, &a, &us, &nn, &cc};
+        RB_HIP(hipModuleLaunchKernel(s->jit.step[s->integrator == RB_EULER ? 0 : 1], blocks_for(cnt, 256), 1, 1, 256, 1, 1, 0,
+                                     stream, args, nullptr));
     } else {
         if (s->integrator == RB_EULER) RB_STEP_LAUNCH(0, RB_BIG_BLOCK_EULER, RB_BIG_UNROLL_EULER);
         else RB_STEP_LAUNCH(1, RB_BIG_BLOCK_RK4, RB_BIG_UNROLL_RK4);
@@ -790,6 +826,9 @@ void rb_destroy(rb_sim *s) {
     (void)hipFree(s->d_state_rows); (void)hipHostFree(s->h_state_rows);
     (void)hipFree(s->d_goal); (void)hipFree(s->d_ep_ret); (void)hipFree(s->d_ep_sum); (void)hipFree(s->d_ep_cnt);
     (void)hipFree(s->d_step_num); (void)hipFree(s->d_infeas_n); (void)hipFree(s->d_stats);
+    if (s->chain_fork) (void)hipEventDestroy(s->chain_fork);
+    if (s->chain_join) (void)hipEventDestroy(s->chain_join);
+    if (s->chain_stream) (void)hipStreamDestroy(s->chain_stream);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     delete s;
 }
@@ -1017,6 +1056,7 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
     if (reinterpret_cast<uintptr_t>(d_ring) % 16) return fail(RB_EINVAL, "action ring must be 16-byte aligned");
     maybe_jit(s);                    // before any capture below
     const size_t slab = size_t(s->n) * s->n_t;
+    const int chains = use_graph ? rollout_chains(s) : 1;
     int t = 0;
     // graphs of up to 128 per-step kernel nodes, each a whole number of ring turns (so every
     // graph starts at ring slot 0); what is left over (< 8 steps or a partial turn) is launched eagerly
@@ -1026,15 +1066,35 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
         if (chunk < 8) break;
         rb_sim::GraphKey key;
         std::memset(&key, 0, sizeof(key));
-        key.ring_ptr = d_ring; key.ring = ring; key.chunk = chunk; key.scale = act_scale; key.kernel = s->kernel;
+        key.ring_ptr = d_ring; key.ring = ring; key.chunk = chunk; key.scale = act_scale; key.kernel = s->kernel | (chains << 8);
         auto it = s->graphs.find(key);
         if (it == s->graphs.end()) {
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
             if (!s->stream) return fail(RB_EINVAL, "hipGraph capture needs a non-default stream (rb_set_stream)");
+            if (chains == 2 && !s->chain_stream) {
+                RB_HIP(hipStreamCreateWithFlags(&s->chain_stream, hipStreamNonBlocking));
+                RB_HIP(hipEventCreateWithFlags(&s->chain_fork, hipEventDisableTiming));
+                RB_HIP(hipEventCreateWithFlags(&s->chain_join, hipEventDisableTiming));
+            }
             RB_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
             int rc = RB_OK;
-            for (int k = 0; k < chunk && rc == RB_OK; ++k) rc = launch_step(s, d_ring + size_t(k % ring) * slab, act_scale);
+            if (chains == 2) {
+                // two parallel branches: envs [0, mid) step on the handle's stream, [mid, n) on the chain stream, joined at the end
+                const long mid = ((s->n / 2 + 255) / 256) * 256;
+                hipError_t ce = hipEventRecord(s->chain_fork, s->stream);
+                if (ce == hipSuccess) ce = hipStreamWaitEvent(s->chain_stream, s->chain_fork, 0);
+                for (int k = 0; k < chunk && rc == RB_OK && ce == hipSuccess; ++k) {
+                    const float *slab_k = d_ring + size_t(k % ring) * slab;
+                    rc = launch_step(s, slab_k, act_scale, 0, mid, s->stream);
+                    if (rc == RB_OK) rc = launch_step(s, slab_k, act_scale, mid, s->n, s->chain_stream);
+                }
+                if (ce == hipSuccess) ce = hipEventRecord(s->chain_join, s->chain_stream);
+                if (ce == hipSuccess) ce = hipStreamWaitEvent(s->stream, s->chain_join, 0);
+                if (ce != hipSuccess && rc == RB_OK) rc = fail(RB_EHIP, std::string("rollout chains: ") + hipGetErrorString(ce));
+            } else {
+                for (int k = 0; k < chunk && rc == RB_OK; ++k) rc = launch_step(s, d_ring + size_t(k % ring) * slab, act_scale);
+            }
             hipError_t e = hipStreamEndCapture(s->stream, &graph);
             if (rc != RB_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
             if (e != hipSuccess) return fail(RB_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -1056,6 +1116,11 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
     }
     s->env_steps += double(s->n) * n_steps;
     return RB_OK;
+}
+
+int rb_rollout_chains(rb_sim *s) {
+    if (check(s)) return -1;
+    return rollout_chains(s);
 }
 
 int rb_rollout_fused_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float act_scale) {

@@ -153,6 +153,10 @@ class HipBatchSimulation:
         nat.check(self._lib.rb_rollout_dev(self._h, ctypes.c_void_p(d_act_ring), int(ring),
                                            int(n_steps), float(act_scale), int(bool(use_graph))))
 
+    def rollout_chains(self) -> int:
+        """1: rollout_dev's graphs launch once per step over the whole batch; 2: the two halves step as two independent chains."""
+        return int(self._lib.rb_rollout_chains(self._h))
+
     def rollout_fused_dev(self, d_act_ring: int, ring: int, n_steps: int, act_scale: float = 1.0):
         """Open-loop rollout in one launch (state in registers across the steps)."""
         nat.check(self._lib.rb_rollout_fused_dev(self._h, ctypes.c_void_p(d_act_ring), int(ring),

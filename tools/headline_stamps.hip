@@ -91,9 +91,9 @@ float run_product(long n, float *q, float *qd, uint32_t *feas, const float *act,
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int reps = 50;
     const Const8 c = rbk::BAKED_HOST;
-    for (int w = 0; w < 10; ++w) hipLaunchKernelGGL((msj_step_env_per_lane<1, 256, 4, true>), dim3(unsigned(n / 256)), dim3(256), 0, 0, c, q, qd, feas, act, us, n);
+    for (int w = 0; w < 10; ++w) hipLaunchKernelGGL((msj_step_env_per_lane<1, 256, 4, true>), dim3(unsigned(n / 256)), dim3(256), 0, 0, c, q, qd, feas, act, us, n, n);
     hipEventRecord(e0);
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((msj_step_env_per_lane<1, 256, 4, true>), dim3(unsigned(n / 256)), dim3(256), 0, 0, c, q, qd, feas, act, us, n);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((msj_step_env_per_lane<1, 256, 4, true>), dim3(unsigned(n / 256)), dim3(256), 0, 0, c, q, qd, feas, act, us, n, n);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms = 0;
@@ -115,7 +115,7 @@ int main() {
     for (int k = 0; k < 8; ++k) us.v[k] = 0.3f * rbk::BAKED_HOST.ten[k].ksg;
     {   // a second of the product kernel first: the clocks of an idle GPU take that long to settle
         const Const8 c = rbk::BAKED_HOST;
-        for (int r = 0; r < 10000; ++r) hipLaunchKernelGGL((msj_step_env_per_lane<1, 256, 4, true>), dim3(8192), dim3(256), 0, 0, c, q, qd, feas, act, us, nmax);
+        for (int r = 0; r < 10000; ++r) hipLaunchKernelGGL((msj_step_env_per_lane<1, 256, 4, true>), dim3(8192), dim3(256), 0, 0, c, q, qd, feas, act, us, nmax, nmax);
         hipDeviceSynchronize();
     }
     for (long n : {262144l, 2097152l}) {
