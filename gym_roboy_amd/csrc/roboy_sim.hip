@@ -507,7 +507,7 @@ void maybe_jit(rb_sim *s) {
     if (rbj::build(s->c8, s->jit, s->jit_why)) s->jit_state = 1;
 }
 
-// Chains: rb_rollout_dev steps large ball-joint batches as TWO independent chains of half-batch launches on two streams
+// Chains: rb_rollout_dev steps large batches (ball joints; joint trees in the one-wave form) as TWO independent chains of half-batch launches on two streams
 // (two parallel branches of its graph).  One launch per step leaves 1.8 us between launches and ~1.1 us of load / store
 // phases that nothing overlaps (profiles/r3_a/headline_stamps.log: one generation of waves); with two chains one half's
 // gaps lie under the other half's arithmetic: RK4 at 262 144 envs 15.7 -> 12.6 us per step, 524 288 envs 27.7 -> 22.8,
@@ -520,13 +520,25 @@ void maybe_jit(rb_sim *s) {
 #ifndef RB_CHAIN_BATCH_EULER
 #define RB_CHAIN_BATCH_EULER 393216
 #endif
+// (the joint-tree env-per-lane kernel, one wave per SIMD and one generation of waves per 65 536 envs - tools/gpu_r3_chain_tree.sh, upper
+// body: Euler 65 536 envs 18.8 -> 17.6 us, 131 072 envs 36.2 -> 30.3, 262 144 envs 70.3 -> 56.9; RK4 65 536 envs 55.9 -> 56.9,
+// 131 072 envs 109.4 -> 102.5, 262 144 envs 214.6 -> 201.9)
+#ifndef RB_CHAIN_BATCH_TREE_EULER
+#define RB_CHAIN_BATCH_TREE_EULER 65536
+#endif
+#ifndef RB_CHAIN_BATCH_TREE_RK4
+#define RB_CHAIN_BATCH_TREE_RK4 131072
+#endif
+bool tree_use_lane(rb_sim *s, int which);
 bool chainable(const rb_sim *s) {
-    return !s->tree && !s->ntx && s->kernel != RB_KERNEL_TENDON_PER_LANE && s->n > RB_SMALL_BATCH;
+    if (s->tree) return s->kernel == RB_KERNEL_ENV_PER_LANE && tree_use_lane(const_cast<rb_sim *>(s), 0);   // one wave per 64 envs, env-major rows
+    return !s->ntx && s->kernel != RB_KERNEL_TENDON_PER_LANE && s->n > RB_SMALL_BATCH;
 }
 int rollout_chains(const rb_sim *s) {
     static const int forced = [] { const char *e = getenv("ROBOY_SIM_CHAINS"); return e ? atoi(e) : 0; }();
     if (!chainable(s)) return 1;
     if (forced == 1 || forced == 2) return forced;
+    if (s->tree) return s->n >= (s->integrator == RB_EULER ? RB_CHAIN_BATCH_TREE_EULER : RB_CHAIN_BATCH_TREE_RK4) ? 2 : 1;
     return s->n >= (s->integrator == RB_EULER ? RB_CHAIN_BATCH_EULER : RB_CHAIN_BATCH_RK4) ? 2 : 1;
 }
 
@@ -537,6 +549,7 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale, long i0 = 0, lon
     const bool whole = i1 < 0;
     if (whole) { i0 = 0; i1 = n; stream = s->stream; }
     const long cnt = i1 - i0;
+    if (!whole && !chainable(s)) return fail(RB_EINVAL, "this kernel form steps whole batches only");
     // Small batches are latency-bound (a few waves per CU): one wave per
     // workgroup spread over the CUs, tendon loop fully unrolled for ILP.
     // Large batches are VALU-issue-bound: rolled tendon loop (one 16-dword
@@ -553,7 +566,7 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale, long i0 = 0, lon
 #define RB_STEP_LAUNCH_BK(INTEG, B, U)                                                                \
     hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U, true>), dim3(blocks_for(cnt, B)), dim3(B), 0, \
                        stream, s->c8, rq, rqd, rfeas, ract, us, n, cnt)
-    if (!whole && !chainable(s)) return fail(RB_EINVAL, "this kernel form steps whole batches only");
+
     if (s->tree && tree_wants_split(s) && (s->split_baked || s->split_step_k.state == 1)) {
         // one workgroup of n_parts waves per 64 envs
         const unsigned groups = blocks_for(n, 64);
@@ -578,23 +591,25 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale, long i0 = 0, lon
         }
     } else if (s->tree && tree_use_lane(s, 0)) {
         // one wave (64 envs) per workgroup: the LDS regions admit four per CU, one per SIMD, and a small batch spreads over the CUs
-        const unsigned waves = blocks_for(n, 64);
+        // (rows are env-major: a sub-range is the same kernel on shifted pointers and its own env count)
+        const unsigned waves = blocks_for(cnt, 64);
         const size_t lds = rblg::lane_lds_bytes_per_wave(s->lane_gen);
         const float h = s->tree_host.dev.h;
         const int nsub = s->tree_host.dev.nsub;
+        float *tq = s->d_q + size_t(i0) * s->n_q, *tqd = s->d_qd + size_t(i0) * s->n_q;
+        uint32_t *tfeas = s->d_feas + i0;
+        const float *tact = d_act + size_t(i0) * s->n_t;
         if (s->lane_baked) {
             if (s->integrator == RB_EULER)
-                hipLaunchKernelGGL(rbl_baked::tree_lane_step<0>, dim3(waves), dim3(64), lds, s->stream, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, h, nsub, n);
+                hipLaunchKernelGGL(rbl_baked::tree_lane_step<0>, dim3(waves), dim3(64), lds, stream, tq, tqd, tfeas, tact, act_scale, h, nsub, cnt);
             else
-                hipLaunchKernelGGL(rbl_baked::tree_lane_step<1>, dim3(waves), dim3(64), lds, s->stream, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, h, nsub, n);
+                hipLaunchKernelGGL(rbl_baked::tree_lane_step<1>, dim3(waves), dim3(64), lds, stream, tq, tqd, tfeas, tact, act_scale, h, nsub, cnt);
         } else {
-            float *q = s->d_q, *qd = s->d_qd;
-            uint32_t *feas = s->d_feas;
             float hh = h;
             int ns = nsub;
-            long nn = n;
-            void *args[] = {&q, &qd, &feas, &d_act, &act_scale, &hh, &ns, &nn};
-            RB_HIP(hipModuleLaunchKernel(s->lane_step_k.fn, waves, 1, 1, 64, 1, 1, unsigned(lds), s->stream, args, nullptr));
+            long nn = cnt;
+            void *args[] = {&tq, &tqd, &tfeas, &tact, &act_scale, &hh, &ns, &nn};
+            RB_HIP(hipModuleLaunchKernel(s->lane_step_k.fn, waves, 1, 1, 64, 1, 1, unsigned(lds), stream, args, nullptr));
         }
     } else if (s->tree) {
         const int wv = s->tree_waves;

@@ -3,6 +3,8 @@ checked through size-independent properties - the oracle cannot run 2M envs in
 seconds, so: a strided sample of the full batch against the oracle, env
 permutation equivariance, shard invariance, determinism, the rest equilibrium,
 and the boundary behaviour, all on the full-size launch configuration."""
+import os
+
 import numpy as np
 import pytest
 
@@ -58,6 +60,27 @@ def test_rollout_in_two_chains_equals_one_launch_per_step(msj_robot, n, integrat
             sim.fill_actions_dev(d_ring + 4 * r * n * 8, r)
         sim.rollout_dev(d_ring, ring, steps, 0.3, use_graph=use_graph)
         sim.rollout_dev(d_ring, ring, 16, 0.3, use_graph=use_graph)        # a second graph (another chunk size) on the same handle
+        sim.synchronize()
+        outs.append(sim.read_state())
+        sim.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    assert np.abs(outs[0][0]).max() > 0.01
+
+
+def test_joint_tree_rollout_in_two_chains_equals_one_launch_per_step():
+    """The same for the env-per-lane joint-tree kernel (env-major rows: the second chain starts at a row offset)."""
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    robot = UpperBodyRobot()
+    n, ring, steps = 65536 + 100, 2, 24
+    outs = []
+    for use_graph in (False, True):
+        sim = HipBatchSimulation(robot, n, integrator="euler", seed=3)
+        assert sim.info()["kernel"] == 1 and (sim.rollout_chains() == 2 or os.environ.get("ROBOY_SIM_CHAINS") == "1")
+        d_ring = sim.malloc(4 * ring * n * sim.n_t)
+        for r in range(ring):
+            sim.fill_actions_dev(d_ring + 4 * r * n * sim.n_t, r)
+        sim.rollout_dev(d_ring, ring, steps, 0.3, use_graph=use_graph)
         sim.synchronize()
         outs.append(sim.read_state())
         sim.close()
