@@ -393,8 +393,9 @@ struct rb_sim {
     rblj::Kernel split_step_k, split_env_k;
     GoalBox box;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipStream_t chain_stream = nullptr;                    // the second chain of rb_rollout_dev (created on first use)
-    hipEvent_t chain_fork = nullptr, chain_join = nullptr;
+    static constexpr int MAX_CHAINS = 4;
+    hipStream_t chain_stream[MAX_CHAINS] = {};             // the further chains of rb_rollout_dev ([0] unused: the handle's stream; created on first use)
+    hipEvent_t chain_fork = nullptr, chain_join[MAX_CHAINS] = {};
     float *d_q = nullptr, *d_qd = nullptr;
     uint32_t *d_feas = nullptr, *d_goal_count = nullptr;
     // fused env layer (rb_env_*)
@@ -537,7 +538,7 @@ bool chainable(const rb_sim *s) {
 int rollout_chains(const rb_sim *s) {
     static const int forced = [] { const char *e = getenv("ROBOY_SIM_CHAINS"); return e ? atoi(e) : 0; }();
     if (!chainable(s)) return 1;
-    if (forced == 1 || forced == 2) return forced;
+    if (forced >= 1 && forced <= rb_sim::MAX_CHAINS) return forced;
     if (s->tree) return s->n >= (s->integrator == RB_EULER ? RB_CHAIN_BATCH_TREE_EULER : RB_CHAIN_BATCH_TREE_RK4) ? 2 : 1;
     return s->n >= (s->integrator == RB_EULER ? RB_CHAIN_BATCH_EULER : RB_CHAIN_BATCH_RK4) ? 2 : 1;
 }
@@ -842,8 +843,10 @@ void rb_destroy(rb_sim *s) {
     (void)hipFree(s->d_goal); (void)hipFree(s->d_ep_ret); (void)hipFree(s->d_ep_sum); (void)hipFree(s->d_ep_cnt);
     (void)hipFree(s->d_step_num); (void)hipFree(s->d_infeas_n); (void)hipFree(s->d_stats);
     if (s->chain_fork) (void)hipEventDestroy(s->chain_fork);
-    if (s->chain_join) (void)hipEventDestroy(s->chain_join);
-    if (s->chain_stream) (void)hipStreamDestroy(s->chain_stream);
+    for (int c = 1; c < rb_sim::MAX_CHAINS; ++c) {
+        if (s->chain_join[c]) (void)hipEventDestroy(s->chain_join[c]);
+        if (s->chain_stream[c]) (void)hipStreamDestroy(s->chain_stream[c]);
+    }
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     delete s;
 }
@@ -1087,25 +1090,32 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
             if (!s->stream) return fail(RB_EINVAL, "hipGraph capture needs a non-default stream (rb_set_stream)");
-            if (chains == 2 && !s->chain_stream) {
-                RB_HIP(hipStreamCreateWithFlags(&s->chain_stream, hipStreamNonBlocking));
-                RB_HIP(hipEventCreateWithFlags(&s->chain_fork, hipEventDisableTiming));
-                RB_HIP(hipEventCreateWithFlags(&s->chain_join, hipEventDisableTiming));
+            if (chains > 1) {
+                if (!s->chain_fork) RB_HIP(hipEventCreateWithFlags(&s->chain_fork, hipEventDisableTiming));
+                for (int c = 1; c < chains; ++c)
+                    if (!s->chain_stream[c]) {
+                        RB_HIP(hipStreamCreateWithFlags(&s->chain_stream[c], hipStreamNonBlocking));
+                        RB_HIP(hipEventCreateWithFlags(&s->chain_join[c], hipEventDisableTiming));
+                    }
             }
             RB_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
             int rc = RB_OK;
-            if (chains == 2) {
-                // two parallel branches: envs [0, mid) step on the handle's stream, [mid, n) on the chain stream, joined at the end
-                const long mid = ((s->n / 2 + 255) / 256) * 256;
+            if (chains > 1) {
+                // parallel branches: chain c steps envs [lo_c, lo_{c+1}) (cuts at multiples of 256) - chain 0 on the handle's stream,
+                // the others on streams of their own, forked at the start and joined at the end
+                long lo[rb_sim::MAX_CHAINS + 1];
+                for (int c = 0; c <= chains; ++c) lo[c] = c == chains ? s->n : ((s->n * c / chains + 255) / 256) * 256;
                 hipError_t ce = hipEventRecord(s->chain_fork, s->stream);
-                if (ce == hipSuccess) ce = hipStreamWaitEvent(s->chain_stream, s->chain_fork, 0);
+                for (int c = 1; c < chains && ce == hipSuccess; ++c) ce = hipStreamWaitEvent(s->chain_stream[c], s->chain_fork, 0);
                 for (int k = 0; k < chunk && rc == RB_OK && ce == hipSuccess; ++k) {
                     const float *slab_k = d_ring + size_t(k % ring) * slab;
-                    rc = launch_step(s, slab_k, act_scale, 0, mid, s->stream);
-                    if (rc == RB_OK) rc = launch_step(s, slab_k, act_scale, mid, s->n, s->chain_stream);
+                    for (int c = 0; c < chains && rc == RB_OK; ++c)
+                        if (lo[c + 1] > lo[c]) rc = launch_step(s, slab_k, act_scale, lo[c], lo[c + 1], c ? s->chain_stream[c] : s->stream);
                 }
-                if (ce == hipSuccess) ce = hipEventRecord(s->chain_join, s->chain_stream);
-                if (ce == hipSuccess) ce = hipStreamWaitEvent(s->stream, s->chain_join, 0);
+                for (int c = 1; c < chains && ce == hipSuccess; ++c) {
+                    ce = hipEventRecord(s->chain_join[c], s->chain_stream[c]);
+                    if (ce == hipSuccess) ce = hipStreamWaitEvent(s->stream, s->chain_join[c], 0);
+                }
                 if (ce != hipSuccess && rc == RB_OK) rc = fail(RB_EHIP, std::string("rollout chains: ") + hipGetErrorString(ce));
             } else {
                 for (int k = 0; k < chunk && rc == RB_OK; ++k) rc = launch_step(s, d_ring + size_t(k % ring) * slab, act_scale);
