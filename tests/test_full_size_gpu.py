@@ -76,7 +76,7 @@ def test_joint_tree_rollout_in_two_chains_equals_one_launch_per_step():
     outs = []
     for use_graph in (False, True):
         sim = HipBatchSimulation(robot, n, integrator="euler", seed=3)
-        assert sim.info()["kernel"] == 1 and (sim.rollout_chains() == 2 or os.environ.get("ROBOY_SIM_CHAINS") == "1")
+        assert sim.info()["kernel"] == 1 and sim.rollout_chains() == int(os.environ.get("ROBOY_SIM_CHAINS", "2"))
         d_ring = sim.malloc(4 * ring * n * sim.n_t)
         for r in range(ring):
             sim.fill_actions_dev(d_ring + 4 * r * n * sim.n_t, r)
