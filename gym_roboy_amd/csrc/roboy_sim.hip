@@ -513,27 +513,28 @@ void maybe_jit(rb_sim *s) {
     if (rbj::build(s->c8, s->jit, s->jit_why)) s->jit_state = 1;
 }
 
-// Chains: rb_rollout_dev steps large batches (ball joints; joint trees in the one-wave form) as TWO independent chains of half-batch launches on two streams
-// (two parallel branches of its graph).  One launch per step leaves 1.8 us between launches and ~1.1 us of load / store
-// phases that nothing overlaps (profiles/r3_a/headline_stamps.log: one generation of waves); with two chains one half's
-// gaps lie under the other half's arithmetic: RK4 at 262 144 envs 15.7 -> 12.6 us per step, 524 288 envs 27.7 -> 22.8,
-// 2 M envs 96.7 -> 89.7; Euler 524 288 envs 10.0 -> 7.3, 2 M envs 32.0 -> 29.0 - and slower below (Euler at 262 144 envs
-// 5.8 -> 7.3 us: a chain cannot step faster than ~3.6 us per launch), hence the thresholds (tools/proto/two_chain_probe.hip).
-// Envs are independent, so the results are those of one launch per step, bit for bit.  ROBOY_SIM_CHAINS=1 switches it off.
+// Chains: rb_rollout_dev steps large batches (ball joints; joint trees in the one-wave form) as TWO independent chains of
+// half-batch launches on two streams (one linear graph per chain).  One launch per step leaves 1.8 us between launches and
+// ~1.1 us of load / store phases that nothing overlaps (profiles/r3_a/headline_stamps.log: one generation of waves); with two
+// chains one half's gaps lie under the other half's arithmetic, and two concurrent launches interleave their generations of
+// waves.  Measured with bench.py's regions (profiles/r3_a/chain_thresholds.log, us per step, one launch -> two chains):
+// MsjRobot RK4 98 304 envs 9.4 -> 9.0, 196 608 envs 12.8 -> 11.6, 262 144 envs 16.6 -> 13.0, 2 M envs 97 -> 92; Euler 131 072 envs
+// 3.9 -> 4.1 (slower: a chain cannot step faster than ~3.6 us per launch), 262 144 envs 6.9 -> 5.6, 524 288 envs 11.0 -> 7.9,
+// 2 M envs 33.7 -> 30.7; upper body (one wave per 64 envs) Euler 32 768 envs 15.8 -> 15.3, 65 536 envs 18.7 -> 16.8, 262 144 envs
+// 70.3 -> 56.9; RK4 65 536 envs 55.6 -> 53.7, 131 072 envs 109.3 -> 102.1.  Three and four chains are no better anywhere
+// (chain_count.log).  Envs are independent, so the results are those of one launch per step, bit for bit.
+// ROBOY_SIM_CHAINS = 1 switches it off (2-4 force a count).
 #ifndef RB_CHAIN_BATCH_RK4
-#define RB_CHAIN_BATCH_RK4 196608
+#define RB_CHAIN_BATCH_RK4 98304
 #endif
 #ifndef RB_CHAIN_BATCH_EULER
-#define RB_CHAIN_BATCH_EULER 393216
+#define RB_CHAIN_BATCH_EULER 262144
 #endif
-// (the joint-tree env-per-lane kernel, one wave per SIMD and one generation of waves per 65 536 envs - tools/gpu_r3_chain_tree.sh, upper
-// body: Euler 65 536 envs 18.8 -> 17.6 us, 131 072 envs 36.2 -> 30.3, 262 144 envs 70.3 -> 56.9; RK4 65 536 envs 55.9 -> 56.9,
-// 131 072 envs 109.4 -> 102.5, 262 144 envs 214.6 -> 201.9)
 #ifndef RB_CHAIN_BATCH_TREE_EULER
-#define RB_CHAIN_BATCH_TREE_EULER 65536
+#define RB_CHAIN_BATCH_TREE_EULER 32768
 #endif
 #ifndef RB_CHAIN_BATCH_TREE_RK4
-#define RB_CHAIN_BATCH_TREE_RK4 131072
+#define RB_CHAIN_BATCH_TREE_RK4 65536
 #endif
 bool tree_use_lane(rb_sim *s, int which);
 bool chainable(const rb_sim *s) {
