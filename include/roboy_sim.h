@@ -185,10 +185,11 @@ int rb_step_dev(rb_sim *sim, const float *d_act, float act_scale);
  * One kernel per env step either way (a policy sits between steps in real use). */
 int rb_rollout_dev(rb_sim *sim, const float *d_act_ring, int ring, int n_steps,
                    float act_scale, int use_graph);
-/* How rb_rollout_dev's graphs step this handle: 1 = one launch over the whole batch per step; 2 = the two halves of the batch as
- * two independent chains of launches on two streams (large ball-joint batches: one half's launch gaps and load / store phases lie
- * under the other half's arithmetic - RK4 at 262 144 envs 16.6 -> 13.6 us per step; envs are independent, the results are the
- * same bit for bit; ROBOY_SIM_CHAINS=1 switches it off).  Eager rollouts (use_graph = 0) and rb_step_dev always launch once. */
+/* How rb_rollout_dev (use_graph = 1) steps this handle: 1 = one launch over the whole batch per step; 2 = the two halves of the batch
+ * as two independent chains of launches, each a linear graph on its own stream (large batches - ball joints from 98 304 envs RK4 /
+ * 262 144 envs Euler, the one-wave joint-tree form from 32 768 / 65 536: one half's launch gaps and load / store phases lie under the
+ * other half's arithmetic - MsjRobot RK4 at 262 144 envs 16.6 -> 13.0 us per step; envs are independent, the results are the same
+ * bit for bit; ROBOY_SIM_CHAINS=1 switches it off, 2-4 force a count).  Eager rollouts (use_graph = 0) and rb_step_dev launch once. */
 int rb_rollout_chains(rb_sim *sim);
 /* Open-loop rollout fused into ONE launch: every env advances n_steps steps, the
  * state stays in registers in between and only the action of each step is read
