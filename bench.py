@@ -581,7 +581,11 @@ def main():
             "config": {"workload": head["label"], "robot": type(robot).__name__, "envs_per_gpu": head["envs_per_gpu"],
                        "total_envs": head["envs_per_gpu"] * world, "integrator": head["integrator"],
                        "substeps": head["substeps"], "step_size": 0.1,
-                       "launch": "hipGraph replay of per-step kernels" if use_graph else "eager per-step launches",
+                       "launch": (("hipGraph replay of per-step kernels" + ("; %d independent chains of launches over 1/%d of the batch each "
+                                                                               "(rb_rollout_chains: concurrent, same results bit for bit)"
+                                                                               % (head["roofline"]["launches_per_step"], head["roofline"]["launches_per_step"])
+                                                                               if head["roofline"].get("launches_per_step", 1) > 1 else ""))
+                                  if use_graph else "eager per-step launches"),
                        "parallelism": ("env shards x%d, RCCL all-reduce of episode statistics every %d steps and at the "
                                        "end of every timed region" % (world, STATS_EVERY)) if world > 1 else "single GPU",
                        "timing": "median of %d repeats of the %d-step region (barrier + synchronize on both sides, "
@@ -590,8 +594,9 @@ def main():
             "ms_per_step_spread": [head["ms_per_step_min"], head["ms_per_step_max"]],
             "roofline": dict(head["roofline"], kernel=head["kernel"],
                              note="launch_us_events = HIP events on the launch stream around the K per-step launches "
-                                  "of a region, median over the repeats, / K: kernel + kernel boundary; "
-                                  "rocprofv3 kernel-only averages are in profiles/"),
+                                  "of a region, median over the repeats, / K = time per STEP over all envs (kernel + kernel boundary); "
+                                  "with launches_per_step > 1 a step is that many concurrent launches and rocprofv3 lists each "
+                                  "with its own, overlapping duration; rocprofv3 kernel-only averages are in profiles/"),
             "cpu_baseline": cpu,
             "collective": head["collective"],
             "also": also,
