@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("ROBOY_SIM_LIB") or os.path.join(_HERE, "csrc", "libro
 RB_OK, RB_EINVAL, RB_EUNSUPPORTED, RB_EHIP, RB_ENOMEM = range(5)
 RB_EULER, RB_RK4 = 0, 1
 RB_KERNEL_AUTO, RB_KERNEL_ENV_PER_LANE, RB_KERNEL_TENDON_PER_LANE, RB_KERNEL_ENV_PER_WAVE = 0, 1, 2, 3
+RB_KERNEL_ENV_PER_LANE_SPLIT, RB_KERNEL_LANE_PAIR = 4, 5
 
 INTEGRATORS = {"euler": RB_EULER, "semi-implicit-euler": RB_EULER, "rk4": RB_RK4,
                RB_EULER: RB_EULER, RB_RK4: RB_RK4}

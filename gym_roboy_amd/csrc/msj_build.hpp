@@ -115,4 +115,43 @@ int msj_build(const rb_robot_desc *d, double step_size, int nsub, MsjConst<T, NT
     return RB_OK;
 }
 
+// Mirror symmetry of an 8-tendon ball-joint robot (msj_kernels.hpp, "mirror pairs"): a reflection S = diag(1,-1,1) (x-z
+// plane, mirror = 0) or diag(-1,1,1) (y-z plane, mirror = 1) that maps the tendon set onto itself without fixed points -
+// A' = S A, B' = S B bit for bit, same muscle constants - for a body that is itself symmetric (c.simple: principal-axis
+// inertia, centre of mass on z, gravity along z) with symmetric limits on the two joints the reflection turns round.
+// half[k] / image[k]: one tendon of each pair (the lower index, ascending) and its image.
+template <typename T>
+bool find_mirror_pairs(const MsjConst<T, 8> &c, int &mirror, int half[4], int image[4]) {
+    if (!c.simple || c.nt != 8) return false;
+    for (int m = 0; m < 2; ++m) {
+        const int ax = m == 0 ? 1 : 0;                      // the coordinate the reflection negates
+        const int f0 = m == 0 ? 0 : 1, f1 = 2;              // joints whose angle changes sign in the mirror
+        if (c.qlo[f0] != -c.qhi[f0] || c.qlo[f1] != -c.qhi[f1]) continue;
+        int partner[8];
+        bool ok = true;
+        for (int k = 0; k < 8 && ok; ++k) {
+            partner[k] = -1;
+            for (int j = 0; j < 8 && partner[k] < 0; ++j) {
+                const MsjTendon<T> &a = c.ten[k], &b = c.ten[j];
+                bool img = j != k && a.ab2 == b.ab2 && a.il0s == b.il0s && a.elcs == b.elcs && a.ksg == b.ksg && a.fmaxv == b.fmaxv;
+                for (int e = 0; e < 3 && img; ++e) {
+                    const T sg = e == ax ? T(-1) : T(1);
+                    img = b.A[e] == sg * a.A[e] && b.Bv[e] == sg * a.Bv[e] && b.B2[e] == sg * a.B2[e];
+                }
+                if (img) partner[k] = j;
+            }
+            ok = partner[k] >= 0;
+        }
+        for (int k = 0; k < 8 && ok; ++k) ok = partner[partner[k]] == k;      // an involution
+        if (!ok) continue;
+        int n = 0;
+        for (int k = 0; k < 8; ++k)
+            if (k < partner[k]) { if (n < 4) { half[n] = k; image[n] = partner[k]; } ++n; }
+        if (n != 4) continue;
+        mirror = m;
+        return true;
+    }
+    return false;
+}
+
 }  // namespace rb

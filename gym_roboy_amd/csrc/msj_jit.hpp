@@ -28,7 +28,7 @@ namespace rbj {
 
 struct Module {
     hipModule_t mod = nullptr;
-    hipFunction_t step[2] = {nullptr, nullptr};   // msj_step_env_per_lane<INTEG, 256, 8 (Euler) / 4 (RK4), true>
+    hipFunction_t step[2] = {nullptr, nullptr};   // msj_step_env_per_lane<0, 256, 8, true> / msj_step_env_per_lane_rs<1, 256, true>
     hipFunction_t env[2] = {nullptr, nullptr};    // msj_env_step_kernel<INTEG, 256, 8 / 4, Const8, true>
     hipFunction_t rollout[2] = {nullptr, nullptr};   // msj_rollout_fused<INTEG, 256, 4, true>
 };
@@ -265,11 +265,12 @@ inline bool compile_and_load(const std::string &src, const char *file_name, cons
 inline bool build(const rb::MsjConst<float, 8> &c, Module &out, std::string &why) {
     const std::string src = "#define RB_JIT_TABLE " + table_text(c) + "\n#include \"msj_kernels.hpp\"\n";
     constexpr int NK = 6;
-    // (Euler: tendon loop fully unrolled, the constants become literals; RK4 by 4 - roboy_sim.hip: RB_BAKED_UNROLL_*)
-    const char *names[NK] = {"rbk::msj_step_env_per_lane<0, 256, 8, true>", "rbk::msj_step_env_per_lane<1, 256, 4, true>",
+    // (Euler: tendon loop fully unrolled, the constants become literals; RK4: the rolled-stages form, 9 = rbk::RS -
+    // roboy_sim.hip: RB_BAKED_UNROLL_*)
+    const char *names[NK] = {"rbk::msj_step_env_per_lane<0, 256, 8, true>", "rbk::msj_step_env_per_lane_rs<1, 256, true>",
                              "rbk::msj_env_step_kernel<0, 256, 8, rbk::Const8, true>",
-                             "rbk::msj_env_step_kernel<1, 256, 4, rbk::Const8, true>",
-                             "rbk::msj_rollout_fused<0, 256, 8, true>", "rbk::msj_rollout_fused<1, 256, 4, true>"};
+                             "rbk::msj_env_step_kernel<1, 256, 9, rbk::Const8, true>",
+                             "rbk::msj_rollout_fused<0, 256, 8, true>", "rbk::msj_rollout_fused<1, 256, 9, true>"};
     hipFunction_t *slots[NK] = {&out.step[0], &out.step[1], &out.env[0], &out.env[1], &out.rollout[0], &out.rollout[1]};
     if (!compile_and_load(src, "roboy_msj_jit.hip", names, NK, out.mod, slots, why)) { out = Module(); return false; }
     return true;

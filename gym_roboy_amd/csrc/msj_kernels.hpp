@@ -23,6 +23,7 @@ using rbe::goal_value;
 using rbe::mul_then_add;
 
 constexpr int NT8 = 8;
+constexpr int RS = rb::MsjModel<float, 8>::RS;      // UNROLL = RS: the "rolled stages" form (msj_math.hpp: step_rs)
 using Const8 = rb::MsjConst<float, NT8>;
 // ball-joint robots with another tendon count: kernels instantiated for up to NTX
 // tendons, the count itself (c.nt) read at run time (UNROLL = 0, rolled loop)
@@ -90,6 +91,137 @@ msj_step_env_per_lane(const Const8 c_arg, float *__restrict__ q, float *__restri
 
 
 
+// a workgroup's slice of an array as a buffer resource (base and size wave-uniform: scalar registers)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const void *base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+
+// One env per lane, second form (round 4): the integrator's four RK4 stages as a ROLLED loop (integrate_acc), all eight
+// tendons written out inside it one after the other, loads and stores through workgroup buffer resources.  With the stage
+// loop rolled the body is a quarter of the code and ~60 registers, so the tendon loop can be written out WITHOUT the register
+// bill that made the fully unrolled RK4 body of the first form lose (roboy_sim.hip: RB_BAKED_UNROLL_RK4) - and written out on
+// baked constants every tendon constant is a literal instead of the scalar-register operand a rolled loop's table read gives:
+// an instruction with a scalar-register source issues at 4.4 cycles against 2.8 at four waves per SIMD
+// (profiles/r3_a/issue_forms_probe.log), and they were 30 % of the first form's instructions.
+template <int INTEG, int BLOCK, bool BK = false>
+__global__ void __launch_bounds__(BLOCK)
+msj_step_env_per_lane_rs(const Const8 c_arg, float *__restrict__ q, float *__restrict__ qd,
+                         uint32_t *__restrict__ feas, const float *__restrict__ act, const Scale8 us, long n, long cnt) {
+    const Const8 &c = robot_consts<BK>(c_arg);
+    const long env0 = long(blockIdx.x) * BLOCK;
+    const long left = cnt - env0;
+    const int live = int(left < BLOCK ? left : BLOCK);
+    const int le = int(threadIdx.x);
+    if (le >= live) return;
+    const int off = le * 4;
+    float qq[3], vv[3], u[NT8];
+    const __amdgpu_buffer_rsrc_t ra = wg_rsrc(act + env0 * NT8, live * NT8 * 4);
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 a0 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ra, off * NT8, 0, 0));
+    const f4 a1 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ra, off * NT8 + 16, 0, 0));
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        qq[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wg_rsrc(q + j * n + env0, live * 4), off, 0, 0));
+        vv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wg_rsrc(qd + j * n + env0, live * 4), off, 0, 0));
+    }
+    const float a[NT8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+    for (int k = 0; k < NT8; ++k) u[k] = a[k] * us.v[k];
+    const bool ok = rb::MsjModel<float, NT8>::template step_rs<INTEG>(c, qq, vv, u);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(qq[j]), wg_rsrc(q + j * n + env0, live * 4), off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vv[j]), wg_rsrc(qd + j * n + env0, live * 4), off, 0, 0);
+    }
+    __builtin_amdgcn_raw_buffer_store_b32(ok ? 1u : 0u, wg_rsrc(feas + env0, live * 4), off, 0, 0);
+}
+
+
+// ------------------------------------------------------------ two lanes per env: mirror pairs
+// The form between "one env per lane" and "eight lanes per env" (round 4): a pair of adjacent lanes shares an env,
+// each evaluates HALF of the tendons and both carry the rigid-body solve and the integrator.  Twice the waves for the
+// same batch (262 144 envs: 8 per SIMD instead of 4 - what the issue rate of this instruction stream needs), a
+// per-wave instruction chain 0.64x as long (mid-size batches, where every SIMD holds one or two waves).
+//
+// What keeps the two lanes on ONE instruction stream with the robot's constants as literals is a mirror symmetry of the
+// robot: MsjRobot's tendon k' = 7 - k is tendon k reflected in the x-z plane (A' = S A, B' = S B, S = diag(1,-1,1), same
+// muscle), the body's inertia is principal-axis with the centre of mass on z, gravity along z, and the joint limits of
+// the two axes the reflection turns round are symmetric.  A reflection maps solutions to solutions: the env seen in the
+// mirror is the same robot in the state q^ = (-q0, q1, -q2) (rotations about an axis in the mirror plane change sense),
+// and its tendons 0..3 are the real env's tendons 7..4.  So the odd lane of a pair simply steps the MIRRORED env:
+// same code, same constants, its own four tendons - and once per acceleration the lanes swap their torque sums (one
+// DPP quad_perm each way; a torque is a pseudovector: (x, y, z) -> (-x, y, -z) through this mirror), after which both
+// hold the full torque of their own world.  No per-lane tables, no selects, no LDS, no barrier.  The x-z mirror (MIRROR = 0)
+// and the y-z mirror (MIRROR = 1: S = diag(-1,1,1), q^ = (q0, -q1, -q2), torque (x, -y, -z)) are instantiated; the host
+// looks for either in the handle's constants (roboy_sim.hip: find_mirror_pairs) and robots without one keep the other forms.
+struct PairMap { int a[4], d[4]; };      // byte offsets in an action row: a[k] = the even lane's tendon k, a[k] + d[k] = its mirror image (odd lane's tendon k)
+struct Scale4 { float v[4]; };           // act_scale * ksg of the even lane's four tendons (their images' are equal)
+
+template <int CTRL>
+__device__ __forceinline__ float rbk_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+template <int MIRROR>
+struct AccelMirrorHalf {
+    const Const8 &c;
+    const float *u;      // activation offsets of this lane's four tendons
+    __device__ __forceinline__ void operator()(const float q[3], const float qd[3], float qdd[3]) const {
+        using M = rb::MsjModel<float, NT8>;
+        const M::Frame f = M::frame(q, qd);
+        float tx, ty, tz;
+        M::half_torque(c, f, u, tx, ty, tz);
+        // the partner lane's sum (quad_perm [1,0,3,2]), seen through the mirror
+        M::template mirror_combine<MIRROR>(tx, ty, tz, rbk_dpp<0xB1>(tx), rbk_dpp<0xB1>(ty), rbk_dpp<0xB1>(tz));
+        M::rigid_body(c, f, qd, tx, ty, tz, qdd);
+    }
+};
+
+// c_arg.ten[0..3]: the even lane's tendons (the host orders the table; the baked table is used when its own first four
+// tendons are a mirror half).  Loads: both lanes of a pair read the env's six state words (same addresses: one request)
+// and their own four action words; stores: the even lane's.  84 algorithmic bytes per env step as before.
+template <int INTEG, int BLOCK, int MIRROR, bool BK = false>
+__global__ void __launch_bounds__(BLOCK)
+msj_step_mirror_pairs(const Const8 c_arg, const PairMap pm, float *__restrict__ q, float *__restrict__ qd,
+                      uint32_t *__restrict__ feas, const float *__restrict__ act, const Scale4 us, long n, long cnt) {
+    const Const8 &c = robot_consts<BK>(c_arg);
+    // Every access is (workgroup's base, in scalar registers) + (a lane offset of a few hundred bytes) through a buffer
+    // resource whose record count is the workgroup's live bytes: one address register for everything, nothing that has to
+    // stay alive until the stores (seven 64-bit address pairs otherwise: 14 of the 64 registers), and no guard - a load past
+    // the end returns 0, a store past the end is dropped.
+    const long env0 = long(blockIdx.x) * (BLOCK / 2);
+    const long left = cnt - env0;
+    const int live = int(left < BLOCK / 2 ? left : BLOCK / 2);
+    const int le = int(threadIdx.x >> 1);      // the pair's env within the workgroup
+    if (le >= live) return;                    // whole pairs leave together
+    const bool odd = (threadIdx.x & 1) != 0;
+    const int off = le * 4, oddi = int(threadIdx.x & 1);
+    float qq[3], vv[3], u[4];
+    const __amdgpu_buffer_rsrc_t ra = wg_rsrc(act + env0 * NT8, live * NT8 * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, off * NT8 + pm.a[k] + oddi * pm.d[k], 0, 0)) * us.v[k];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        qq[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wg_rsrc(q + j * n + env0, live * 4), off, 0, 0));
+        vv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wg_rsrc(qd + j * n + env0, live * 4), off, 0, 0));
+    }
+    // the odd lane's env is the mirror image: the two joints whose axes lie in the mirror plane change sign
+    constexpr int F0 = MIRROR == 0 ? 0 : 1, F1 = 2;
+    const uint32_t flip = odd ? 0x80000000u : 0u;
+    qq[F0] = __uint_as_float(__float_as_uint(qq[F0]) ^ flip); vv[F0] = __uint_as_float(__float_as_uint(vv[F0]) ^ flip);
+    qq[F1] = __uint_as_float(__float_as_uint(qq[F1]) ^ flip); vv[F1] = __uint_as_float(__float_as_uint(vv[F1]) ^ flip);
+    const bool ok = rb::MsjModel<float, NT8>::template integrate_acc<INTEG>(c, qq, vv, AccelMirrorHalf<MIRROR>{c, u});
+    // the even lane holds the env itself: its stores (the odd lane's offset is pushed past the end: dropped)
+    const int soff = odd ? 0x7fffff00 : le * 4;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(qq[j]), wg_rsrc(q + j * n + env0, live * 4), soff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vv[j]), wg_rsrc(qd + j * n + env0, live * 4), soff, 0, 0);
+    }
+    __builtin_amdgcn_raw_buffer_store_b32(ok ? 1u : 0u, wg_rsrc(feas + env0, live * 4), soff, 0, 0);
+}
+
+
 // Open-loop rollout fused into one launch (rb_rollout_fused_dev): the env-per-lane
 // step applied n_steps times with the state held in registers; per step only the
 // env's 32-byte action record is read.  Instantiated with the same BLOCK/UNROLL
@@ -120,7 +252,9 @@ msj_rollout_fused(const Const8 c_arg, float *__restrict__ q, float *__restrict__
             const float4 *nx = rec + long(slab) * 2 * n;
             a0 = nx[0]; a1 = nx[1];
         }
-        if (UNROLL >= NT8) {
+        if (UNROLL == RS) {
+            ok = rb::MsjModel<float, NT8>::template step_rs<INTEG>(c, qq, vv, sp);
+        } else if (UNROLL >= NT8) {
             ok = rb::MsjModel<float, NT8>::template step_sp<INTEG, UNROLL>(c, qq, vv, rb::SpArray<float, NT8>{sp});
         } else {
 #pragma unroll
@@ -181,7 +315,9 @@ msj_env_step_kernel(const CONST c_arg, const EnvParams e, const GoalBox box,
     const float a[NT8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
     for (int k = 0; k < NT8; ++k) sp[k] = rescale(a[k]) * c.ten[k].ksg;   // set-point -> activation offset
-    if (UNROLL >= NT8) {
+    if (UNROLL == RS) {
+        ok = rb::MsjModel<float, NT8>::template step_rs<INTEG>(c, qq, vv, sp);
+    } else if (UNROLL >= NT8) {
         ok = rb::MsjModel<float, NT8>::template step_sp<INTEG, UNROLL>(c, qq, vv, rb::SpArray<float, NT8>{sp});
     } else {
         // rolled tendon loop: the set-points are indexed at run time, keep them as an LDS column

@@ -327,6 +327,32 @@ struct MsjModel {
         }
     };
 
+    // ---- mirror pairs (two lanes per env; msj_kernels.hpp) --------------------------------------------------------------
+    // A robot with a mirror plane - tendons in mirror-image pairs, symmetric body - seen in the mirror is the same robot
+    // in the state sigma * q (the two joints whose axes lie in the mirror plane change sign), and the images of tendons
+    // half[0..3] are its tendons half[0..3].  MIRROR = 0: the x-z plane, S = diag(1,-1,1), sigma = (-1,+1,-1);
+    // MIRROR = 1: the y-z plane, S = diag(-1,1,1), sigma = (+1,-1,-1).  A torque is a pseudovector: through the mirror it
+    // becomes det(S) S t = sigma * t (component-wise), which is how the two half sums are combined.
+    template <int MIRROR> static RB_HD T mirror_sign(int j) { return (j == 2 || j == MIRROR) ? T(-1) : T(1); }
+    // torque of the FIRST FOUR tendons of c (the host orders the table so that they are one half of the mirror pairs)
+    static RB_HD void half_torque(const C &c, const Frame &f, const T u[4], T &tx, T &ty, T &tz) {
+        tx = T(0); ty = T(0); tz = T(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tendon(c, f, c.ten[k], u[k], tx, ty, tz);
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);     // one tendon's temporaries at a time: 8 waves per SIMD are the latency cover, not ILP
+#endif
+        }
+    }
+    // own half + the partner's half seen through the mirror
+    template <int MIRROR>
+    static RB_HD void mirror_combine(T &tx, T &ty, T &tz, T px, T py, T pz) {
+        tx = MIRROR == 0 ? tx - px : tx + px;
+        ty = MIRROR == 0 ? ty + py : ty - py;
+        tz = tz - pz;
+    }
+
     static RB_HD void sat(const C &c, const T v[3], T out[3]) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) out[j] = tclamp(v[j], -c.qdmax[j], c.qdmax[j]);
@@ -389,6 +415,65 @@ struct MsjModel {
             feasible = limit(c, q, qd) && feasible;
         }
         return feasible;
+    }
+
+    // The same step with RK4's four stages as a ROLLED loop over running sums: 18 values live across an acceleration
+    // (q, qd, the two weighted sums, the stage state) whatever the stage, against the 24-30 the unrolled integrate()
+    // accumulates by its fourth stage, and a quarter of the code - for kernel forms that need 8 waves per SIMD
+    // (<= 64 registers).  Another summation order than integrate(): equal to ~1 ulp, not bit for bit.
+    template <int INTEG, typename ACCEL>
+    static RB_HD bool integrate_acc(const C &c, T q[3], T qd[3], const ACCEL &accel) {
+        if (INTEG == 0) return integrate<0>(c, q, qd, accel);
+        bool feasible = true;
+        const T h = c.h, h6 = c.h * T(1.0 / 6.0);
+        for (int sub = 0; sub < c.nsub; ++sub) {
+            T aq[3] = {T(0), T(0), T(0)}, av[3] = {T(0), T(0), T(0)}, qs[3], vs[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { qs[j] = q[j]; vs[j] = qd[j]; }
+#pragma unroll 1
+            for (int stage = 0; stage < 4; ++stage) {
+                T kq[3], kv[3];
+                sat(c, vs, kq);
+                accel(qs, kq, kv);
+                const T w = (stage == 0 || stage == 3) ? T(1) : T(2);        // weight of this stage in the sums
+                const T a = stage < 2 ? T(0.5) * h : h;                       // step to the next stage's state
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    aq[j] += w * kq[j]; av[j] += w * kv[j];
+                    qs[j] = q[j] + a * kq[j]; vs[j] = qd[j] + a * kv[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { q[j] = q[j] + h6 * aq[j]; qd[j] = qd[j] + h6 * av[j]; }
+            feasible = limit(c, q, qd) && feasible;
+        }
+        return feasible;
+    }
+
+    // All NT tendons written out one after the other, each behind a scheduling barrier (device): one tendon's temporaries
+    // at a time.  The acceleration of the "rolled stages" form (RS) of the kernels, below.
+    struct AccelPinned {
+        const C &c;
+        const T *u;          // activation offsets (prescale() of the set-points)
+        RB_HD void operator()(const T q[3], const T qd[3], T qdd[3]) const {
+            const Frame f = frame(q, qd);
+            T tx = T(0), ty = T(0), tz = T(0);
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                tendon(c, f, c.ten[k], u[k], tx, ty, tz);
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+            rigid_body(c, f, qd, tx, ty, tz, qdd);
+        }
+    };
+    // RS: the integrator's stages as a rolled loop over running sums (integrate_acc), the tendons written out inside it
+    // (AccelPinned).  UNROLL = RS in the kernels' template arguments selects it.
+    static constexpr int RS = 9;
+    template <int INTEG>
+    static RB_HD bool step_rs(const C &c, T q[3], T qd[3], const T u[NT]) {
+        return integrate_acc<INTEG>(c, q, qd, AccelPinned{c, u});
     }
 
     // sp(k): activation offset of tendon k (prescale() of its set-point)

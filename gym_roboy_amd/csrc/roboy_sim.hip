@@ -58,11 +58,18 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // AUTO picks the tendon-per-lane form up to this many envs (measured crossover,
 // profiles/r1_b/sweep.log: Euler 2.9 vs 3.5 us at 8 192 and a tie at 16 384; RK4
 // 6.2 vs 7.0 us at 16 384 and 10.2 vs 7.1 us at 32 768)
+// (round 4, robots with a mirror plane: the two-lanes-per-env form takes over from 4 096 / 12 288 envs - auto_kernel())
 #ifndef RB_TENDON_LANE_BATCH_EULER
 #define RB_TENDON_LANE_BATCH_EULER 8192
 #endif
 #ifndef RB_TENDON_LANE_BATCH_RK4
 #define RB_TENDON_LANE_BATCH_RK4 16384
+#endif
+#ifndef RB_TENDON_LANE_BATCH_PAIR_EULER
+#define RB_TENDON_LANE_BATCH_PAIR_EULER 4096
+#endif
+#ifndef RB_TENDON_LANE_BATCH_PAIR_RK4
+#define RB_TENDON_LANE_BATCH_PAIR_RK4 12288
 #endif
 // launch configuration of the env-per-lane form above RB_SMALL_BATCH envs: workgroup size and
 // unroll factor of the tendon loop, per integrator (A/B: profiles/r2_a/kernel_ab_experiments.log)
@@ -86,8 +93,12 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #ifndef RB_BAKED_UNROLL_EULER
 #define RB_BAKED_UNROLL_EULER 8
 #endif
+// (round 4: RK4 = RS, the "rolled stages" form - msj_math.hpp: step_rs, msj_kernels.hpp: msj_step_env_per_lane_rs - the four
+// stages as a loop over running sums, the eight tendons written out inside it: a quarter of the code and 64 registers, so
+// the constants are literals without the register bill that sank U = 8; 262 144 envs 16.6 -> 15.9 us per step with one launch,
+// 12.9 -> 12.0 us in two chains, 131 072 envs 9.5 -> 8.6 / 7.4 us; profiles/r4_a/rs_sweep.log)
 #ifndef RB_BAKED_UNROLL_RK4
-#define RB_BAKED_UNROLL_RK4 4
+#define RB_BAKED_UNROLL_RK4 RS
 #endif
 // (the fused open-loop rollout is instantiated with the SAME unroll factor as the step kernel - its results are bit-identical to
 // single steps only then: the fully unrolled body contracts its products differently - although it loses to it: it keeps its
@@ -107,6 +118,18 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // the waves of a launch still find a SIMD each (measured crossover against the one-wave form: profiles/r3_a)
 #ifndef RB_TREE_SPLIT_BATCH
 #define RB_TREE_SPLIT_BATCH 16384
+#endif
+// the two-lanes-per-env form launches one-wave workgroups up to this many envs (spread over the CUs), 256-thread ones above
+#ifndef RB_PAIR_SMALL_BATCH
+#define RB_PAIR_SMALL_BATCH 65536
+#endif
+// AUTO picks the two-lanes-per-env form (robots with a mirror plane) above the tendon-per-lane range up to this many envs
+// (0: never; set from the sweep in profiles/r4_a)
+#ifndef RB_PAIR_BATCH_EULER
+#define RB_PAIR_BATCH_EULER 16384
+#endif
+#ifndef RB_PAIR_BATCH_RK4
+#define RB_PAIR_BATCH_RK4 32768
 #endif
 using namespace rbk;    // the env-per-lane kernels (msj_kernels.hpp), EnvParams, GoalBox, ...
 
@@ -375,6 +398,11 @@ struct rb_sim {
     rbj::Module jit;
     std::string jit_why;
     rb::MsjTendon<float> *d_ten = nullptr;   // device copy of c8.ten for the tendon-per-lane form
+    // two lanes per env (msj_kernels.hpp: mirror pairs): available when the robot has a mirror plane (find_mirror_pairs)
+    bool pair_ok = false, pair_baked = false;   // pair_baked: the baked table's own tendons 0..3 are a mirror half (BK instances apply)
+    int pair_mirror = 0;                        // 0: x-z plane, 1: y-z plane
+    int pair_half[4] = {0, 1, 2, 3}, pair_image[4] = {7, 6, 5, 4};   // the even lane's tendons and their mirror images
+    Const8 c8p;                                 // c8 with the even lane's tendons first (kernarg instances)
     int kernel_choice = RB_KERNEL_AUTO;
     // generic joint-tree robots (tree_aba.hpp): a few envs per wave, articulated-body algorithm
     bool tree = false;
@@ -549,6 +577,25 @@ int rollout_chains(const rb_sim *s) {
     return s->n >= (s->integrator == RB_EULER ? RB_CHAIN_BATCH_EULER : RB_CHAIN_BATCH_RK4) ? 2 : 1;
 }
 
+// the env-per-lane step on baked constants: U = RS is a kernel of its own (msj_step_env_per_lane_rs: the rolled-stages form)
+template <int INTEG, int B, int U>
+void launch_baked_step(unsigned blocks, hipStream_t stream, const Const8 &c8, float *q, float *qd, uint32_t *feas, const float *act,
+                       const Scale8 &us, long n, long cnt) {
+    if constexpr (U == RS) hipLaunchKernelGGL((msj_step_env_per_lane_rs<INTEG, B, true>), dim3(blocks), dim3(B), 0, stream, c8, q, qd, feas, act, us, n, cnt);
+    else hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U, true>), dim3(blocks), dim3(B), 0, stream, c8, q, qd, feas, act, us, n, cnt);
+}
+
+// does rb_rollout_dev put one ring turn of plain launches in front of its graphs?  Where a step kernel outlasts the host's
+// launches of a step (~3.5 us each, one per chain) with room to spare: ball joints, RK4, from 196 608 envs on (20-step rollouts
+// of the headline batch 13.7 -> 13.4 us per step; at 131 072 envs and for the joint trees it is a wash: head_sweep.log);
+// ROBOY_SIM_EAGER_HEAD=0 / 1 forces it off / on
+bool rollout_eager_head(const rb_sim *s, int chains) {
+    static const int forced = [] { const char *e = getenv("ROBOY_SIM_EAGER_HEAD"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced != 0;
+    if (s->tree) return false;
+    return !s->ntx && s->integrator == RB_RK4 && s->n >= 196608;
+}
+
 // envs [i0, i1) on `stream` (i1 < 0: the whole batch on the handle's stream).  Only the env-per-lane kernels of the ball-joint class
 // take a sub-range (rb_rollout_dev's chains ask for nothing else).
 int launch_step(rb_sim *s, const float *d_act, float act_scale, long i0 = 0, long i1 = -1, hipStream_t stream = nullptr) {
@@ -571,8 +618,7 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale, long i0 = 0, lon
     hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U>), dim3(blocks_for(cnt, B)), dim3(B), 0,    \
                        stream, s->c8, rq, rqd, rfeas, ract, us, n, cnt)
 #define RB_STEP_LAUNCH_BK(INTEG, B, U)                                                                \
-    hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U, true>), dim3(blocks_for(cnt, B)), dim3(B), 0, \
-                       stream, s->c8, rq, rqd, rfeas, ract, us, n, cnt)
+    launch_baked_step<INTEG, B, U>(blocks_for(cnt, B), stream, s->c8, rq, rqd, rfeas, ract, us, n, cnt)
 
     if (s->tree && tree_wants_split(s) && (s->split_baked || s->split_step_k.state == 1)) {
         // one workgroup of n_parts waves per 64 envs
@@ -637,6 +683,26 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale, long i0 = 0, lon
         if (n <= RB_SMALL_BATCH) { if (s->integrator == RB_EULER) RB_NT_LAUNCH(0, 64); else RB_NT_LAUNCH(1, 64); }
         else                     { if (s->integrator == RB_EULER) RB_NT_LAUNCH(0, 256); else RB_NT_LAUNCH(1, 256); }
 #undef RB_NT_LAUNCH
+    } else if (s->kernel == RB_KERNEL_LANE_PAIR) {
+        // two lanes per env: 128 envs per 256-thread workgroup (64-thread workgroups for small batches: spread over the CUs)
+        PairMap pm;
+        Scale4 us4;
+        for (int k = 0; k < 4; ++k) {
+            pm.a[k] = 4 * s->pair_half[k]; pm.d[k] = 4 * (s->pair_image[k] - s->pair_half[k]);
+            us4.v[k] = act_scale * s->c8.ten[s->pair_half[k]].ksg;
+        }
+#define RB_PAIR_LAUNCH(INTEG, B, M, BKF)                                                                          \
+    hipLaunchKernelGGL((msj_step_mirror_pairs<INTEG, B, M, BKF>), dim3(blocks_for(2 * cnt, B)), dim3(B), 0, stream, \
+                       s->c8p, pm, rq, rqd, rfeas, ract, us4, n, cnt)
+#define RB_PAIR_LAUNCH_B(INTEG, M, BKF)                                                                           \
+    do { if (n <= RB_PAIR_SMALL_BATCH) RB_PAIR_LAUNCH(INTEG, 64, M, BKF); else RB_PAIR_LAUNCH(INTEG, 256, M, BKF); } while (0)
+#define RB_PAIR_LAUNCH_M(INTEG, BKF)                                                                              \
+    do { if (s->pair_mirror == 0) RB_PAIR_LAUNCH_B(INTEG, 0, BKF); else RB_PAIR_LAUNCH_B(INTEG, 1, BKF); } while (0)
+        if (s->pair_baked) { if (s->integrator == RB_EULER) RB_PAIR_LAUNCH_M(0, true); else RB_PAIR_LAUNCH_M(1, true); }
+        else               { if (s->integrator == RB_EULER) RB_PAIR_LAUNCH_M(0, false); else RB_PAIR_LAUNCH_M(1, false); }
+#undef RB_PAIR_LAUNCH_M
+#undef RB_PAIR_LAUNCH_B
+#undef RB_PAIR_LAUNCH
     } else if (s->kernel == RB_KERNEL_TENDON_PER_LANE) {
         const unsigned g = blocks_for(n * NT8, 64);
         if (s->integrator == RB_EULER)
@@ -671,6 +737,21 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale, long i0 = 0, lon
     return RB_OK;
 }
 
+// AUTO for 8-tendon ball-joint robots: eight lanes per env for small batches (latency), then - if the robot has a mirror
+// plane - two lanes per env, one env per lane otherwise / beyond (thresholds measured: profiles/r4_a)
+int auto_kernel(const rb_sim *s) {
+    // measured (profiles/r4_a/mid_sweep.log, us per step, tendon per lane / two lanes per env / env per lane): RK4 8 192 envs
+    // 3.39 / 4.11 / 5.07, 16 384 envs 4.63 / 4.23 / 5.11, 32 768 envs 7.25 / 4.50 / 5.23, 49 152 envs 9.84 / 6.19 / 5.35; Euler
+    // 4 096 envs 2.21 / 2.22 / 2.43, 8 192 envs 2.34 / 2.25 / 2.45, 16 384 envs 2.79 / 2.38 / 2.49, 32 768 envs 3.58 / 2.68 / 2.62
+    const bool euler = s->integrator == RB_EULER;
+    if (s->pair_ok) {
+        if (s->n <= (euler ? RB_TENDON_LANE_BATCH_PAIR_EULER : RB_TENDON_LANE_BATCH_PAIR_RK4)) return RB_KERNEL_TENDON_PER_LANE;
+        if (s->n <= (euler ? RB_PAIR_BATCH_EULER : RB_PAIR_BATCH_RK4)) return RB_KERNEL_LANE_PAIR;
+        return RB_KERNEL_ENV_PER_LANE;
+    }
+    return s->n <= (euler ? RB_TENDON_LANE_BATCH_EULER : RB_TENDON_LANE_BATCH_RK4) ? RB_KERNEL_TENDON_PER_LANE : RB_KERNEL_ENV_PER_LANE;
+}
+
 int check(const rb_sim *s) {
     if (!s) return fail(RB_EINVAL, "null simulation handle");
     return RB_OK;
@@ -688,6 +769,25 @@ int read_state_host(rb_sim *s, float *q, float *qd, uint8_t *feasible) {
     if (q) std::memcpy(q, h, plane);
     if (qd) std::memcpy(qd, h + plane, plane);
     if (feasible) std::memcpy(feasible, h + 2 * plane, size_t(n));
+    return RB_OK;
+}
+
+// Every stream this handle may still have work on - the stream in use (the caller's after rb_set_stream), its own, and the
+// chain streams of rb_rollout_dev / rb_env_step_dev - drained; then the cached graph executables may go.
+int drain(rb_sim *s) {
+    RB_HIP(hipSetDevice(s->device));
+    RB_HIP(hipStreamSynchronize(s->stream));
+    if (s->own_stream && s->own_stream != s->stream) RB_HIP(hipStreamSynchronize(s->own_stream));
+    for (int c = 1; c < rb_sim::MAX_CHAINS; ++c)
+        if (s->chain_stream[c]) RB_HIP(hipStreamSynchronize(s->chain_stream[c]));
+    return RB_OK;
+}
+int drop_graphs(rb_sim *s) {
+    if (s->graphs.empty()) return RB_OK;
+    int rc = drain(s);                 // none may be in flight when destroyed
+    if (rc) return rc;
+    for (auto &kv : s->graphs) kv.second.destroy();
+    s->graphs.clear();
     return RB_OK;
 }
 
@@ -730,6 +830,13 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
                   a.nsub == b.nsub && a.simple == b.simple && a.nt == b.nt;
         for (int k = 0; k < NT8 && eq; ++k) eq = same(a.ten[k].A, b.ten[k].A, 16);
         s->baked = eq;
+        s->pair_ok = rb::find_mirror_pairs(s->c8, s->pair_mirror, s->pair_half, s->pair_image);
+        if (s->pair_ok) {
+            s->c8p = s->c8;
+            bool first_four = true;
+            for (int k = 0; k < 4; ++k) { s->c8p.ten[k] = s->c8.ten[s->pair_half[k]]; first_four = first_four && s->pair_half[k] == k; }
+            s->pair_baked = s->baked && first_four;      // the BK instances read BAKED.ten[0..3]
+        }
     }
     if (rc == RB_EUNSUPPORTED && robot->n_t != NT8) {
         // a ball-joint robot with another tendon count: same closed form, run-time count
@@ -837,8 +944,9 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
 
 void rb_destroy(rb_sim *s) {
     if (!s) return;
-    (void)hipSetDevice(s->device);
-    if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
+    // whichever stream is in use (a caller's after rb_set_stream - it must still exist), the handle's own and the chain
+    // streams: nothing of this handle may be in flight when its graph executables, streams and buffers go
+    (void)drain(s);
     for (auto &kv : s->graphs) kv.second.destroy();
     rbj::unload(s->jit);
     rblj::unload(s->lane_step_k); rblj::unload(s->lane_env_k); rblj::unload(s->split_step_k); rblj::unload(s->split_env_k);
@@ -925,56 +1033,52 @@ int rb_specialization(rb_sim *s) {
 
 int rb_select_kernel(rb_sim *s, int kernel) {
     if (check(s)) return RB_EINVAL;
-    if (kernel < RB_KERNEL_AUTO || kernel > RB_KERNEL_ENV_PER_LANE_SPLIT) return fail(RB_EINVAL, "unknown kernel variant");
+    // validate first: a refused request leaves the handle as it was (kernel_choice, rb_info, the graph cache)
+    if (kernel < RB_KERNEL_AUTO || kernel > RB_KERNEL_LANE_PAIR) return fail(RB_EINVAL, "unknown kernel variant");
+    if (kernel == RB_KERNEL_LANE_PAIR && !(s->pair_ok && !s->tree && !s->ntx))
+        return fail(RB_EUNSUPPORTED, "the two-lanes-per-env form needs an 8-tendon ball-joint robot with a mirror plane (tendons in mirror-image pairs, "
+                                     "principal-axis inertia, symmetric joint limits)");
     if (kernel == RB_KERNEL_ENV_PER_LANE_SPLIT && !(s->tree && s->split_ok))
         return fail(RB_EUNSUPPORTED, "no split form for this robot (a ball-joint robot, a serial chain, or branches tied together by tendons)");
-    s->kernel_choice = kernel;
     if (s->tree) {
         if (kernel == RB_KERNEL_TENDON_PER_LANE) return fail(RB_EUNSUPPORTED, "joint-tree robots have no tendon-per-lane kernel");
         if (kernel == RB_KERNEL_ENV_PER_LANE && !s->lane_ok) return fail(RB_EUNSUPPORTED, "no env-per-lane kernel can be generated for this robot");
-        if (!s->graphs.empty()) { RB_HIP(hipSetDevice(s->device)); RB_HIP(hipStreamSynchronize(s->stream)); }
-        for (auto &kv : s->graphs) kv.second.destroy();
-        s->graphs.clear();
-        s->kernel_choice = kernel;
+        const int before = s->kernel_choice;
+        s->kernel_choice = kernel;           // lane_kernel() / tree_wants_*() read it; restored on every failure below
         if (kernel == RB_KERNEL_ENV_PER_LANE && !s->lane_baked) {
             // an explicit choice builds the step kernel now (and fails loudly if that is not possible)
-            if (capturing(s)) return fail(RB_EINVAL, "the env-per-lane kernels cannot be built during a stream capture");
+            if (capturing(s)) { s->kernel_choice = before; return fail(RB_EINVAL, "the env-per-lane kernels cannot be built during a stream capture"); }
             if (lane_kernel(s, 0)->state != 1) {
-                s->kernel_choice = RB_KERNEL_AUTO;
+                s->kernel_choice = before;
                 return fail(RB_EUNSUPPORTED, "env-per-lane kernel not available: " + s->lane_step_k.why);
             }
         }
         if (kernel == RB_KERNEL_ENV_PER_LANE_SPLIT && !s->split_baked) {
-            if (capturing(s)) return fail(RB_EINVAL, "the split-form kernel cannot be built during a stream capture");
+            if (capturing(s)) { s->kernel_choice = before; return fail(RB_EINVAL, "the split-form kernel cannot be built during a stream capture"); }
             if (!build_split_kernel(s)) {
-                s->kernel_choice = RB_KERNEL_AUTO;
+                s->kernel_choice = before;
                 return fail(RB_EUNSUPPORTED, "split-form kernel not available: " + s->split_step_k.why);
             }
         }
+        int rc = drop_graphs(s);             // graphs captured with another variant must not be replayed
+        if (rc) { s->kernel_choice = before; return rc; }
         s->kernel = tree_wants_split(s) ? RB_KERNEL_ENV_PER_LANE_SPLIT : (tree_wants_lane(s) ? RB_KERNEL_ENV_PER_LANE : RB_KERNEL_ENV_PER_WAVE);
         return RB_OK;
     }
     if (kernel == RB_KERNEL_ENV_PER_WAVE) return fail(RB_EUNSUPPORTED, "ball-joint robots have no env-per-wave kernel");
-    if (s->ntx) {   // 8 lanes per env is the 8-tendon form
-        if (kernel == RB_KERNEL_TENDON_PER_LANE)
-            return fail(RB_EUNSUPPORTED, "the tendon-per-lane kernel is built for 8 tendons");
-        s->kernel = RB_KERNEL_ENV_PER_LANE;
-        return RB_OK;
-    }
-    s->kernel = kernel != RB_KERNEL_AUTO ? kernel
-                : (s->n <= (s->integrator == RB_EULER ? RB_TENDON_LANE_BATCH_EULER : RB_TENDON_LANE_BATCH_RK4)
-                       ? RB_KERNEL_TENDON_PER_LANE : RB_KERNEL_ENV_PER_LANE);
-    // graphs captured with the other variant must not be replayed (and none may be in flight when destroyed)
-    if (!s->graphs.empty()) { RB_HIP(hipSetDevice(s->device)); RB_HIP(hipStreamSynchronize(s->stream)); }
-    for (auto &kv : s->graphs) kv.second.destroy();
-    s->graphs.clear();
+    if (s->ntx && kernel == RB_KERNEL_TENDON_PER_LANE)    // 8 lanes per env is the 8-tendon form
+        return fail(RB_EUNSUPPORTED, "the tendon-per-lane kernel is built for 8 tendons");
+    int rc = drop_graphs(s);
+    if (rc) return rc;
+    s->kernel_choice = kernel;
+    if (s->ntx) { s->kernel = RB_KERNEL_ENV_PER_LANE; return RB_OK; }
+    s->kernel = kernel != RB_KERNEL_AUTO ? kernel : auto_kernel(s);
     return RB_OK;
 }
 
 int rb_set_stream(rb_sim *s, void *hip_stream) {
     if (check(s)) return RB_EINVAL;
-    RB_HIP(hipSetDevice(s->device));
-    RB_HIP(hipStreamSynchronize(s->stream));
+    { int rc = drain(s); if (rc) return rc; }                            // the previous stream and the chain streams
     if (hip_stream == RB_STREAM_DEVICE_DEFAULT) s->stream = nullptr;     // the null stream
     else s->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->own_stream;
     return RB_OK;
@@ -1081,7 +1185,56 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
     maybe_jit(s);                    // before any capture below
     const size_t slab = size_t(s->n) * s->n_t;
     const int chains = use_graph ? rollout_chains(s) : 1;
+    if (use_graph && n_steps >= 8 && !s->stream) return fail(RB_EINVAL, "hipGraph capture needs a non-default stream (rb_set_stream)");
+    // chain c steps envs [lo_c, lo_{c+1}) (cuts at multiples of 256) on its own stream (chain 0: the handle's)
+    long lo[rb_sim::MAX_CHAINS + 1];
+    for (int c = 0; c <= chains; ++c) lo[c] = c == chains ? s->n : (chains == 1 ? 0 : ((s->n * c / chains + 255) / 256) * 256);
+    auto chain_stream = [&](int c) { return c ? s->chain_stream[c] : s->stream; };
+    bool forked = false;
+    auto fork = [&]() -> int {       // the further chains start behind everything the handle's stream holds so far
+        if (chains == 1 || forked) return RB_OK;
+        if (!s->chain_fork) RB_HIP(hipEventCreateWithFlags(&s->chain_fork, hipEventDisableTiming));
+        for (int c = 1; c < chains; ++c)
+            if (!s->chain_stream[c]) {
+                RB_HIP(hipStreamCreateWithFlags(&s->chain_stream[c], hipStreamNonBlocking));
+                RB_HIP(hipEventCreateWithFlags(&s->chain_join[c], hipEventDisableTiming));
+            }
+        // (a stream that reports everything done has nothing for the chains to wait for: saves the two calls' ~5 us of host time in
+        // front of the first launch of a short rollout)
+        if (capturing(s) || hipStreamQuery(s->stream) != hipSuccess) {
+            RB_HIP(hipEventRecord(s->chain_fork, s->stream));
+            for (int c = 1; c < chains; ++c) if (lo[c + 1] > lo[c]) RB_HIP(hipStreamWaitEvent(s->chain_stream[c], s->chain_fork, 0));
+        }
+        (void)hipGetLastError();         // hipErrorNotReady from the query is not an error
+        forked = true;
+        return RB_OK;
+    };
+    auto join = [&]() -> int {       // ... and the handle's stream continues behind all of them
+        if (!forked) return RB_OK;
+        for (int c = 1; c < chains; ++c)
+            if (lo[c + 1] > lo[c]) {
+                RB_HIP(hipEventRecord(s->chain_join[c], s->chain_stream[c]));
+                RB_HIP(hipStreamWaitEvent(s->stream, s->chain_join[c], 0));
+            }
+        forked = false;
+        return RB_OK;
+    };
     int t = 0;
+    // An eager head in front of the graphs (large batches whose step kernel outlasts a host-side launch): replaying a graph
+    // costs ~10 us between the call and its first kernel, and the second chain's graph is launched after the first one's - a
+    // 20-step rollout of the headline batch lost 38 us to that (13.9 instead of 12.0 us per step, profiles/r4_a).  One ring
+    // turn of plain launches, the chains taking turns, has the device busy after ~4 us; the graphs are enqueued behind them
+    // while they run.  The same kernels on the same streams: nothing changes in the results.
+    if (use_graph && rollout_eager_head(s, chains) && n_steps >= ring + 8 && ring <= 8) {
+        int rc = fork();
+        for (int k = 0; k < ring && rc == RB_OK; ++k)
+            for (int c = chains - 1; c >= 0 && rc == RB_OK; --c)      // the further chains first (below)
+                if (lo[c + 1] > lo[c])
+                    rc = chains == 1 ? launch_step(s, d_ring + size_t(k) * slab, act_scale)
+                                     : launch_step(s, d_ring + size_t(k) * slab, act_scale, lo[c], lo[c + 1], chain_stream(c));
+        if (rc) return rc;
+        t = ring;
+    }
     // graphs of up to 128 per-step kernel nodes, each a whole number of ring turns (so every
     // graph starts at ring slot 0); what is left over (< 8 steps or a partial turn) is launched eagerly
     while (use_graph) {
@@ -1093,25 +1246,15 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
         key.ring_ptr = d_ring; key.ring = ring; key.chunk = chunk; key.scale = act_scale; key.kernel = s->kernel | (chains << 8);
         auto it = s->graphs.find(key);
         if (it == s->graphs.end()) {
-            if (!s->stream) return fail(RB_EINVAL, "hipGraph capture needs a non-default stream (rb_set_stream)");
-            if (chains > 1) {
-                if (!s->chain_fork) RB_HIP(hipEventCreateWithFlags(&s->chain_fork, hipEventDisableTiming));
-                for (int c = 1; c < chains; ++c)
-                    if (!s->chain_stream[c]) {
-                        RB_HIP(hipStreamCreateWithFlags(&s->chain_stream[c], hipStreamNonBlocking));
-                        RB_HIP(hipEventCreateWithFlags(&s->chain_join[c], hipEventDisableTiming));
-                    }
-            }
-            // chain c steps envs [lo_c, lo_{c+1}) (cuts at multiples of 256): one linear graph of `chunk` launches per chain, captured
-            // on the chain's own stream (chain 0: the handle's).  (One graph with parallel branches is replayed badly - its second
-            // branch starts late: 16.2 us per step in a 20-step region against 13.9 for two linear graphs on two streams.)
-            long lo[rb_sim::MAX_CHAINS + 1];
-            for (int c = 0; c <= chains; ++c) lo[c] = c == chains ? s->n : (chains == 1 ? 0 : ((s->n * c / chains + 255) / 256) * 256);
+            { int rc = fork(); if (rc) return rc; }     // creates the chain streams
+            // one LINEAR graph of `chunk` launches per chain, captured on the chain's own stream.  (One graph with parallel
+            // branches is replayed badly - its second branch starts late: 16.2 us per step in a 20-step region against 13.9 for two
+            // linear graphs on two streams.)
             rb_sim::ChainGraphs cg;
             cg.chains = chains;
             for (int c = 0; c < chains; ++c) {
                 if (lo[c + 1] <= lo[c]) continue;
-                hipStream_t st = c ? s->chain_stream[c] : s->stream;
+                hipStream_t st = chain_stream(c);
                 hipGraph_t graph = nullptr;
                 hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
                 if (e != hipSuccess) { cg.destroy(); return fail(RB_EHIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
@@ -1128,27 +1271,23 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
                 if (e != hipSuccess) { cg.destroy(); return fail(RB_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
             }
             if (s->graphs.size() >= 16) {   // bound the cache: callers that keep changing slabs get re-captures, not a leak
-                RB_HIP(hipStreamSynchronize(s->stream));   // a cached exec may still be in flight (launched by an earlier chunk)
-                for (auto &kv : s->graphs) kv.second.destroy();
-                s->graphs.clear();
+                int rc = drop_graphs(s);                   // a cached exec may still be in flight (launched by an earlier chunk, on any chain)
+                if (rc) { cg.destroy(); return rc; }
+                forked = false;                            // (drained: fork again below)
             }
             it = s->graphs.emplace(key, cg).first;
         }
-        // all the chunks of this size: the chains are forked once, replay their graphs back to back, and join at the end
+        // all the chunks of this size: the chains replay their graphs back to back; they are joined once, at the end
         const rb_sim::ChainGraphs &cg = it->second;
-        if (cg.chains > 1) {
-            RB_HIP(hipEventRecord(s->chain_fork, s->stream));
-            for (int c = 1; c < cg.chains; ++c) if (cg.exec[c]) RB_HIP(hipStreamWaitEvent(s->chain_stream[c], s->chain_fork, 0));
-        }
+        { int rc = fork(); if (rc) return rc; }
+        // The further chains' graphs are launched FIRST: with the handle's stream first its chain ran ahead and the other one
+        // finished 13 us behind it - a 20-step rollout of the headline batch took 308 us against 272 us in this order, where the
+        // two chains end within 6 us of each other (tools/proto/region_timeline_probe.hip, profiles/r4_a/region_timeline.log)
         for (; t + chunk <= n_steps; t += chunk)
-            for (int c = 0; c < cg.chains; ++c)
-                if (cg.exec[c]) RB_HIP(hipGraphLaunch(cg.exec[c], c ? s->chain_stream[c] : s->stream));
-        for (int c = 1; c < cg.chains; ++c)
-            if (cg.exec[c]) {
-                RB_HIP(hipEventRecord(s->chain_join[c], s->chain_stream[c]));
-                RB_HIP(hipStreamWaitEvent(s->stream, s->chain_join[c], 0));
-            }
+            for (int c = cg.chains - 1; c >= 0; --c)
+                if (cg.exec[c]) RB_HIP(hipGraphLaunch(cg.exec[c], chain_stream(c)));
     }
+    { int rc = join(); if (rc) return rc; }
     for (; t < n_steps; ++t) {
         int rc = launch_step(s, d_ring + size_t(t % ring) * slab, act_scale);
         if (rc) return rc;

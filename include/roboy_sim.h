@@ -56,9 +56,13 @@ enum rb_kernel {
     RB_KERNEL_ENV_PER_LANE = 1,    /* one env per lane: throughput form        */
     RB_KERNEL_TENDON_PER_LANE = 2, /* 8 lanes per env + DPP reductions: latency form */
     RB_KERNEL_ENV_PER_WAVE = 3,    /* generic joint-tree robots: a few envs per wave, eight lanes per link, LDS */
-    RB_KERNEL_ENV_PER_LANE_SPLIT = 4 /* joint trees, small batches: one env per lane, but several waves per group of 64
+    RB_KERNEL_ENV_PER_LANE_SPLIT = 4,/* joint trees, small batches: one env per lane, but several waves per group of 64
                                       envs - one per set of branches of the tree - so that a step waits for a part of
                                       the instruction stream only */
+    RB_KERNEL_LANE_PAIR = 5          /* ball-joint robots with a mirror plane (MsjRobot): two lanes per env - the odd lane
+                                      steps the env's mirror image with the same code and constants, four tendons each,
+                                      torque sums swapped by DPP: twice the waves of the env-per-lane form for the same
+                                      batch, a per-wave instruction chain 0.64x as long */
 };
 
 /* Robot description, format "roboy-tendon-robot/1" (Python

@@ -50,3 +50,62 @@ extern "C" int hm_step_f32(const rb_robot_desc *d, double step_size, int nsub, i
                            float *q, float *qd, const float *sp, unsigned char *feas) {
     return run<float>(d, step_size, nsub, integ, n, q, qd, sp, feas);
 }
+
+// ---- mirror pairs (the two-lanes-per-env form of msj_kernels.hpp) emulated on the host: the even lane's half torque from the
+// env's state, the odd lane's from the mirror image of that state (same constants, the images' set-points), combined as
+// the kernel combines them, then the rolled RK4 / Euler of integrate_acc.  What the DPP swap does is the only piece
+// that is not this code.  Returns 0, or 1 if the robot has no mirror plane; *mirror_out gets the plane found.
+template <typename T, int MIRROR>
+struct HostPairAccel {
+    const rb::MsjConst<T, 8> &c;   // the even lane's tendons first
+    const T *u_even, *u_odd;
+    void operator()(const T q[3], const T qd[3], T qdd[3]) const {
+        using M = rb::MsjModel<T, 8>;
+        T qm[3], vm[3];
+        for (int j = 0; j < 3; ++j) { qm[j] = M::template mirror_sign<MIRROR>(j) * q[j]; vm[j] = M::template mirror_sign<MIRROR>(j) * qd[j]; }
+        const typename M::Frame f = M::frame(q, qd), fm = M::frame(qm, vm);
+        T tx, ty, tz, px, py, pz;
+        M::half_torque(c, f, u_even, tx, ty, tz);
+        M::half_torque(c, fm, u_odd, px, py, pz);
+        M::template mirror_combine<MIRROR>(tx, ty, tz, px, py, pz);
+        M::rigid_body(c, f, qd, tx, ty, tz, qdd);
+    }
+};
+template <typename T>
+static int run_pairs(const rb_robot_desc *d, double step_size, int nsub, int integ, long n,
+                     T *q, T *qd, const T *sp, unsigned char *feas, int *mirror_out, int *half_out) {
+    std::string err;
+    rb::MsjConst<T, 8> c;
+    int rc = rb::msj_build<T, 8>(d, step_size, nsub, &c, err);
+    if (rc) return rc;
+    // the plane is looked for in the fp32 constants, as the library does (MsjRobot's via-points are mirror images bit for bit
+    // in fp32; in fp64 cos / sin of the ring angles differ in the last place)
+    rb::MsjConst<float, 8> cf;
+    rc = rb::msj_build<float, 8>(d, step_size, nsub, &cf, err);
+    if (rc) return rc;
+    int mirror = 0, half[4], image[4];
+    if (!rb::find_mirror_pairs(cf, mirror, half, image)) return 1;
+    if (mirror_out) *mirror_out = mirror;
+    for (int k = 0; k < 4 && half_out; ++k) { half_out[k] = half[k]; half_out[4 + k] = image[k]; }
+    rb::MsjConst<T, 8> cp = c;
+    for (int k = 0; k < 4; ++k) cp.ten[k] = c.ten[half[k]];
+    for (long i = 0; i < n; ++i) {
+        T ue[4], uo[4];
+        for (int k = 0; k < 4; ++k) { ue[k] = c.ten[half[k]].ksg * sp[8 * i + half[k]]; uo[k] = c.ten[half[k]].ksg * sp[8 * i + image[k]]; }
+        bool ok;
+#define HM_PAIR(M) (integ == 0 ? rb::MsjModel<T, 8>::template integrate_acc<0>(cp, q + 3 * i, qd + 3 * i, HostPairAccel<T, M>{cp, ue, uo}) \
+                               : rb::MsjModel<T, 8>::template integrate_acc<1>(cp, q + 3 * i, qd + 3 * i, HostPairAccel<T, M>{cp, ue, uo}))
+        ok = mirror == 0 ? HM_PAIR(0) : HM_PAIR(1);
+#undef HM_PAIR
+        feas[i] = ok ? 1 : 0;
+    }
+    return 0;
+}
+extern "C" int hm_step_pairs_f64(const rb_robot_desc *d, double step_size, int nsub, int integ, long n,
+                                 double *q, double *qd, const double *sp, unsigned char *feas, int *mirror_out, int *half_out) {
+    return run_pairs<double>(d, step_size, nsub, integ, n, q, qd, sp, feas, mirror_out, half_out);
+}
+extern "C" int hm_step_pairs_f32(const rb_robot_desc *d, double step_size, int nsub, int integ, long n,
+                                 float *q, float *qd, const float *sp, unsigned char *feas, int *mirror_out, int *half_out) {
+    return run_pairs<float>(d, step_size, nsub, integ, n, q, qd, sp, feas, mirror_out, half_out);
+}
