@@ -3,9 +3,13 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-One "step" = one lock-step call of the batched ``forward_step_command`` = one
-kernel launch that advances every env of the rank's shard by one integrator
-step of dt = 0.1.  Actions are i.i.d. U[-1,1) from the Philox
+One "step" = one lock-step advance of every env of the rank's shard by one
+integrator step of dt = 0.1: the batched ``forward_step_command``.
+Per step and chain one kernel launch: the default rollout steps large batches as
+two independent chains of launches, one per half of the batch (``rb_rollout_chains``;
+``roofline.launches_per_step``), and the line carries the figure for ONE launch per
+step over the whole batch - what a per-step caller (``rb_step_dev``) gets - beside
+it (``roofline.one_launch``).  Actions are i.i.d. U[-1,1) from the Philox
 streams, pre-generated as a ring of 4 slabs resident in HBM and rescaled by
 0.3 in the kernel.
 
@@ -70,7 +74,7 @@ VALU_PEAK = 157.3e12       # flop/s, fp32 vector peak (MI355X_MICROARCH.md "Peak
 VALU_FMA_MEASURED = 64 * 2 * 1024 / 1.20e-9
 KERNEL_NAMES = {1: "msj_step_env_per_lane", 2: "msj_step_tendon_per_lane", 3: "tree_step_aba", 5: "msj_step_mirror_pairs"}
 TREE_KERNEL_NAMES = {1: "tree_lane_step", 3: "tree_step_aba", 4: "tree_split_step"}   # joint trees: env-per-lane (generated) / octets / several waves per env group
-PROFILE_DIRS = ("r3_a", "r2_a", "r1_b")   # newest first: where the committed rocprofv3 PMC passes live
+PROFILE_DIRS = ("r4_a", "r3_a", "r2_a", "r1_b")   # newest first: where the committed rocprofv3 PMC passes live
 
 
 def pmc_traffic(workload):
@@ -149,7 +153,7 @@ def parse():
 
 
 def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world, dist, substeps=None, kernel=0,
-                 repeats=None):
+                 repeats=None, force_chains=0):
     """Returns dict(ms_per_step, value, kernel_us, ...) for this workload."""
     from gym_roboy_amd.envs.simulations import HipBatchSimulation
     n_envs, integrator, nsub, d_steps, d_warm, label = WORKLOADS[name]
@@ -161,6 +165,8 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
     sim = HipBatchSimulation(robot, n_envs, integrator=integrator, n_substeps=nsub, device=dev,
                              seed=0, env_id_offset=rank * n_envs)
     sim.select_kernel(kernel)
+    if force_chains:
+        sim.set_rollout_chains(force_chains)
     stream = torch.cuda.current_stream()        # main() made a non-default stream current
     sim.set_stream(stream.cuda_stream)          # launches and torch events share one stream
     slab = n_envs * sim.n_t
@@ -569,6 +575,31 @@ def main():
                     also.append({"workload": "ppo-65536-%s" % ("fused" if fused else "torch"), "error": repr(exc)[:300],
                                  "finite": False, "feasible_frac": 0.0})
 
+    # the headline workload once more with ONE launch per step over the whole batch (what rb_step_dev / rb_env_step_dev and
+    # every per-step caller launch): beside the default form in the same line
+    one_launch = None
+    if head["roofline"].get("launches_per_step", 1) > 1 and not os.environ.get("ROBOY_BENCH_NO_ONE_LAUNCH"):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            one = run_workload(torch, robot, args.workload, args.steps, args.warmup, args.envs, use_graph, rank, world, dist,
+                               args.substeps, args.kernel, max(3, (head["repeats"] + 3) // 4), force_chains=1)
+        one_launch = {"us_events": one["launch_us_events"], "ms_per_step": one["ms_per_step"], "value": one["value"],
+                      "frac": one["roofline"]["frac"], "hbm_frac": one["roofline"]["hbm"]["frac"], "repeats": one["repeats"]}
+
+    def compact(r):
+        """One row of roofline.configs: a secondary workload's numbers in a dozen scalars (the driver's record keeps `roofline`)."""
+        rf = r.get("roofline") or {}
+        return {"us_events": r.get("launch_us_events", r.get("us_per_step_events")), "env_steps_per_s": r["value"],
+                "hbm_frac": (rf.get("hbm") or {}).get("frac"), "valu_frac": (rf.get("valu") or {}).get("frac"),
+                "bound": rf.get("bound"), "launches_per_step": rf.get("launches_per_step"), "kernel": r.get("kernel"),
+                "traffic_over_algorithmic": (rf["traffic"] / rf["hbm"]["bytes_per_launch"]) if rf.get("traffic") else None,
+                "finite": r.get("finite"), "feasible_frac": r.get("feasible_frac")}
+    configs = {a["workload"]: compact(a) for a in also
+               if a.get("workload", "").startswith(("msj-", "upper-body-", "fused-env")) and "value" in a}
+    for a in also:
+        if a.get("workload", "").startswith("ppo-") and "value" in a:
+            configs[a["workload"]] = {"timesteps_per_s": a["value"], "rollout_ms": a.get("rollout_ms"), "update_ms": a.get("update_ms"),
+                                      "rollout_us_per_step": (a["rollout_ms"] * 1e3 / (a["steps"] / 2)) if a.get("rollout_ms") else None}
+
     rc = 0
     if rank == 0:
         line = {
@@ -592,7 +623,8 @@ def main():
                                  "max over ranks); %.1f ms of device time in all"
                                  % (head["repeats"], head["steps"], head["timed_device_ms"])},
             "ms_per_step_spread": [head["ms_per_step_min"], head["ms_per_step_max"]],
-            "roofline": dict(head["roofline"], kernel=head["kernel"],
+            "roofline": dict(head["roofline"], kernel=head["kernel"], one_launch_us=(one_launch or {}).get("us_events"),
+                             one_launch=one_launch, configs=configs,
                              note="launch_us_events = HIP events on the launch stream around the K per-step launches "
                                   "of a region, median over the repeats, / K = time per STEP over all envs (kernel + kernel boundary); "
                                   "with launches_per_step > 1 a step is that many concurrent launches and rocprofv3 lists each "

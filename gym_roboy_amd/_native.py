@@ -75,6 +75,11 @@ SIGNATURES = {
     "rb_step_dev": (ctypes.c_int, [_sim, _vp, ctypes.c_float]),
     "rb_rollout_dev": (ctypes.c_int, [_sim, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]),
     "rb_rollout_chains": (ctypes.c_int, [_sim]),
+    "rb_set_rollout_chains": (ctypes.c_int, [_sim, ctypes.c_int]),
+    "rb_range_capable": (ctypes.c_int, [_sim]),
+    "rb_step_range_dev": (ctypes.c_int, [_sim, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float]),
+    "rb_env_step_range_dev": (ctypes.c_int, [_sim, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_void_p]),
     "rb_rollout_fused_dev": (ctypes.c_int, [_sim, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float]),
     "rb_fill_actions_dev": (ctypes.c_int, [_sim, _vp, ctypes.c_uint32]),
     "rb_sample_goals_dev": (ctypes.c_int, [_sim, _vp, _vp]),

@@ -290,10 +290,12 @@ msj_env_step_kernel(const CONST c_arg, const EnvParams e, const GoalBox box,
                     uint32_t *__restrict__ goal_count, const float *__restrict__ act,
                     float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
                     double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt, uint32_t *__restrict__ infeas_n,
-                    long n, uint64_t seed, uint64_t env0) {
+                    long n, long cnt, uint64_t seed, uint64_t env0) {
+    // n: the handle's envs = the stride of the state / goal / statistics planes; cnt: the envs of THIS launch - all of them, or a
+    // sub-range (rb_env_step_range_dev: every pointer then points at the range's first env, env0 is its global id)
     const CONST &c = robot_consts<BK>(c_arg);
     const long i = long(blockIdx.x) * BLOCK + threadIdx.x;
-    if (i >= n) return;
+    if (i >= cnt) return;
     float qq[3], vv[3], gg[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { qq[j] = q[j * n + i]; vv[j] = qd[j * n + i]; gg[j] = goal[j * n + i]; }

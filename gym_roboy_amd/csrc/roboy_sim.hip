@@ -422,6 +422,7 @@ struct rb_sim {
     GoalBox box;
     hipStream_t own_stream = nullptr, stream = nullptr;
     static constexpr int MAX_CHAINS = 4;
+    int chains_choice = 0;                                 // rb_set_rollout_chains: 0 = the library's choice, 1..MAX_CHAINS = that many
     hipStream_t chain_stream[MAX_CHAINS] = {};             // the further chains of rb_rollout_dev ([0] unused: the handle's stream; created on first use)
     hipEvent_t chain_fork = nullptr, chain_join[MAX_CHAINS] = {};
     float *d_q = nullptr, *d_qd = nullptr;
@@ -565,13 +566,16 @@ void maybe_jit(rb_sim *s) {
 #define RB_CHAIN_BATCH_TREE_RK4 65536
 #endif
 bool tree_use_lane(rb_sim *s, int which);
-bool chainable(const rb_sim *s) {
+// kernel forms that step a sub-range of the batch (shifted pointers, own env count): what chains and the rb_*_range_dev entry points need
+bool range_capable(const rb_sim *s) {
     if (s->tree) return s->kernel == RB_KERNEL_ENV_PER_LANE && tree_use_lane(const_cast<rb_sim *>(s), 0);   // one wave per 64 envs, env-major rows
-    return !s->ntx && s->kernel != RB_KERNEL_TENDON_PER_LANE && s->n > RB_SMALL_BATCH;
+    return !s->ntx && s->kernel != RB_KERNEL_TENDON_PER_LANE;
 }
+bool chainable(const rb_sim *s) { return range_capable(s) && (s->tree || s->n > RB_SMALL_BATCH); }
 int rollout_chains(const rb_sim *s) {
     static const int forced = [] { const char *e = getenv("ROBOY_SIM_CHAINS"); return e ? atoi(e) : 0; }();
     if (!chainable(s)) return 1;
+    if (s->chains_choice >= 1) return s->chains_choice;
     if (forced >= 1 && forced <= rb_sim::MAX_CHAINS) return forced;
     if (s->tree) return s->n >= (s->integrator == RB_EULER ? RB_CHAIN_BATCH_TREE_EULER : RB_CHAIN_BATCH_TREE_RK4) ? 2 : 1;
     return s->n >= (s->integrator == RB_EULER ? RB_CHAIN_BATCH_EULER : RB_CHAIN_BATCH_RK4) ? 2 : 1;
@@ -603,7 +607,7 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale, long i0 = 0, lon
     const bool whole = i1 < 0;
     if (whole) { i0 = 0; i1 = n; stream = s->stream; }
     const long cnt = i1 - i0;
-    if (!whole && !chainable(s)) return fail(RB_EINVAL, "this kernel form steps whole batches only");
+    if (!whole && !range_capable(s)) return fail(RB_EINVAL, "this kernel form steps whole batches only");
     // Small batches are latency-bound (a few waves per CU): one wave per
     // workgroup spread over the CUs, tendon loop fully unrolled for ILP.
     // Large batches are VALU-issue-bound: rolled tendon loop (one 16-dword
@@ -1301,6 +1305,13 @@ int rb_rollout_chains(rb_sim *s) {
     return rollout_chains(s);
 }
 
+int rb_set_rollout_chains(rb_sim *s, int chains) {
+    if (check(s)) return RB_EINVAL;
+    if (chains < 0 || chains > rb_sim::MAX_CHAINS) return fail(RB_EINVAL, "chains must be 0 (the library's choice) or 1..4");
+    s->chains_choice = chains;      // (graphs are cached per chain count: nothing to drop)
+    return RB_OK;
+}
+
 int rb_rollout_fused_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float act_scale) {
     if (check(s) || !d_ring) return fail(RB_EINVAL, "null argument");
     RB_HIP(hipSetDevice(s->device));
@@ -1424,13 +1435,13 @@ int rb_env_set_goal(rb_sim *s, const float *goal_q, const uint32_t *step_num) {
     return RB_OK;
 }
 
-int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward, uint32_t *d_done) {
-    if (check(s) || !d_act || !d_obs || !d_reward || !d_done) return fail(RB_EINVAL, "null argument");
-    RB_HIP(hipSetDevice(s->device));
-    if (!s->env_ready) return fail(RB_EINVAL, "rb_env_configure has not been called");
-    if (!s->tree && reinterpret_cast<uintptr_t>(d_act) % 16) return fail(RB_EINVAL, "action slab must be 16-byte aligned");
+// RoboyEnv.step for envs [i0, i0 + cnt) on `stream`; the array arguments are those of the whole batch (offsets are applied here).
+// Sub-ranges: the env-per-lane kernels of the ball-joint class and the joint trees' one-wave-per-64-envs form.
+static int env_step_launch(rb_sim *s, long i0, long cnt, hipStream_t stream, const float *d_act, float *d_obs, float *d_reward, uint32_t *d_done) {
     const long n = s->n;
+    const bool whole = i0 == 0 && cnt == n;
     if (s->tree && tree_wants_split(s) && (s->split_baked || build_split_kernel(s, 1))) {
+        if (!whole) return fail(RB_EUNSUPPORTED, "the split form of the joint-tree kernels steps whole batches only");
         const unsigned groups = blocks_for(n, 64);
         const size_t lds = split_lds_bytes(s->split_gen);
         const float h = s->tree_host.dev.h;
@@ -1439,8 +1450,8 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
 #define RB_SPLIT_ENV_ARGS s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, s->d_ep_ret, s->d_goal_count, d_act, \
                           d_obs, d_reward, d_done, s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, h, nsub, n, s->seed, uint64_t(s->env0)
         if (s->split_baked) {
-            if (s->integrator == RB_EULER) hipLaunchKernelGGL(rbl_split_baked::tree_split_env_step<0>, dim3(groups), dim3(threads), lds, s->stream, RB_SPLIT_ENV_ARGS);
-            else hipLaunchKernelGGL(rbl_split_baked::tree_split_env_step<1>, dim3(groups), dim3(threads), lds, s->stream, RB_SPLIT_ENV_ARGS);
+            if (s->integrator == RB_EULER) hipLaunchKernelGGL(rbl_split_baked::tree_split_env_step<0>, dim3(groups), dim3(threads), lds, stream, RB_SPLIT_ENV_ARGS);
+            else hipLaunchKernelGGL(rbl_split_baked::tree_split_env_step<1>, dim3(groups), dim3(threads), lds, stream, RB_SPLIT_ENV_ARGS);
         } else {
             EnvParams ep = s->env;
             GoalBox box = s->box;
@@ -1450,45 +1461,51 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
             uint64_t seed = s->seed, env0 = uint64_t(s->env0);
             void *args[] = {&ep, &box, &s->d_q, &s->d_qd, &s->d_feas, &s->d_goal, &s->d_step_num, &s->d_ep_ret, &s->d_goal_count, &d_act,
                             &d_obs, &d_reward, &d_done, &s->d_ep_sum, &s->d_ep_cnt, &s->d_infeas_n, &hh, &ns, &nn, &seed, &env0};
-            RB_HIP(hipModuleLaunchKernel(s->split_env_k.fn, groups, 1, 1, threads, 1, 1, unsigned(lds), s->stream, args, nullptr));
+            RB_HIP(hipModuleLaunchKernel(s->split_env_k.fn, groups, 1, 1, threads, 1, 1, unsigned(lds), stream, args, nullptr));
         }
 #undef RB_SPLIT_ENV_ARGS
         RB_HIP(hipGetLastError());
-        s->env_steps += double(n);
         return RB_OK;
     }
     if (s->tree && tree_use_lane(s, 1)) {
-        const unsigned waves = blocks_for(n, 64);
+        // env-major rows: a sub-range is the same kernel on shifted pointers and its own env count; the per-env statistics
+        // planes keep their stride n
+        const unsigned waves = blocks_for(cnt, 64);
         const size_t lds = rblg::lane_lds_bytes_per_wave(s->lane_gen);
         const float h = s->tree_host.dev.h;
         const int nsub = s->tree_host.dev.nsub;
-#define RB_LANE_ENV_ARGS s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, s->d_ep_ret, s->d_goal_count, d_act, \
-                         d_obs, d_reward, d_done, s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, h, nsub, n, s->seed, uint64_t(s->env0)
+        const size_t nq = size_t(s->n_q), nt = size_t(s->n_t);
+        float *tq = s->d_q + i0 * nq, *tqd = s->d_qd + i0 * nq, *tgoal = s->d_goal + i0 * nq, *tret = s->d_ep_ret + i0, *tobs = d_obs + i0 * 3 * nq, *trew = d_reward + i0;
+        uint32_t *tfeas = s->d_feas + i0, *tsn = s->d_step_num + i0, *tgc = s->d_goal_count + i0, *tdone = d_done + i0, *tcnt = s->d_ep_cnt + i0, *tinf = s->d_infeas_n + i0;
+        const float *tact = d_act + i0 * nt;
+        double *tsum = s->d_ep_sum + i0;
+        const uint64_t e0 = uint64_t(s->env0) + uint64_t(i0);
+#define RB_LANE_ENV_ARGS s->env, s->box, tq, tqd, tfeas, tgoal, tsn, tret, tgc, tact, tobs, trew, tdone, tsum, tcnt, tinf, h, nsub, cnt, s->seed, e0, n
         if (s->lane_baked) {
-            if (s->integrator == RB_EULER) hipLaunchKernelGGL(rbl_baked::tree_lane_env_step<0>, dim3(waves), dim3(64), lds, s->stream, RB_LANE_ENV_ARGS);
-            else hipLaunchKernelGGL(rbl_baked::tree_lane_env_step<1>, dim3(waves), dim3(64), lds, s->stream, RB_LANE_ENV_ARGS);
+            if (s->integrator == RB_EULER) hipLaunchKernelGGL(rbl_baked::tree_lane_env_step<0>, dim3(waves), dim3(64), lds, stream, RB_LANE_ENV_ARGS);
+            else hipLaunchKernelGGL(rbl_baked::tree_lane_env_step<1>, dim3(waves), dim3(64), lds, stream, RB_LANE_ENV_ARGS);
         } else {
             EnvParams ep = s->env;
             GoalBox box = s->box;
             float hh = h;
             int ns = nsub;
-            long nn = n;
-            uint64_t seed = s->seed, env0 = uint64_t(s->env0);
-            void *args[] = {&ep, &box, &s->d_q, &s->d_qd, &s->d_feas, &s->d_goal, &s->d_step_num, &s->d_ep_ret, &s->d_goal_count, &d_act,
-                            &d_obs, &d_reward, &d_done, &s->d_ep_sum, &s->d_ep_cnt, &s->d_infeas_n, &hh, &ns, &nn, &seed, &env0};
-            RB_HIP(hipModuleLaunchKernel(s->lane_env_k.fn, waves, 1, 1, 64, 1, 1, unsigned(lds), s->stream, args, nullptr));
+            long nn = cnt, stride = n;
+            uint64_t seed = s->seed, env0 = e0;
+            void *args[] = {&ep, &box, &tq, &tqd, &tfeas, &tgoal, &tsn, &tret, &tgc, &tact,
+                            &tobs, &trew, &tdone, &tsum, &tcnt, &tinf, &hh, &ns, &nn, &seed, &env0, &stride};
+            RB_HIP(hipModuleLaunchKernel(s->lane_env_k.fn, waves, 1, 1, 64, 1, 1, unsigned(lds), stream, args, nullptr));
         }
 #undef RB_LANE_ENV_ARGS
         RB_HIP(hipGetLastError());
-        s->env_steps += double(n);
         return RB_OK;
     }
     if (s->tree) {
+        if (!whole) return fail(RB_EUNSUPPORTED, "the octet form of the joint-tree kernels steps whole batches only");
         const int wv = s->tree_waves;
         const size_t lds = rbt::tree_lds_bytes(s->tree_host, wv);
         const long per_block = long(wv) * rbt::TREE_E;
 #define RB_TREE_ENV_LAUNCH(INTEG, SP)                                                                        \
-    hipLaunchKernelGGL((rbt::tree_env_step_aba<INTEG, rbt::TREE_E, SP>), dim3(unsigned((n + per_block - 1) / per_block)), dim3(64 * wv), lds, s->stream, \
+    hipLaunchKernelGGL((rbt::tree_env_step_aba<INTEG, rbt::TREE_E, SP>), dim3(unsigned((n + per_block - 1) / per_block)), dim3(64 * wv), lds, stream, \
                        s->tree_host.dev, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, \
                        s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done, s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, \
                        n, s->seed, uint64_t(s->env0))
@@ -1497,37 +1514,34 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
         else                           { if (sp) RB_TREE_ENV_LAUNCH(1, true); else RB_TREE_ENV_LAUNCH(1, false); }
 #undef RB_TREE_ENV_LAUNCH
         RB_HIP(hipGetLastError());
-        s->env_steps += double(n);
         return RB_OK;
     }
+    // ball joints: SoA planes keep their stride n; everything else is indexed by env and shifted
+    const int nt = s->n_t;
+    float *rq = s->d_q + i0, *rqd = s->d_qd + i0, *rgoal = s->d_goal + i0, *rret = s->d_ep_ret + i0, *robs = d_obs + i0 * 9, *rrew = d_reward + i0;
+    uint32_t *rfeas = s->d_feas + i0, *rsn = s->d_step_num + i0, *rgc = s->d_goal_count + i0, *rdone = d_done + i0, *rcnt = s->d_ep_cnt + i0, *rinf = s->d_infeas_n + i0;
+    const float *ract = d_act + i0 * nt;
+    double *rsum = s->d_ep_sum + i0;
+    const uint64_t e0 = uint64_t(s->env0) + uint64_t(i0);
+#define RB_ENV_ARGS s->env, s->box, rq, rqd, rfeas, rgoal, rsn, rret, rgc, ract, robs, rrew, rdone, rsum, rcnt, rinf, n, cnt, s->seed, e0
 #define RB_ENV_LAUNCH(INTEG, B, U)                                                                       \
-    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, U>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream, \
-                       s->c8, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num,      \
-                       s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done, s->d_ep_sum,       \
-                       s->d_ep_cnt, s->d_infeas_n, n,                                                   \
-                       s->seed, uint64_t(s->env0))
+    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, U>), dim3(blocks_for(cnt, B)), dim3(B), 0, stream, s->c8, RB_ENV_ARGS)
 #define RB_ENV_LAUNCH_NT(INTEG, B)                                                                       \
-    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, 0, ConstX>), dim3(blocks_for(n, B)), dim3(B), 0,   \
-                       s->stream, s->cx, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal,          \
-                       s->d_step_num, s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done,      \
-                       s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, n, s->seed, uint64_t(s->env0))
+    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, 0, ConstX>), dim3(blocks_for(cnt, B)), dim3(B), 0, stream, s->cx, RB_ENV_ARGS)
 #define RB_ENV_LAUNCH_BK(INTEG, B, U)                                                                    \
-    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, U, Const8, true>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream, \
-                       s->c8, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num,      \
-                       s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done, s->d_ep_sum,       \
-                       s->d_ep_cnt, s->d_infeas_n, n, s->seed, uint64_t(s->env0))
+    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, U, Const8, true>), dim3(blocks_for(cnt, B)), dim3(B), 0, stream, s->c8, RB_ENV_ARGS)
     maybe_jit(s);
     if (s->jit_state == 1) {
-        // msj_env_step_kernel<INTEG, 256, 4, Const8, true> of this robot's own module; same parameter list
+        // msj_env_step_kernel<INTEG, 256, 8 / RS, Const8, true> of this robot's own module; same parameter list
         Const8 c8 = s->c8;
         EnvParams ep = s->env;
         GoalBox box = s->box;
-        long nn = n;
-        uint64_t seed = s->seed, env0 = uint64_t(s->env0);
-        void *args[] = {&c8, &ep, &box, &s->d_q, &s->d_qd, &s->d_feas, &s->d_goal, &s->d_step_num, &s->d_ep_ret, &s->d_goal_count,
-                        &d_act, &d_obs, &d_reward, &d_done, &s->d_ep_sum, &s->d_ep_cnt, &s->d_infeas_n, &nn, &seed, &env0};
-        RB_HIP(hipModuleLaunchKernel(s->jit.env[s->integrator == RB_EULER ? 0 : 1], blocks_for(n, 256), 1, 1, 256, 1, 1, 0,
-                                     s->stream, args, nullptr));
+        long nn = n, cc = cnt;
+        uint64_t seed = s->seed, env0 = e0;
+        void *args[] = {&c8, &ep, &box, &rq, &rqd, &rfeas, &rgoal, &rsn, &rret, &rgc,
+                        &ract, &robs, &rrew, &rdone, &rsum, &rcnt, &rinf, &nn, &cc, &seed, &env0};
+        RB_HIP(hipModuleLaunchKernel(s->jit.env[s->integrator == RB_EULER ? 0 : 1], blocks_for(cnt, 256), 1, 1, 256, 1, 1, 0,
+                                     stream, args, nullptr));
     } else
     if (s->baked) {
         if (n <= RB_SMALL_BATCH) { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_BK(0, 64, 8); else RB_ENV_LAUNCH_BK(1, 64, 8); }
@@ -1542,9 +1556,56 @@ int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward
 #undef RB_ENV_LAUNCH_NT
 #undef RB_ENV_LAUNCH_BK
 #undef RB_ENV_LAUNCH
+#undef RB_ENV_ARGS
     RB_HIP(hipGetLastError());
-    s->env_steps += double(n);
     return RB_OK;
+}
+
+int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward, uint32_t *d_done) {
+    if (check(s) || !d_act || !d_obs || !d_reward || !d_done) return fail(RB_EINVAL, "null argument");
+    RB_HIP(hipSetDevice(s->device));
+    if (!s->env_ready) return fail(RB_EINVAL, "rb_env_configure has not been called");
+    if (!s->tree && reinterpret_cast<uintptr_t>(d_act) % 16) return fail(RB_EINVAL, "action slab must be 16-byte aligned");
+    int rc = env_step_launch(s, 0, s->n, s->stream, d_act, d_obs, d_reward, d_done);
+    if (rc == RB_OK) s->env_steps += double(s->n);
+    return rc;
+}
+
+// a sub-range on a stream of the caller's choice: envs are independent, so disjoint ranges may be stepped concurrently
+static int range_ok(const rb_sim *s, int64_t first, int64_t count) {
+    if (first < 0 || count < 1 || first + count > s->n) return fail(RB_EINVAL, "range outside the batch");
+    if (first % 256) return fail(RB_EINVAL, "a range starts at a multiple of 256 envs");
+    return RB_OK;
+}
+int rb_env_step_range_dev(rb_sim *s, int64_t first_env, int64_t n_envs, void *hip_stream, const float *d_act, float *d_obs, float *d_reward, uint32_t *d_done) {
+    if (check(s) || !d_act || !d_obs || !d_reward || !d_done) return fail(RB_EINVAL, "null argument");
+    RB_HIP(hipSetDevice(s->device));
+    if (!s->env_ready) return fail(RB_EINVAL, "rb_env_configure has not been called");
+    if (!s->tree && reinterpret_cast<uintptr_t>(d_act) % 16) return fail(RB_EINVAL, "action slab must be 16-byte aligned");
+    if (range_ok(s, first_env, n_envs)) return RB_EINVAL;
+    int rc = env_step_launch(s, long(first_env), long(n_envs), hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream, d_act, d_obs, d_reward, d_done);
+    if (rc == RB_OK) s->env_steps += double(n_envs);
+    return rc;
+}
+int rb_step_range_dev(rb_sim *s, int64_t first_env, int64_t n_envs, void *hip_stream, const float *d_act, float act_scale) {
+    if (check(s) || !d_act) return fail(RB_EINVAL, "null argument");
+    RB_HIP(hipSetDevice(s->device));
+    if (reinterpret_cast<uintptr_t>(d_act) % 16) return fail(RB_EINVAL, "action slab must be 16-byte aligned");
+    if (range_ok(s, first_env, n_envs)) return RB_EINVAL;
+    maybe_jit(s);
+    const bool whole = first_env == 0 && n_envs == s->n;
+    if (!whole && !range_capable(s)) return fail(RB_EUNSUPPORTED, "this kernel form steps whole batches only (rb_range_capable)");
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
+    int rc = whole && st == s->stream ? launch_step(s, d_act, act_scale) : launch_step(s, d_act, act_scale, long(first_env), long(first_env + n_envs), st);
+    if (rc == RB_OK) s->env_steps += double(n_envs);
+    return rc;
+}
+int rb_range_capable(rb_sim *s) {
+    if (check(s)) return -1;
+    // the fused env layer of the ball-joint class is always an env-per-lane kernel (whatever form the plain step takes);
+    // joint trees: the one-wave-per-64-envs form, not the split form and not the octets
+    const bool env = s->tree ? (!tree_wants_split(s) && tree_use_lane(s, 1)) : true;
+    return (range_capable(s) ? 1 : 0) | (env ? 2 : 0);
 }
 
 static int stats_launch(rb_sim *s, double *d_out2) {

@@ -244,7 +244,9 @@ tree_lane_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__res
                    float *__restrict__ ep_ret, uint32_t *__restrict__ goal_count, const float *__restrict__ act,
                    float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
                    double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt, uint32_t *__restrict__ infeas_n,
-                   float h, int nsub, long n, uint64_t seed, uint64_t env_id0) {
+                   float h, int nsub, long n, uint64_t seed, uint64_t env_id0, long stat_stride) {
+    // n: the envs of this launch (the whole batch, or a sub-range on shifted pointers: rb_env_step_range_dev); stat_stride: the
+    // batch's env count = the stride of the per-env statistics planes ep_sum[2][.], ep_cnt[3][.]
     extern __shared__ float lds_lane[];
     const int lane = threadIdx.x;
     const long env0 = long(blockIdx.x) * 64;      // a workgroup is ONE wave: everything derived from the block index is scalar
@@ -304,8 +306,8 @@ tree_lane_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__res
             for (int j = 0; j < RBL_NQ; ++j) { qq[j] = 0.0f; vv[j] = 0.0f; o[j] = 0.0f; o[RBL_NQ + j] = 0.0f; o[2 * RBL_NQ + j] = gn[j]; }
         }
         if (mine) {
-            ep_sum[me] += double(ret); ep_sum[n + me] += double(ret) * double(ret);
-            ep_cnt[me] += 1u; ep_cnt[n + me] += sn - 1u; ep_cnt[2 * n + me] += reached ? 1u : 0u;
+            ep_sum[me] += double(ret); ep_sum[stat_stride + me] += double(ret) * double(ret);
+            ep_cnt[me] += 1u; ep_cnt[stat_stride + me] += sn - 1u; ep_cnt[2 * stat_stride + me] += reached ? 1u : 0u;
             goal_count[me] = draw;
         }
         if (ep.auto_reset) { sn = 1u; fz = 1u; }

@@ -148,6 +148,16 @@ class HipBatchSimulation:
     def step_dev(self, d_act: int, act_scale: float = 1.0):
         nat.check(self._lib.rb_step_dev(self._h, ctypes.c_void_p(d_act), float(act_scale)))
 
+    def range_capable(self, env_layer: bool = False) -> bool:
+        """True if this handle's kernel form steps sub-ranges of the batch (``rb_range_capable``): the plain step, or
+        (env_layer) the fused env step."""
+        return bool(int(self._lib.rb_range_capable(self._h)) & (2 if env_layer else 1))
+
+    def step_range_dev(self, first_env: int, n_envs: int, stream_ptr, d_act: int, act_scale: float = 1.0):
+        """Envs [first_env, first_env + n_envs) on the stream ``stream_ptr`` (None / 0: the handle's); ``d_act`` is the WHOLE batch's slab."""
+        nat.check(self._lib.rb_step_range_dev(self._h, int(first_env), int(n_envs), ctypes.c_void_p(int(stream_ptr or 0)),
+                                              ctypes.c_void_p(d_act), float(act_scale)))
+
     def rollout_dev(self, d_act_ring: int, ring: int, n_steps: int, act_scale: float = 1.0,
                     use_graph: bool = False):
         nat.check(self._lib.rb_rollout_dev(self._h, ctypes.c_void_p(d_act_ring), int(ring),
@@ -156,6 +166,10 @@ class HipBatchSimulation:
     def rollout_chains(self) -> int:
         """1: rollout_dev's graphs launch once per step over the whole batch; 2: the two halves step as two independent chains."""
         return int(self._lib.rb_rollout_chains(self._h))
+
+    def set_rollout_chains(self, chains: int):
+        """0: the library's choice; 1..4: that many chains of launches per step in graph rollouts (``rb_set_rollout_chains``)."""
+        nat.check(self._lib.rb_set_rollout_chains(self._h, int(chains)))
 
     def rollout_fused_dev(self, d_act_ring: int, ring: int, n_steps: int, act_scale: float = 1.0):
         """Open-loop rollout in one launch (state in registers across the steps)."""

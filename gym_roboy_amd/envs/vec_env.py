@@ -111,6 +111,18 @@ class RoboyVecEnv:
             self.sim.handle, ctypes.c_void_p(d_act), ctypes.c_void_p(d_obs),
             ctypes.c_void_p(d_rew), ctypes.c_void_p(d_done)))
 
+    def step_range_dev(self, first_env, n_envs, stream_ptr, d_act, d_obs, d_rew, d_done):
+        """``step_dev`` for envs [first_env, first_env + n_envs) on the stream ``stream_ptr`` (None: the simulation's); the
+        pointers are those of the WHOLE batch's arrays.  Disjoint ranges may be stepped concurrently on different streams
+        (``rb_env_step_range_dev``): how a closed-loop caller overlaps one half's launch gaps and memory phases with the
+        other half's arithmetic (``gym_roboy_amd/ppo.py``)."""
+        nat.check(self.sim._lib.rb_env_step_range_dev(
+            self.sim.handle, int(first_env), int(n_envs), ctypes.c_void_p(int(stream_ptr or 0)), ctypes.c_void_p(d_act),
+            ctypes.c_void_p(d_obs), ctypes.c_void_p(d_rew), ctypes.c_void_p(d_done)))
+
+    def range_capable(self) -> bool:
+        return self.sim.range_capable(env_layer=True)
+
     def _step_torch(self, actions):
         import torch
         n = self.num_envs

@@ -296,11 +296,17 @@ class PPO:
     def __init__(self, env, policy=None, n_steps=128, nminibatches=4, noptepochs=4, gamma=0.99, lam=0.95,
                  learning_rate=2.5e-4, cliprange=0.2, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5,
                  device="cuda", dist=None, reward_scale=1.0, seed=0, use_graphs=False, fused_policy=None,
-                 fused_update=None):
+                 fused_update=None, rollout_chains=None):
         """fused_policy / fused_update: None = the fused MFMA kernels whenever they apply (a GPU, MlpPolicy's shape,
         dimensions the kernels support), True = insist, False = the torch path (the statement the kernels are
-        tested against)."""
+        tested against).
+        rollout_chains: graph mode with the fused policy step - 2 = the rollout as two independent chains of (policy step, env
+        step) launches over the two halves of the batch on two streams, joined in front of GAE (the sub-range entry points of
+        include/roboy_sim.h: one half's launch gaps and load / store phases lie under the other half's kernels; the results do
+        not depend on the split); 1 = one chain over the whole batch; None = two from ``CHAIN_BATCH`` envs on where the env's
+        kernel form steps sub-ranges."""
         self.env, self.dist, self.device = env, dist, torch.device(device)
+        self._chains_arg = rollout_chains
         torch.manual_seed(seed)
         obs_dim = env.observation_space.shape[0]
         act_dim = env.action_space.shape[0]
@@ -323,6 +329,7 @@ class PPO:
         self._epoch = 0                       # update epochs so far: keys the fused path's sample order
         self._seed = int(seed) + (7919 * dist.get_rank() if multi_rank else 0)
         self._rollout_graph = None
+        self.rollout_chains = 1
         # fused_policy: the rollout's policy step runs as one MFMA kernel (FusedPolicyStep) instead of ~30 torch kernels
         self._fused = None
         if fused_policy:
@@ -349,23 +356,36 @@ class PPO:
         return x.to(self.device, dtype) if torch.is_tensor(x) else torch.as_tensor(x, dtype=dtype, device=self.device)
 
     # -- HIP-graph mode ------------------------------------------------------------
-    def _rollout_body(self, b):
+    CHAIN_BATCH = 32768      # two chains from this many envs on (measured: profiles/r4_a/ppo_chains.log)
+
+    def _rollout_steps(self, b, lo, hi, stream_ptr=None):
+        """The T (policy step, env step) pairs of envs [lo, hi): the whole batch on the env's stream (stream_ptr None), or one
+        chain's half on its own stream."""
         env, T = self.env, self.n_steps
-        b["obs"][0].copy_(b["carry"])
+        whole = stream_ptr is None
+        b["obs"][0][lo:hi].copy_(b["carry"][lo:hi])
         packed = self._fused.pack() if self._fused is not None else None     # (inside the graph: re-gathered on every replay)
         for t in range(T):
             if self._fused is not None:
-                # straight into the rollout buffers; the env kernel clamps the action to its box itself
-                self._fused.act_into(b["obs"][t], b["act"][t], b["logp"][t], b["val"][t], step=t, packed=packed,
-                                     step_base=self._step_base)
-                env.step_dev(b["act"][t].data_ptr(), b["obs"][t + 1].data_ptr(), b["rew_raw"][t].data_ptr(),
-                             b["done_i"][t].data_ptr())
+                # straight into the rollout buffers; the env kernel clamps the action to its box itself.  The noise is keyed by
+                # the GLOBAL sample index (sample_offset): the same draw however the batch is cut
+                self._fused.act_into(b["obs"][t][lo:hi], b["act"][t][lo:hi], b["logp"][t][lo:hi], b["val"][t][lo:hi], step=t,
+                                     packed=packed, step_base=self._step_base, sample_offset=lo)
+                if whole:
+                    env.step_dev(b["act"][t].data_ptr(), b["obs"][t + 1].data_ptr(), b["rew_raw"][t].data_ptr(),
+                                 b["done_i"][t].data_ptr())
+                else:
+                    env.step_range_dev(lo, hi - lo, stream_ptr, b["act"][t].data_ptr(), b["obs"][t + 1].data_ptr(),
+                                       b["rew_raw"][t].data_ptr(), b["done_i"][t].data_ptr())
                 continue
             a, logp, v = self.policy.act(b["obs"][t])
             b["act"][t].copy_(a); b["logp"][t].copy_(logp); b["val"][t].copy_(v)
             clipped = a.clamp(-1.0, 1.0).contiguous()
             env.step_dev(clipped.data_ptr(), b["obs"][t + 1].data_ptr(), b["rew_raw"][t].data_ptr(),
                          b["done_i"][t].data_ptr())
+
+    def _rollout_tail(self, b):
+        T = self.n_steps
         if self._fused is not None:
             self._step_base += T                                             # fresh noise on the next replay
         b["rew"].copy_(b["rew_raw"] * self.reward_scale)
@@ -378,6 +398,17 @@ class PPO:
             adv, ret = gae(b["rew"], b["val"], b["done"], last_value, self.gamma, self.lam)
             b["adv"].copy_(adv); b["ret"].copy_(ret)
         b["carry"].copy_(b["obs"][T])
+
+    def _rollout_body(self, b):
+        self._rollout_steps(b, 0, b["carry"].shape[0])
+        self._rollout_tail(b)
+
+    def _pick_chains(self, N):
+        if self._fused is None or not hasattr(self.env, "step_range_dev") or not self.env.range_capable():
+            return 1
+        if self._chains_arg is not None:
+            return 2 if int(self._chains_arg) >= 2 and N >= 512 else 1
+        return 2 if N >= self.CHAIN_BATCH else 1
 
     def _build_rollout_graph(self):
         env, T, dev = self.env, self.n_steps, self.device
@@ -401,22 +432,52 @@ class PPO:
             if self._fused is not None:       # its one-time launch configuration must not fall into the capture either
                 self._fused.act_into(b["carry"], b["act"][0], b["logp"][0], b["val"][0], deterministic=True)
         side.synchronize()
-        graph = torch.cuda.CUDAGraph()
+        self.rollout_chains = self._pick_chains(N)
         # thread-local capture mode: another thread of the process (RCCL's watchdog in a multi-rank run) may call into
         # the runtime while this one captures
-        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
-            self._rollout_body(b)
+        if self.rollout_chains == 1:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                self._rollout_body(b)
+            self._rollout_graph = graph
+        else:
+            # two chains: one graph per half of the batch (each on a stream of its own when replayed) and one for what follows
+            # the join.  Two LINEAR graphs, not one with two branches: csrc/roboy_sim.hip, rb_rollout_dev.
+            mid = ((N // 2 + 255) // 256) * 256
+            side2 = torch.cuda.Stream(device=dev)
+            self._chain_stream = side2
+            graphs = []
+            for (lo, hi), st in (((0, mid), side), ((mid, N), side2)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+                    self._rollout_steps(b, lo, hi, stream_ptr=st.cuda_stream)
+                graphs.append(g)
+            tail = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(tail, stream=side, capture_error_mode="thread_local"):
+                self._rollout_tail(b)
+            self._rollout_graph = (graphs[0], graphs[1], tail)
         torch.cuda.current_stream(dev).wait_stream(side)
         # replays (and every later eager env call) run on the caller's current stream
         env.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         if hasattr(env, "note_replayed_steps"):
             env.note_replayed_steps(-T)    # the capture pass went through the counting entry point without running
-        self._rollout_graph, self._rb = graph, b
+        self._rb = b
 
     def _collect_graph(self):
         if self._rollout_graph is None:
             self._build_rollout_graph()
-        self._rollout_graph.replay()
+        if self.rollout_chains == 1:
+            self._rollout_graph.replay()
+        else:
+            # fork - the second chain on its own stream, launched first (rb_rollout_dev's order) - replay, join, tail
+            ga, gb, tail = self._rollout_graph
+            cur = torch.cuda.current_stream(self.device)
+            self._chain_stream.wait_stream(cur)
+            with torch.cuda.stream(self._chain_stream):
+                gb.replay()
+            ga.replay()
+            cur.wait_stream(self._chain_stream)
+            tail.replay()
         b, T = self._rb, self.n_steps
         if hasattr(self.env, "note_replayed_steps"):
             self.env.note_replayed_steps(T)

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define RB_ABI_VERSION 3
+#define RB_ABI_VERSION 4
 
 enum rb_status {
     RB_OK = 0,
@@ -184,9 +184,10 @@ int rb_sample_goals(rb_sim *sim, const uint8_t *mask, float *goal_q);
  * env-major rows q[n_envs][n_q], qd[n_envs][n_q] (a wave owns a few whole envs).  feasible[n_envs] either way. */
 int rb_state_ptrs(rb_sim *sim, float **d_q, float **d_qd, uint32_t **d_feasible);
 int rb_step_dev(rb_sim *sim, const float *d_act, float act_scale);
-/* n_steps per-step launches; step t reads slab (t % ring) of d_act_ring
- * ([ring][n_envs][n_t]).  use_graph != 0 replays them from a captured hipGraph.
- * One kernel per env step either way (a policy sits between steps in real use). */
+/* n_steps steps, one kernel boundary per step; step t reads slab (t % ring) of d_act_ring
+ * ([ring][n_envs][n_t]).  use_graph != 0 replays the launches from captured hipGraphs -
+ * for large batches as rb_rollout_chains() independent chains, i.e. one launch per step
+ * and HALF of the batch (below); use_graph = 0 launches once per step over the whole batch. */
 int rb_rollout_dev(rb_sim *sim, const float *d_act_ring, int ring, int n_steps,
                    float act_scale, int use_graph);
 /* How rb_rollout_dev (use_graph = 1) steps this handle: 1 = one launch over the whole batch per step; 2 = the two halves of the batch
@@ -195,6 +196,9 @@ int rb_rollout_dev(rb_sim *sim, const float *d_act_ring, int ring, int n_steps,
  * other half's arithmetic - MsjRobot RK4 at 262 144 envs 16.6 -> 13.0 us per step; envs are independent, the results are the same
  * bit for bit; ROBOY_SIM_CHAINS=1 switches it off, 2-4 force a count).  Eager rollouts (use_graph = 0) and rb_step_dev launch once. */
 int rb_rollout_chains(rb_sim *sim);
+/* 0 = the library's choice (above), 1..4 = that many chains for the kernel forms that can be stepped in sub-ranges (others keep 1):
+ * what bench.py uses to time the one-launch-per-step form beside the default one. */
+int rb_set_rollout_chains(rb_sim *sim, int chains);
 /* Open-loop rollout fused into ONE launch: every env advances n_steps steps, the
  * state stays in registers in between and only the action of each step is read
  * (slab t % ring of d_act_ring).  For action sequences that are known up front
@@ -221,6 +225,22 @@ int rb_env_reset_dev(rb_sim *sim, float *d_obs /* [n_envs][3 n_q] */);
 int rb_env_set_goal(rb_sim *sim, const float *goal_q, const uint32_t *step_num /* [n_envs] or NULL */);
 int rb_env_step_dev(rb_sim *sim, const float *d_act /* [n_envs][n_t] in [-1,1] */,
                     float *d_obs, float *d_reward, uint32_t *d_done);
+/* ---- sub-ranges: envs [first_env, first_env + n_envs) on a stream of the caller's choice ----
+ * The per-step entry points above launch ONCE per step over the whole batch - which, for a large batch, leaves the launch
+ * gap and the load / store phases of a single generation of waves uncovered (rb_rollout_dev's chains exist for that).  A
+ * closed-loop caller gets the same overlap by running its loop as two independent chains over the two halves of the batch
+ * on two streams - its policy kernel and this step per half (gym_roboy_amd/ppo.py does: the reference's consumer,
+ * train_parallel.py:28-35) - forked and joined by the caller, once per rollout.  (Forking and joining inside every step
+ * call does not pay: a join costs ~8 us on this stack, profiles/r4_a/region_timeline.log.)  Envs are independent, so
+ * disjoint ranges may run concurrently and the results do not depend on the split.  The array arguments are those of the
+ * WHOLE batch (the library applies the offsets); first_env is a multiple of 256; hip_stream NULL = the handle's stream.
+ * rb_range_capable(): bit 0 = rb_step_range_dev takes sub-ranges with the handle's kernel form (ball joints with 8 tendons
+ * except the tendon-per-lane form; joint trees in the one-wave-per-64-envs form), bit 1 = rb_env_step_range_dev does (ball
+ * joints always; joint trees in that form); a clear bit = whole batches only (RB_EUNSUPPORTED otherwise). */
+int rb_range_capable(rb_sim *sim);
+int rb_step_range_dev(rb_sim *sim, int64_t first_env, int64_t n_envs, void *hip_stream, const float *d_act, float act_scale);
+int rb_env_step_range_dev(rb_sim *sim, int64_t first_env, int64_t n_envs, void *hip_stream,
+                          const float *d_act, float *d_obs, float *d_reward, uint32_t *d_done);
 /* episode statistics summed over this handle's envs since the last reset of
  * the accumulators: [sum episode return, sum return^2, n_episodes, sum episode
  * length, n_goal_reached, n_infeasible_env_steps, n_env_steps, sum reward]

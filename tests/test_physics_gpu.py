@@ -639,3 +639,44 @@ def test_run_time_specialised_fused_env_kernel(msj_robot):
         np.testing.assert_allclose(rew[same], h_rew[same], rtol=2e-5, atol=2e-4)
         assert same.all()
     vec.close(); host.stepper.close()
+
+
+@pytest.mark.parametrize("kernel,n", [(1, 3000), (1, 70000), (5, 3000)])
+def test_sub_ranges_on_two_streams_equal_the_whole_batch_step(msj_robot, kernel, n):
+    """rb_step_range_dev: the batch stepped as two disjoint ranges on two streams (the second one ragged) against one launch
+    over the whole batch - bit for bit; misaligned and out-of-range requests are refused, as are kernel forms that step whole
+    batches only."""
+    import torch
+    desc = msj_robot.get_description()
+    q, qd, sp = random_states(desc, n, 55)
+    out = []
+    for split in (False, True):
+        sim = _sim(msj_robot, n, integrator="rk4")
+        sim.select_kernel(kernel)
+        sim.set_state(q, qd)
+        act = torch.from_numpy(sp).cuda()
+        if not split:
+            sim.step_dev(act.data_ptr(), 1.0)
+        else:
+            assert sim.range_capable()
+            mid = ((n // 2 + 255) // 256) * 256
+            s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+            torch.cuda.synchronize()
+            sim.step_range_dev(mid, n - mid, s2.cuda_stream, act.data_ptr(), 1.0)
+            sim.step_range_dev(0, mid, s1.cuda_stream, act.data_ptr(), 1.0)
+            torch.cuda.synchronize()
+            with pytest.raises(Exception, match="multiple of 256"):
+                sim.step_range_dev(100, 200, None, act.data_ptr(), 1.0)
+            with pytest.raises(Exception, match="outside"):
+                sim.step_range_dev(0, n + 1, None, act.data_ptr(), 1.0)
+        sim.synchronize()
+        out.append(sim.read_state())
+        sim.close()
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    sim = _sim(msj_robot, 1024)
+    sim.select_kernel(KERNELS["tendon_per_lane"])
+    assert not sim.range_capable()
+    with pytest.raises(Exception, match="whole batches"):
+        sim.step_range_dev(0, 512, None, torch.zeros(1024, 8, device="cuda").data_ptr(), 1.0)
+    sim.close()

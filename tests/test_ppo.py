@@ -184,6 +184,33 @@ def test_graph_mode_on_a_robot_whose_kernels_are_built_at_run_time():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("robot_name,n", [("msj", 2048 + 256), ("msj", 70000), ("upper", 20000)])
+def test_two_chain_rollout_equals_the_one_chain_rollout(robot_name, n):
+    """PPO's graph rollout as two chains of (policy step, env step) launches over the two halves of the batch
+    (rb_env_step_range_dev on two streams) against the same rollout as one chain over the whole batch: the policy's noise is
+    keyed by the global sample index and envs are independent, so every rollout tensor is the same bit for bit - over two
+    replays (fresh noise, carried observations) and with a ragged second half."""
+    import torch
+    from gym_roboy_amd.envs.robots import MsjRobot, UpperBodyRobot
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    rolls = {}
+    for chains in (1, 2):
+        env = RoboyVecEnv(MsjRobot() if robot_name == "msj" else UpperBodyRobot(), n, seed=5)
+        if robot_name == "upper":
+            env.sim.select_kernel(1)                  # one wave per 64 envs: the joint-tree form that steps sub-ranges
+        agent = PPO(env, n_steps=6, device="cuda", ent_coef=0.1, reward_scale=0.01, seed=3, use_graphs=True, rollout_chains=chains)
+        agent.collect()
+        assert agent.rollout_chains == chains
+        roll = agent.collect()
+        rolls[chains] = {k: v.clone() for k, v in roll.items()}
+        assert env.stats()["n_env_steps"] == 2 * 6 * n
+        env.close()
+    for k in rolls[1]:
+        assert torch.equal(rolls[1][k], rolls[2][k]), k
+    assert bool(torch.isfinite(rolls[2]["adv"]).all())
+
+
+@pytest.mark.gpu
 def test_train_then_play_back(tmp_path, capsys):
     """train_parallel.py -> model.pkl -> visualize_agent.py, the reference's two drivers."""
     from gym_roboy_amd import train_parallel, visualize_agent
