@@ -304,7 +304,7 @@ class PPO:
         step) launches over the two halves of the batch on two streams, joined in front of GAE (the sub-range entry points of
         include/roboy_sim.h: one half's launch gaps and load / store phases lie under the other half's kernels; the results do
         not depend on the split); 1 = one chain over the whole batch; None = two from ``CHAIN_BATCH`` envs on where the env's
-        kernel form steps sub-ranges."""
+        kernel form steps sub-ranges and the policy is of MsjRobot's size."""
         self.env, self.dist, self.device = env, dist, torch.device(device)
         self._chains_arg = rollout_chains
         torch.manual_seed(seed)
@@ -356,7 +356,12 @@ class PPO:
         return x.to(self.device, dtype) if torch.is_tensor(x) else torch.as_tensor(x, dtype=dtype, device=self.device)
 
     # -- HIP-graph mode ------------------------------------------------------------
-    CHAIN_BATCH = 32768      # two chains from this many envs on (measured: profiles/r4_a/ppo_chains.log)
+    # two chains from this many envs on, for policies of MsjRobot's size (measured, us per vectorised rollout step, one -> two chains,
+    # profiles/r4_a/ppo_chains.log: MsjRobot 32 768 envs 21.7 -> 25.8, 65 536 envs 31.5 -> 28.4, 262 144 envs 87.6 -> 76.9, 1 M envs
+    # 349 -> 296; the upper body's 60 -> 38 policy step does not share the chip with a second launch: 65 536 envs 92.8 -> 91.5,
+    # 32 768 envs 55.6 -> 101.8)
+    CHAIN_BATCH = 65536
+    CHAIN_MAX_OBS = 29
 
     def _rollout_steps(self, b, lo, hi, stream_ptr=None):
         """The T (policy step, env step) pairs of envs [lo, hi): the whole batch on the env's stream (stream_ptr None), or one
@@ -408,7 +413,7 @@ class PPO:
             return 1
         if self._chains_arg is not None:
             return 2 if int(self._chains_arg) >= 2 and N >= 512 else 1
-        return 2 if N >= self.CHAIN_BATCH else 1
+        return 2 if N >= self.CHAIN_BATCH and self._fused.obs_dim <= self.CHAIN_MAX_OBS else 1
 
     def _build_rollout_graph(self):
         env, T, dev = self.env, self.n_steps, self.device
