@@ -13,9 +13,16 @@ extern thread_local std::string g_err;
 int fail(int code, const std::string &msg);
 
 // The rp_* entry points take no device argument: the device of a call is the one its first device pointer lives on.
-// enter_device() looks it up and makes it current (one process per GPU never notices; a process that drives several
-// GPUs gets its launches, its CU count and its LDS opt-ins on the right one).
-int enter_device(const void *d_ptr, int *dev_out);
+// DeviceScope looks it up and makes it current for the duration of the call, then puts the caller's current device back
+// (one process per GPU never notices; a process that drives several GPUs gets its launches, its CU count and its LDS
+// opt-ins on the right one without torch's current device changing behind its back).  rc != 0: the call fails with it.
+struct DeviceScope {
+    int rc = 0, dev = 0, prev = -1;
+    explicit DeviceScope(const void *d_ptr);
+    ~DeviceScope();
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
 int cu_count(int dev);
 // Dynamic LDS above 64 KB has to be granted per kernel with hipFuncSetAttribute - per DEVICE: the grant is remembered per
 // (kernel id, device), under a mutex.  lds_grant_needed() is the bookkeeping alone (host only; tests/test_policy_abi.py

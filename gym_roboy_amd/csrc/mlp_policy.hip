@@ -36,19 +36,20 @@ namespace rpd {
 thread_local std::string g_err;
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
-int enter_device(const void *d_ptr, int *dev_out) {
+DeviceScope::DeviceScope(const void *d_ptr) {
     hipPointerAttribute_t at;
-    int dev = 0;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); rc = fail(RP_EHIP, "no HIP device"); return; }
+    dev = cur;
     if (d_ptr && hipPointerGetAttributes(&at, d_ptr) == hipSuccess && at.type == hipMemoryTypeDevice) dev = at.device;
-    else {
-        (void)hipGetLastError();                           // (a pointer the runtime does not know leaves an error behind)
-        if (hipGetDevice(&dev) != hipSuccess) return fail(RP_EHIP, "no HIP device");
+    else (void)hipGetLastError();                          // (a pointer the runtime does not know leaves an error behind)
+    if (dev != cur) {
+        const hipError_t e = hipSetDevice(dev);
+        if (e != hipSuccess) { rc = fail(RP_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); return; }
+        prev = cur;                                        // restored when the call returns
     }
-    const hipError_t e = hipSetDevice(dev);
-    if (e != hipSuccess) return fail(RP_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
-    *dev_out = dev;
-    return RP_OK;
 }
+DeviceScope::~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
 
 int cu_count(int dev) {
     int n = 256;
@@ -61,22 +62,27 @@ constexpr int GRANT_KERNELS = 8, GRANT_DEVICES = 64;
 std::mutex g_grant_mutex;
 size_t g_granted[GRANT_KERNELS][GRANT_DEVICES];            // bytes granted so far (0: the default 64 KB)
 }
-bool lds_grant_needed(int kernel_id, int dev, size_t lds) {
+static bool tracked(int kernel_id, int dev) { return kernel_id >= 0 && kernel_id < GRANT_KERNELS && dev >= 0 && dev < GRANT_DEVICES; }
+// the bookkeeping alone (caller holds the mutex or is the single-threaded test hook): does (kernel, device) still need a grant of `lds`?
+static bool needs_grant_locked(int kernel_id, int dev, size_t lds) {
     if (lds <= 64 * 1024) return false;
-    if (kernel_id < 0 || kernel_id >= GRANT_KERNELS || dev < 0 || dev >= GRANT_DEVICES) return true;   // not tracked: always ask
+    if (!tracked(kernel_id, dev)) return true;                                                           // not tracked: always ask
+    return g_granted[kernel_id][dev] < lds;
+}
+bool lds_grant_needed(int kernel_id, int dev, size_t lds) {
     std::lock_guard<std::mutex> lock(g_grant_mutex);
-    if (g_granted[kernel_id][dev] >= lds) return false;
-    g_granted[kernel_id][dev] = lds;
-    return true;
+    const bool need = needs_grant_locked(kernel_id, dev, lds);
+    if (need && tracked(kernel_id, dev)) g_granted[kernel_id][dev] = lds;      // (the test hook plays the successful grant)
+    return need;
 }
 int grant_lds(const void *kernel, int kernel_id, int dev, size_t lds) {
-    if (!lds_grant_needed(kernel_id, dev, lds)) return RP_OK;
+    // the mutex is held across hipFuncSetAttribute and the grant is recorded only once it has succeeded: a second thread
+    // cannot see "granted" and launch with more than 64 KB before the attribute is set
+    std::lock_guard<std::mutex> lock(g_grant_mutex);
+    if (!needs_grant_locked(kernel_id, dev, lds)) return RP_OK;
     const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    if (e != hipSuccess) {
-        std::lock_guard<std::mutex> lock(g_grant_mutex);
-        if (kernel_id >= 0 && kernel_id < GRANT_KERNELS && dev >= 0 && dev < GRANT_DEVICES) g_granted[kernel_id][dev] = 0;
-        return fail(RP_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
-    }
+    if (e != hipSuccess) return fail(RP_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+    if (tracked(kernel_id, dev)) g_granted[kernel_id][dev] = lds;
     return RP_OK;
 }
 }  // namespace rpd
@@ -300,7 +306,7 @@ int rp_act_dev(const float *d_packed, const float *d_obs, float *d_act, float *d
     if (lds > 160 * 1024) return fail(RP_EUNSUPPORTED, "policy too large for the LDS-resident form");
     hipError_t e = hipSuccess;
     int dev = 0;
-    if (int rc = enter_device(d_packed, &dev)) return rc;          // the blob's device is the device of the call
+    DeviceScope scope(d_packed); if (scope.rc) return scope.rc; dev = scope.dev;          // the blob's device is the device of the call
     if (int rc = grant_lds(reinterpret_cast<const void *>(&mlp_act_kernel), 0, dev, lds)) return rc;   // per kernel and device
     const int n_cu = cu_count(dev);
     const long n_tiles = (n + 63) / 64;

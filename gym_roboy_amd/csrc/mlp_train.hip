@@ -644,8 +644,7 @@ int rp_gae_dev(const float *d_rew, const float *d_val, const float *d_done, cons
                float *d_adv, float *d_ret, int n_steps, int64_t n_envs, void *stream) {
     if (!d_rew || !d_val || !d_done || !d_last_val || !d_adv || !d_ret) return fail(RP_EINVAL, "null argument");
     if (n_steps < 1 || n_envs < 1) return fail(RP_EINVAL, "n_steps and n_envs must be >= 1");
-    int dev = 0;
-    if (int rc = enter_device(d_rew, &dev)) return rc;
+    DeviceScope scope(d_rew); if (scope.rc) return scope.rc;
     hipLaunchKernelGGL(gae_kernel, dim3(unsigned((n_envs + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), d_rew,
                        d_val, d_done, d_last_val, gamma, lam, d_adv, d_ret, n_steps, long(n_envs));
     const hipError_t e = hipGetLastError();
@@ -684,7 +683,7 @@ int rp_ppo_grad_dev(const float *d_packed_train, const float *d_obs, const float
     if (batch < 1) return fail(RP_EINVAL, "batch must be >= 1");
     if (rp_train_packed_floats(obs_dim, act_dim) < 0) return RP_EUNSUPPORTED;
     int dev = 0;
-    if (int rc0 = enter_device(d_packed_train, &dev)) return rc0;      // the blob's device is the device of the call
+    DeviceScope scope(d_packed_train); if (scope.rc) return scope.rc; dev = scope.dev;      // the blob's device is the device of the call
     const Layout L = layout_of(obs_dim, act_dim);
     const int gs = gstride_of(obs_dim, act_dim);
     const long blocks = grad_blocks(batch), waves = blocks * WAVES_PER_BLOCK;

@@ -153,7 +153,7 @@ int rp_perm_host(uint64_t key, int64_t n, int64_t first, int64_t count, int64_t 
 int rp_perm_dev(uint64_t key, int64_t n, int64_t first, int64_t count, int64_t *d_out, void *stream) {
     if (!d_out || n < 1 || first < 0 || count < 0 || first + count > n) return fail(RP_EINVAL, "need 0 <= first, first + count <= n");
     int dev = 0;
-    if (int rc = enter_device(d_out, &dev)) return rc;
+    DeviceScope scope(d_out); if (scope.rc) return scope.rc; dev = scope.dev;
     if (count == 0) return RP_OK;
     long blocks = (count + 255) / 256;
     const long cap = 8l * cu_count(dev);
@@ -170,8 +170,7 @@ int64_t rp_adv_stats_scratch_doubles(void) { return 2 * STAT_BLOCKS + 1; }
 int rp_adv_stats_dev(const float *d_adv, const int64_t *d_index, int64_t batch, float *d_stats2, double *d_scratch, void *stream) {
     if (!d_adv || !d_stats2 || !d_scratch) return fail(RP_EINVAL, "null argument");
     if (batch < 1) return fail(RP_EINVAL, "batch must be >= 1");
-    int dev = 0;
-    if (int rc = enter_device(d_adv, &dev)) return rc;
+    DeviceScope scope(d_adv); if (scope.rc) return scope.rc;
     long blocks = (batch + 2047) / 2048;                   // at least eight samples per thread
     if (blocks > STAT_BLOCKS) blocks = STAT_BLOCKS;
     hipLaunchKernelGGL(adv_stats_kernel, dim3(unsigned(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), d_adv,
@@ -188,8 +187,7 @@ int rp_clip_adam_dev(float *d_params, const float *d_grad, float *d_m, float *d_
     if (step < 1) return fail(RP_EINVAL, "step counts from 1");
     const int64_t n = rp_grad_floats(obs_dim, act_dim);
     if (n < 0) return RP_EUNSUPPORTED;
-    int dev = 0;
-    if (int rc = enter_device(d_params, &dev)) return rc;
+    DeviceScope scope(d_params); if (scope.rc) return scope.rc;
     AdamArgs a;
     a.p = d_params; a.g = d_grad; a.m = d_m; a.v = d_v; a.n = int(n);
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;

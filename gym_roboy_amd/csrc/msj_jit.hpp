@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -43,6 +44,7 @@ struct Rtc {
     decltype(&hiprtcGetCodeSize) code_size = nullptr;
     decltype(&hiprtcGetCode) code = nullptr;
     decltype(&hiprtcDestroyProgram) destroy = nullptr;
+    decltype(&hiprtcVersion) version = nullptr;
     bool ok = false;
 };
 
@@ -57,6 +59,7 @@ inline const Rtc &rtc() {
         RBJ_SYM(compile, "hiprtcCompileProgram"); RBJ_SYM(log_size, "hiprtcGetProgramLogSize");
         RBJ_SYM(log, "hiprtcGetProgramLog"); RBJ_SYM(lowered, "hiprtcGetLoweredName");
         RBJ_SYM(code_size, "hiprtcGetCodeSize"); RBJ_SYM(code, "hiprtcGetCode"); RBJ_SYM(destroy, "hiprtcDestroyProgram");
+        RBJ_SYM(version, "hiprtcVersion");
 #undef RBJ_SYM
         x.ok = x.create && x.add_name && x.compile && x.log_size && x.log && x.lowered && x.code_size && x.code && x.destroy;
         return x;
@@ -121,12 +124,17 @@ inline std::string cache_dir() {
     } else {
         const char *x = std::getenv("XDG_CACHE_HOME"), *h = std::getenv("HOME");
         if (x && x[0]) d = std::string(x) + "/gym_roboy_amd";
-        else if (h && h[0]) { (void)mkdir((std::string(h) + "/.cache").c_str(), 0777); d = std::string(h) + "/.cache/gym_roboy_amd"; }
+        else if (h && h[0]) { (void)mkdir((std::string(h) + "/.cache").c_str(), 0700); d = std::string(h) + "/.cache/gym_roboy_amd"; }
         else return "";
     }
-    (void)mkdir(d.c_str(), 0777);
+    // The files are code objects this process will load and run: the directory is created for the owner alone and is used
+    // only if it belongs to the current user and nobody else can write to it (a shared or planted directory is ignored:
+    // the kernels are then compiled, never loaded from disk).  Never pruned: remove the directory to clear it.
+    (void)mkdir(d.c_str(), 0700);
     struct stat st;
-    return stat(d.c_str(), &st) == 0 && S_ISDIR(st.st_mode) ? d : "";
+    if (stat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return "";
+    if (st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) return "";
+    return d;
 }
 
 inline uint64_t fnv1a64(const void *data, size_t n, uint64_t h = 1469598103934665603ull) {
@@ -135,9 +143,16 @@ inline uint64_t fnv1a64(const void *data, size_t n, uint64_t h = 146959810393466
     return h;
 }
 
-inline std::string cache_key(const std::string &src, const std::string &arch, const char *const *names, int nk) {
+inline std::string cache_key(const std::string &src, const std::string &arch, const char *const *names, int nk, const std::string &options) {
     uint64_t h = fnv1a64(src.data(), src.size());
     h = fnv1a64(arch.data(), arch.size(), h);
+    h = fnv1a64(options.data(), options.size(), h);
+    // the compiler and the runtime that will load the code object: a toolchain upgrade must not be served stale code
+    int ver[4] = {0, 0, 0, 0};
+    if (rtc().version) (void)rtc().version(&ver[0], &ver[1]);
+    (void)hipRuntimeGetVersion(&ver[2]);
+    (void)hipDriverGetVersion(&ver[3]);
+    h = fnv1a64(ver, sizeof ver, h);
     for (int k = 0; k < nk; ++k) h = fnv1a64(names[k], std::strlen(names[k]) + 1, h);
     Dl_info info;
     struct stat st;
@@ -155,6 +170,11 @@ constexpr char CACHE_MAGIC[8] = {'R', 'B', 'J', 'C', '0', '0', '1', '\n'};
 inline bool cache_load(const std::string &path, int nk, std::vector<std::string> &lowered, std::string &code) {
     FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) return false;
+    struct stat fst;
+    if (fstat(fileno(f), &fst) != 0 || fst.st_uid != geteuid() || !S_ISREG(fst.st_mode) || (fst.st_mode & (S_IWGRP | S_IWOTH))) {
+        std::fclose(f);                      // not this user's file, or writable by others: never load it
+        return false;
+    }
     bool ok = false;
     char magic[8];
     uint64_t n_names = 0, n_code = 0;
@@ -179,8 +199,9 @@ inline bool cache_load(const std::string &path, int nk, std::vector<std::string>
 
 inline void cache_store(const std::string &path, const std::vector<std::string> &lowered, const std::string &code) {
     const std::string tmp = path + ".tmp." + std::to_string(static_cast<long long>(getpid()));
-    FILE *f = std::fopen(tmp.c_str(), "wb");
-    if (!f) return;
+    const int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0600);
+    FILE *f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
+    if (!f) { if (fd >= 0) ::close(fd); return; }
     const uint64_t n_names = lowered.size(), n_code = code.size(), sum = fnv1a64(code.data(), code.size());
     bool ok = std::fwrite(CACHE_MAGIC, 1, 8, f) == 8 && std::fwrite(&n_names, 8, 1, f) == 1;
     for (const std::string &l : lowered) {
@@ -219,7 +240,8 @@ inline bool compile_and_load(const std::string &src, const char *file_name, cons
         arch = "--offload-arch=" + a.substr(0, a.find(':'));
     }
     const std::string dir = cache_dir();
-    const std::string cached = dir.empty() ? "" : dir + "/" + cache_key(src, arch, names, nk) + ".rbjc";
+    const std::string opt_text = "-O3 -std=c++17 -fno-slp-vectorize";
+    const std::string cached = dir.empty() ? "" : dir + "/" + cache_key(src, arch, names, nk, opt_text) + ".rbjc";
     if (!cached.empty()) {
         std::vector<std::string> lowered;
         std::string code;
@@ -232,7 +254,7 @@ inline bool compile_and_load(const std::string &src, const char *file_name, cons
     for (int k = 0; k < nk; ++k) r.add_name(prog, names[k]);
     const std::string inc = "-I" + library_dir();
     cache_stats().compiles++;
-    const char *opts[] = {arch.c_str(), "-O3", "-std=c++17", "-fno-slp-vectorize", inc.c_str()};
+    const char *opts[] = {arch.c_str(), "-O3", "-std=c++17", "-fno-slp-vectorize", inc.c_str()};      // (opt_text above: part of the cache key)
     const hiprtcResult rc = r.compile(prog, 5, opts);
     if (rc != HIPRTC_SUCCESS) {
         size_t n = 0;

@@ -258,11 +258,65 @@ class FusedAdam:
         return {"fused_adam": True, "m": self.m.clone(), "v": self.v.clone(), "t": self.t}
 
     def load_state_dict(self, sd):
+        if tuple(sd["m"].shape) != tuple(self.m.shape) or tuple(sd["v"].shape) != tuple(self.v.shape):
+            raise ValueError("optimiser state of another policy layout: moments of %d values, this policy's flat vector has %d "
+                             "(obs_dim %d, act_dim %d)" % (sd["m"].numel(), self.m.numel(), self._f.obs_dim, self._f.act_dim))
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.t = int(sd["t"])
 
     def rebind(self, state_dict):
         """load_state_dict() of the module copies INTO the views (in place), so nothing to re-point; kept for clarity."""
         return state_dict
+
+
+def _flat_names(policy):
+    """layout name (include/roboy_policy.h: the flat gradient / parameter vector) -> parameter of an MlpPolicy"""
+    pi, vf = policy.pi, policy.vf
+    return {"pi_w1": pi[0].weight, "pi_b1": pi[0].bias, "pi_w2": pi[2].weight, "pi_b2": pi[2].bias, "pi_w3": pi[4].weight,
+            "pi_b3": pi[4].bias, "vf_w1": vf[0].weight, "vf_b1": vf[0].bias, "vf_w2": vf[2].weight, "vf_b2": vf[2].bias,
+            "vf_w3": vf[4].weight, "vf_b3": vf[4].bias, "log_std": policy.log_std}
+
+
+def _param_slices(policy, layout):
+    """[(offset, shape)] in the flat vector for policy.parameters(), in that order"""
+    by_id = {id(p): name for name, p in _flat_names(policy).items()}
+    return [layout[by_id[id(p)]] for p in policy.parameters()]
+
+
+def adam_state_torch_to_flat(sd, policy, layout, m, v):
+    """Moments and step count of a ``torch.optim.Adam`` state_dict over ``policy.parameters()`` into the flat vectors m, v of
+    the fused optimiser; returns the step count, or None if the state holds no moments yet (an optimiser that never stepped)."""
+    state = sd.get("state", {})
+    if not state:
+        return None
+    order = [i for g in sd["param_groups"] for i in g["params"]]
+    slices = _param_slices(policy, layout)
+    if len(order) != len(slices):
+        raise ValueError("optimiser state of another module: %d parameters, this policy has %d" % (len(order), len(slices)))
+    t = 0
+    for idx, (off, shape) in zip(order, slices):
+        st = state.get(idx)
+        if st is None:
+            continue
+        if tuple(st["exp_avg"].shape) != tuple(shape):
+            raise ValueError("optimiser state of another policy layout: %r against %r" % (tuple(st["exp_avg"].shape), tuple(shape)))
+        n = int(st["exp_avg"].numel())
+        m[off:off + n].copy_(st["exp_avg"].reshape(-1)); v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+        t = max(t, int(st["step"]))
+    return t
+
+
+def adam_state_flat_to_torch(fsd, policy, layout, template_sd):
+    """A ``FusedAdam`` state (flat moments m, v and step count t) as the state_dict of a ``torch.optim.Adam`` over
+    ``policy.parameters()`` with the parameter groups of ``template_sd``."""
+    order = [i for g in template_sd["param_groups"] for i in g["params"]]
+    state = {}
+    for idx, (off, shape) in zip(order, _param_slices(policy, layout)):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        state[idx] = {"step": torch.tensor(float(fsd["t"])), "exp_avg": fsd["m"][off:off + n].view(shape).clone(),
+                      "exp_avg_sq": fsd["v"][off:off + n].view(shape).clone()}
+    return {"state": state, "param_groups": template_sd["param_groups"]}
 
 
 def average_gradients(module, dist=None):
@@ -616,7 +670,23 @@ class PPO:
             self._fadam.load_state_dict(ck["optimizer"])
         elif self._fgrad is None and not fused_ck:
             self.opt.load_state_dict(ck["optimizer"])
-        # (a checkpoint of the other optimiser form: the moments start afresh)
+        elif self._fgrad is not None:
+            # a checkpoint of the torch path (fused_update=False, or written before the fused update was the default): its
+            # moments and step count move into the flat vectors
+            t = adam_state_torch_to_flat(ck["optimizer"], self.policy, self._fgrad._layout, self._fadam.m, self._fadam.v)
+            if t is None:
+                import warnings
+                warnings.warn("the checkpoint's optimiser had not stepped yet: Adam's moments start afresh")
+            else:
+                self._fadam.t = t
+        else:
+            # a checkpoint of the fused path resumed on the torch path: torch's per-parameter state from the flat moments
+            from . import _policy_native as pn
+            layout, n = pn.grad_layout(self.policy.pi[0].in_features, self.policy.pi[-1].out_features)
+            if int(ck["optimizer"]["m"].numel()) != int(n):
+                raise ValueError("optimiser state of another policy layout: %d values, this policy's flat vector has %d"
+                                 % (ck["optimizer"]["m"].numel(), n))
+            self.opt.load_state_dict(adam_state_flat_to_torch(ck["optimizer"], self.policy, layout, self.opt.state_dict()))
         self.num_timesteps = ck["num_timesteps"]
         self._epoch = int(ck.get("epoch", 0))
         if self._fused is not None:

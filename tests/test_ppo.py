@@ -87,6 +87,39 @@ def test_two_rank_gradient_average_equals_full_batch_gradient(tmp_path):
         assert torch.allclose(a, p.grad, atol=1e-6)
 
 
+def test_adam_state_moves_between_the_two_optimiser_forms():
+    """A checkpoint of the torch path resumed on the fused path and back (PPO.load): torch.optim.Adam's per-parameter
+    moments <-> the flat moment vectors of FusedAdam, laid out like the gradient vector of include/roboy_policy.h."""
+    import torch
+    from gym_roboy_amd import _policy_native as pn
+    from gym_roboy_amd.ppo import MlpPolicy, adam_state_flat_to_torch, adam_state_torch_to_flat
+    torch.manual_seed(0)
+    policy = MlpPolicy(9, 8)
+    opt = torch.optim.Adam(policy.parameters(), lr=1e-3)
+    for _ in range(3):
+        opt.zero_grad()
+        a, logp, v = policy.act(torch.randn(32, 9))
+        d = policy.dist(torch.randn(32, 9))
+        (d.log_prob(torch.randn(32, 8)).sum() + policy.value(torch.randn(32, 9)).sum()).backward()
+        opt.step()
+    layout, n = pn.grad_layout(9, 8)
+    m, v = torch.zeros(n), torch.zeros(n)
+    t = adam_state_torch_to_flat(opt.state_dict(), policy, layout, m, v)
+    assert t == 3
+    off, shape = layout["vf_w2"]
+    assert torch.equal(m[off:off + 64 * 64].view(64, 64), opt.state[policy.vf[2].weight]["exp_avg"])
+    off, shape = layout["log_std"]
+    assert torch.equal(v[off:off + 8], opt.state[policy.log_std]["exp_avg_sq"])
+    back = adam_state_flat_to_torch({"m": m, "v": v, "t": t}, policy, layout, opt.state_dict())
+    opt2 = torch.optim.Adam(policy.parameters(), lr=1e-3)
+    opt2.load_state_dict(back)
+    for p in policy.parameters():
+        assert torch.equal(opt2.state[p]["exp_avg"], opt.state[p]["exp_avg"]) and float(opt2.state[p]["step"]) == 3.0
+    assert adam_state_torch_to_flat(torch.optim.Adam(policy.parameters()).state_dict(), policy, layout, m, v) is None
+    with pytest.raises(ValueError):
+        adam_state_torch_to_flat(opt.state_dict(), MlpPolicy(5, 8), pn.grad_layout(5, 8)[0], m, v)
+
+
 @pytest.mark.gpu
 def test_ppo_runs_on_the_device_env_without_host_copies():
     from gym_roboy_amd.envs.robots import MsjRobot
@@ -158,6 +191,37 @@ def test_graph_mode_learns_counts_and_resumes(tmp_path):
     agent.learn(total_timesteps=256 * 16, log=logs.append)
     assert np.isfinite(logs[-1]["loss"])
     assert any(not torch.equal(before[k], v) for k, v in agent.policy.state_dict().items())
+    env.close()
+
+
+@pytest.mark.gpu
+def test_checkpoints_resume_across_the_two_optimiser_forms(tmp_path):
+    """model.pkl written by the torch path (fused_update=False) resumes on the fused path with Adam's moments and step count,
+    and the other way round (PPO.load used to restart them silently)."""
+    import torch
+    from gym_roboy_amd.envs.robots import MsjRobot
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    env = RoboyVecEnv(MsjRobot(), 512, seed=1)
+    kw = dict(n_steps=8, device="cuda", ent_coef=0.1, reward_scale=0.01, seed=1)
+    a = PPO(env, fused_policy=False, fused_update=False, **kw)
+    a.learn(total_timesteps=512 * 8 * 2)
+    pa = str(tmp_path / "torch.pkl")
+    a.save(pa)
+    b = PPO(env, **kw)
+    assert b._fgrad is not None
+    b.load(pa)
+    assert b._fadam.t == a.opt.state[a.policy.log_std]["step"] and float(b._fadam.m.abs().sum()) > 0
+    off, shape = b._fgrad._layout["pi_w1"]
+    assert torch.equal(b._fadam.v[off:off + 64 * 9].view(64, 9), a.opt.state[a.policy.pi[0].weight]["exp_avg_sq"])
+    b.learn(total_timesteps=512 * 8)
+    pb = str(tmp_path / "fused.pkl")
+    b.save(pb)
+    c = PPO(env, fused_policy=False, fused_update=False, **kw)
+    c.load(pb)
+    assert float(c.opt.state[c.policy.log_std]["step"]) == b._fadam.t
+    off, shape = b._fgrad._layout["vf_b2"]
+    assert torch.equal(c.opt.state[c.policy.vf[2].bias]["exp_avg"], b._fadam.m[off:off + 64])
+    c.learn(total_timesteps=512 * 8)
     env.close()
 
 
