@@ -22,15 +22,15 @@ reported under "also"; they are not the headline.
 Timing: W untimed warm-up steps, then the K-step region - bracketed by a
 barrier and a device synchronisation on both sides - is timed R times (R chosen
 so that the repeats cover >= 50 ms of device time, so a small K does not turn
-the number into a measurement of launch latency); ``ms_per_step`` is the median
+the number into a measurement of launch latency); ``ms_per_step`` is the mean
 over the repeats of (max over ranks of the region's wall time) / K and ``value``
 the env steps of all ranks in one region divided by that time.
 
 N > 1: launched by torch.distributed.run, one rank per GPU; envs shard
 contiguously (weak scaling: the per-GPU batch is fixed), no data-path
-collective; every STATS_EVERY steps and at the end of every timed region the
-rank's episode statistics (8 doubles) are all-reduced over RCCL, and the line
-carries a ``collective`` object that audits it.  Prints ONE JSON line on rank 0.
+collective; every STATS_EVERY = 100 steps (counted across the timed regions) the
+rank's episode statistics (8 doubles) are reduced on the device and all-reduced
+over RCCL, and the line carries a ``collective`` object that audits it.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -174,7 +174,7 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
     for r in range(RING):
         sim.fill_actions_dev(ring.data_ptr() + 4 * r * slab, r)
     # Episode statistics: every rank reduces its envs' counters on the device (rb_env_stats_dev) after every
-    # STATS_EVERY steps and at the end of every timed region - at N = 1 too, so that every N runs the same
+    # STATS_EVERY steps, counted across the timed regions - at N = 1 too, so that every N runs the same
     # per-GPU work and the scaling curve measures the collective alone - and N > 1 all-reduces the block.
     # The all-reduce: 64 bytes, enqueued IN-LINE on the launch stream (a non-async
     # c10d op runs on the current stream).  Measured on one MI355X (profiles/r1_b/
@@ -183,7 +183,7 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
     # for the whole rollout, independent of how often it runs; in line it costs its own
     # ~20 us per call and nothing else.
     stats_ring = [torch.zeros(8, dtype=torch.float64, device="cuda") for _ in range(2)]
-    state = {"chunk": 0, "last": stats_ring[0], "steps_issued": 0, "calls": 0, "ar_events": []}
+    state = {"chunk": 0, "last": stats_ring[0], "steps_issued": 0, "calls": 0, "ar_events": [], "since": 0}
     act_scale = float(robot.get_action_space().high[0])
 
     def reduce_stats():
@@ -209,22 +209,22 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
             dist.all_reduce(host)
             buf.copy_(host)
 
-    def rollout(k, final_reduce=False):
-        """k per-step launches; the statistics block is all-reduced after every full
-        STATS_EVERY-step chunk and - when asked - after the last (partial) chunk too."""
+    def advance(k, before_reduce=None):
+        """k steps; the statistics block is reduced (and all-reduced) every STATS_EVERY steps, counted ACROSS calls - the
+        measurement spec's cadence whatever K a timed region has.  before_reduce: called once all k
+        steps are issued, in front of a reduction that falls on the region's end (the closing event goes there)."""
         done = 0
-        reduced = True
         while done < k:
-            chunk = min(STATS_EVERY, k - done)
+            chunk = min(STATS_EVERY - state["since"], k - done)
             sim.rollout_dev(ring.data_ptr(), RING, chunk, act_scale, use_graph=use_graph)
             done += chunk
             state["steps_issued"] += chunk
-            reduced = False
-            if chunk == STATS_EVERY:
+            state["since"] += chunk
+            if done == k and before_reduce is not None:
+                before_reduce()
+            if state["since"] >= STATS_EVERY:
                 reduce_stats()
-                reduced = True
-        if final_reduce and not reduced:
-            reduce_stats()
+                state["since"] = 0
 
     def timed_region():
         """One K-step region between barrier + synchronize pairs.  Returns (wall seconds
@@ -237,16 +237,7 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
-        done = 0
-        while done < steps:                      # rollout() with the closing event before the final reduce
-            chunk = min(STATS_EVERY, steps - done)
-            sim.rollout_dev(ring.data_ptr(), RING, chunk, act_scale, use_graph=use_graph)
-            done += chunk
-            state["steps_issued"] += chunk
-            if done == steps:
-                ev1.record(stream)
-            if chunk == STATS_EVERY or done == steps:
-                reduce_stats()                   # at least one per region, whatever K is (one GPU: the local reduction alone)
+        advance(steps, before_reduce=lambda: ev1.record(stream))
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0          # this rank: start of the region -> its work is complete
         if dist is not None:
@@ -259,8 +250,8 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
         return wall, ev0.elapsed_time(ev1) * 1e-3
 
     # 16 untimed steps from the reset state decorrelate the envs, then warm-up
-    rollout(16)
-    rollout(warmup)
+    advance(16)
+    advance(warmup)
     # untimed rehearsal of the timed region, so that no hipGraph is captured / instantiated
     # inside it (graphs are cached per chunk size) and RCCL's first call is behind us
     timed_region()
@@ -274,8 +265,11 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
         w, d = timed_region()
         walls.append(w)
         devs.append(d)
-    wall = statistics.median(walls)
-    launch_s = statistics.median(devs) / steps   # HIP events on the launch stream, per launch
+    # The statistics reduction (+ all-reduce at N > 1) falls into one region in every STATS_EVERY / K: the MEAN over the repeats
+    # carries its amortised cost (a median would hide it whenever fewer than half of the regions contain one).
+    wall = statistics.fmean(walls)
+    launch_s = statistics.median(devs) / steps   # HIP events on the launch stream around the K steps (no reduction inside unless K > STATS_EVERY)
+    reduce_stats()                               # untimed: the audit below wants a block that covers every step issued
     q, qd, feas = sim.read_state()
     info = sim.info()
     # audit of the collective: the all-reduced block's slot 6 is the sum over ranks of the
@@ -301,6 +295,7 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
         "substeps": nsub, "steps": steps, "warmup": warmup, "repeats": repeats,
         "value": world * n_envs * steps / wall, "ms_per_step": wall * 1e3 / steps,
         "ms_per_step_min": min(walls) * 1e3 / steps, "ms_per_step_max": max(walls) * 1e3 / steps,
+        "ms_per_step_median": statistics.median(walls) * 1e3 / steps,
         "timed_device_ms": sum(devs) * 1e3,
         "launch_us_events": launch_s * 1e6,
         "roofline": roofline(robot_name, integrator, nsub, n_envs, info["bytes_per_env_step"], launch_s,
@@ -617,12 +612,12 @@ def main():
                                                                                % (head["roofline"]["launches_per_step"], head["roofline"]["launches_per_step"])
                                                                                if head["roofline"].get("launches_per_step", 1) > 1 else ""))
                                   if use_graph else "eager per-step launches"),
-                       "parallelism": ("env shards x%d, RCCL all-reduce of episode statistics every %d steps and at the "
-                                       "end of every timed region" % (world, STATS_EVERY)) if world > 1 else "single GPU",
-                       "timing": "median of %d repeats of the %d-step region (barrier + synchronize on both sides, "
-                                 "max over ranks); %.1f ms of device time in all"
+                       "parallelism": ("env shards x%d, RCCL all-reduce of episode statistics every %d steps"
+                                       % (world, STATS_EVERY)) if world > 1 else "single GPU",
+                       "timing": "mean of %d repeats of the %d-step region (barrier + synchronize on both sides, "
+                                 "max over ranks; the statistics reduction every 100 steps falls into some of them); %.1f ms of device time in all"
                                  % (head["repeats"], head["steps"], head["timed_device_ms"])},
-            "ms_per_step_spread": [head["ms_per_step_min"], head["ms_per_step_max"]],
+            "ms_per_step_spread": [head["ms_per_step_min"], head["ms_per_step_max"]], "ms_per_step_median": head["ms_per_step_median"],
             "roofline": dict(head["roofline"], kernel=head["kernel"], one_launch_us=(one_launch or {}).get("us_events"),
                              one_launch=one_launch, configs=configs,
                              note="launch_us_events = HIP events on the launch stream around the K per-step launches "

@@ -48,6 +48,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert abs(d["value"] - d["config"]["total_envs"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-6
     _check_roofline(d["roofline"], 262144)
     assert d["roofline"]["bound"] == "valu"       # four acceleration evaluations per env step
+    assert d["roofline"]["launches_per_step"] == 2 and d["roofline"]["one_launch_us"] > d["roofline"]["launch_us_events"]
+    assert d["roofline"]["configs"] == {}         # --no-also
     # wall time per step (barrier + sync around 20 launches) within 12 % of the device-event time per launch
     assert d["ms_per_step"] * 1e3 < 1.12 * d["roofline"]["launch_us_events"]
     c = d["cpu_baseline"]
@@ -66,6 +68,10 @@ def test_bench_default_run_carries_every_config_with_sanity_fields():
         assert w in names, names
     ppo = {a["workload"]: a for a in d["also"] if a["workload"].startswith("ppo-")}
     assert ppo["ppo-65536-fused"]["value"] > 3 * ppo["ppo-65536-torch"]["value"]      # the consumer on the matrix cores
+    cfg = d["roofline"]["configs"]                # the driver's record keeps `roofline`: the secondary workloads in compact form
+    for w in ("msj-4096-euler", "msj-262144-euler", "msj-2097152-euler", "upper-body-8192-euler", "upper-body-8192-rk4", "fused-env-2097152"):
+        assert cfg[w]["us_events"] > 0 and cfg[w]["hbm_frac"] > 0 and cfg[w]["finite"] is True, w
+    assert cfg["msj-262144-euler"]["hbm_frac"] > 0.4 and cfg["ppo-65536-fused"]["rollout_us_per_step"] > 0
     for a in d["also"]:
         assert a["finite"] is True and 0.0 <= a["feasible_frac"] <= 1.0, a["workload"]
         if "roofline" in a:
@@ -73,8 +79,8 @@ def test_bench_default_run_carries_every_config_with_sanity_fields():
 
 
 def test_bench_collective_path_with_one_rccl_rank():
-    """The multi-rank code path (process group over RCCL, in-line statistics all-reduce at the end of
-    every timed region and every STATS_EVERY steps, barrier, max-reduce) rehearsed with world size 1
+    """The multi-rank code path (process group over RCCL, in-line statistics all-reduce every STATS_EVERY
+    steps counted across the timed regions, barrier, max-reduce) rehearsed with world size 1
     at the driver's --steps 20: one JSON line on stdout (RCCL's banner must not reach it), the
     collective object audits the all-reduce, and the collective costs little throughput."""
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
@@ -83,20 +89,22 @@ def test_bench_collective_path_with_one_rccl_rank():
     assert d["n_gpus"] == 1 and d["steps"] == 20
     c = d["collective"]
     assert c["ok"] and c["world_size"] == 1 and c["backend"].startswith("rccl")
-    assert c["allreduce_calls"] == d["repeats"] + 2            # one per timed region (+ the rehearsal and the sizing region)
-    assert c["n_env_steps_allreduced"] == c["expected"] == 262144.0 * (16 + 5 + 20 * (d["repeats"] + 2))
+    total = 16 + 5 + 20 * (d["repeats"] + 2)                   # decorrelation + warm-up + the regions (rehearsal and sizing region included)
+    assert c["allreduce_calls"] == total // 100 + 1            # every 100 steps across the regions, + the closing one for the audit
+    assert c["n_env_steps_allreduced"] == c["expected"] == 262144.0 * total
+    assert d["roofline"]["one_launch"]["us_events"] > d["roofline"]["launch_us_events"]      # the one-launch form beside the chains
     assert d["sanity"]["allreduced_stats"][6] == c["expected"]
     assert d["ms_per_step"] * 1e3 < 1.25 * d["roofline"]["launch_us_events"]
 
 
 def test_bench_collective_with_full_chunks():
-    """--steps above STATS_EVERY: an all-reduce after every full chunk and one after the partial tail."""
+    """--steps above STATS_EVERY: an all-reduce every STATS_EVERY steps, inside the regions too, and the closing one."""
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                MASTER_PORT="29634", ROBOY_BENCH_DIST_AT_1="1", ROBOY_BENCH_STATS_EVERY="100")
     d = _run(["--gpus", "1", "--steps", "250", "--warmup", "10", "--no-also", "--no-cpu-baseline",
               "--workload", "msj-4096-euler", "--repeats", "3"], env=env)
     c = d["collective"]
-    assert c["ok"] and c["allreduce_calls"] == 3 * 4 and c["every_steps"] == 100     # --repeats given: no sizing region
+    assert c["ok"] and c["allreduce_calls"] == (16 + 10 + 250 * 4) // 100 + 1 and c["every_steps"] == 100     # --repeats given: no sizing region
     assert c["expected"] == 4096.0 * (16 + 10 + 250 * 4)
 
 
@@ -116,6 +124,6 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 2 * 262144 and d["scaling"] == "weak"
     c = d["collective"]
     assert c["ok"] and c["world_size"] == 2 and c["backend"] == "gloo"
-    assert c["allreduce_calls"] == 3 + 1                      # three timed regions + the rehearsal (--repeats given: no sizing region)
+    assert c["allreduce_calls"] == (16 + 5 + 20 * 4) // 100 + 1       # three timed regions + the rehearsal (--repeats given: no sizing region)
     assert c["n_env_steps_allreduced"] == 2 * 262144.0 * (16 + 5 + 20 * 4)
     assert d["cpu_baseline"] is None and d["also"] == []
