@@ -17,9 +17,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r2_a"
 SRC = os.path.join(ROOT, "gpurun_out", tag)
-DST = os.path.join(ROOT, "profiles", tag)
+DST = os.path.join(ROOT, "profiles", sys.argv[2] if len(sys.argv) > 2 else tag)       # (raw run directory, committed directory)
 os.makedirs(DST, exist_ok=True)
-STEP_KERNELS = ("msj_step_env_per_lane", "msj_step_tendon_per_lane", "tree_step_aba", "msj_env_step_kernel",
+STEP_KERNELS = ("msj_step_env_per_lane", "msj_step_tendon_per_lane", "msj_step_mirror_pairs", "tree_step_aba", "msj_env_step_kernel",
                 "tree_lane_step", "tree_lane_env_step", "tree_env_step_aba", "tree_split_step", "tree_split_env_step")
 
 
@@ -68,7 +68,7 @@ if by_grid:
             v = by_grid[key]
             tail = v[10:] if len(v) > 20 else v
             # threads per env: 8 in the tendon-per-lane form, 32 in the octet kernels (2 envs per wave), 1 otherwise
-            per_env = 8 if "tendon_per_lane" in key[0] else (32 if "_aba" in key[0] else (key[2] // 64 if "tree_split" in key[0] else 1))
+            per_env = 8 if "tendon_per_lane" in key[0] else 2 if "mirror_pairs" in key[0] else (32 if "_aba" in key[0] else (key[2] // 64 if "tree_split" in key[0] else 1))
             w.writerow([key[0], key[1], key[2], key[1] // per_env, len(v), "%.1f" % (sum(tail) / len(tail)), min(tail), max(tail)] + list(meta[key]))
 
 traffic = {}
