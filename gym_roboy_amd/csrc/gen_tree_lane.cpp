@@ -3,6 +3,7 @@
 // upper body (tree_lane_baked.hpp, compiled into the library ahead of time); tests/test_tree_lane_gen.py runs it
 // on random robots and checks the text, compiled with g++, against the fp64 oracle.  Built with g++.
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "tree_lane_gen.hpp"
@@ -40,12 +41,16 @@ extern "C" int rb_gen_tree_lane_mates(const rb_robot_desc *d, int *mate, int *tm
     return RB_OK;
 }
 
-// the split form (several waves per env group): writes the header, returns parts / slots / statement counts
-extern "C" int rb_gen_tree_lane_split(const rb_robot_desc *d, int max_parts, const char *path, int *n_parts, int *part_lds, int *x_slots,
-                                      int *max_stmt, int *n_stmt, int *part_of_joint, unsigned long long *hash) {
+// the split form (several waves per env group): writes the header, returns parts / slots / statement counts.
+// max_helpers: helper waves at most (tendon helpers of the longest parts; 0: the three-wave form of round 3)
+extern "C" int rb_gen_tree_lane_split_h(const rb_robot_desc *d, int max_parts, int max_helpers, const char *path, int *n_parts, int *part_lds,
+                                        int *x_slots, int *max_stmt, int *n_stmt, int *part_of_joint, unsigned long long *hash,
+                                        int *n_helpers, int *helper_stmt) {
     rblg::SplitGenerated g;
     std::string err;
-    const int rc = rblg::generate_split(d, max_parts, g, err);
+    // max_helpers: low byte = helper waves at most; bits 8-15 = the helpers' share of their parts' tendons in percent (0: the default)
+    const int share = (max_helpers >> 8) & 0xff;
+    const int rc = share ? rblg::generate_split(d, max_parts, g, err, max_helpers & 0xff, share) : rblg::generate_split(d, max_parts, g, err, max_helpers & 0xff);
     if (rc) { std::fprintf(stderr, "rb_gen_tree_lane_split: %s\n", err.c_str()); return rc; }
     FILE *f = std::fopen(path, "w");
     if (!f) return RB_EINVAL;
@@ -59,5 +64,11 @@ extern "C" int rb_gen_tree_lane_split(const rb_robot_desc *d, int max_parts, con
     if (n_stmt) *n_stmt = g.n_stmt;
     if (part_of_joint) for (int i = 0; i < g.n_q; ++i) part_of_joint[i] = g.part_of_joint[i];
     if (hash) *hash = g.hash;
+    if (n_helpers) *n_helpers = g.n_helpers;
+    if (helper_stmt) *helper_stmt = g.helper_stmt;
     return RB_OK;
+}
+extern "C" int rb_gen_tree_lane_split(const rb_robot_desc *d, int max_parts, const char *path, int *n_parts, int *part_lds, int *x_slots,
+                                      int *max_stmt, int *n_stmt, int *part_of_joint, unsigned long long *hash) {
+    return rb_gen_tree_lane_split_h(d, max_parts, 0, path, n_parts, part_lds, x_slots, max_stmt, n_stmt, part_of_joint, hash, nullptr, nullptr);
 }

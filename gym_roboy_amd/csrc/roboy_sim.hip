@@ -119,6 +119,15 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #ifndef RB_TREE_SPLIT_BATCH
 #define RB_TREE_SPLIT_BATCH 16384
 #endif
+// tendon-helper waves of the split form (tree_lane_gen.hpp: generate_split): at most this many, for the longest parts.  Must be the
+// number the ahead-of-time text was generated with (tools/gen_tree_lane_baked.py: SPLIT_HELPERS).
+#ifndef RB_SPLIT_HELPERS
+#define RB_SPLIT_HELPERS 2
+#endif
+// ... and the share (percent, proximal first) of a helped part's tendons its helper takes (SPLIT_HELPER_SHARE there)
+#ifndef RB_SPLIT_HELPER_SHARE
+#define RB_SPLIT_HELPER_SHARE 45
+#endif
 // the two-lanes-per-env form launches one-wave workgroups up to this many envs (spread over the CUs), 256-thread ones above
 #ifndef RB_PAIR_SMALL_BATCH
 #define RB_PAIR_SMALL_BATCH 65536
@@ -489,7 +498,7 @@ bool tree_wants_split(const rb_sim *s) {
 }
 size_t split_lds_bytes(const rblg::SplitGenerated &g) {      // the formula of tree_lane_split.hpp: SP_LDS_BYTES
     const int img = 5 * g.n_q > 3 * g.n_q + g.n_t ? 5 * g.n_q : 3 * g.n_q + g.n_t;
-    return size_t(img + 2 * g.x_slots + g.n_parts * (g.part_lds + 2 * g.n_q) + 3 * g.n_parts + 1) * 64 * 4;
+    return size_t(img + (g.n_helpers > 0 ? 1 : 2) * g.x_slots + g.n_parts * (g.part_lds + 2 * g.n_q) + 3 * g.n_parts + 1) * 64 * 4;
 }
 // the hiprtc-built split kernels of a robot without ahead-of-time instances (explicit choice only); kind: 0 = step, 1 = env step
 bool build_split_kernel(rb_sim *s, int kind = 0) {
@@ -625,12 +634,12 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale, long i0 = 0, lon
     launch_baked_step<INTEG, B, U>(blocks_for(cnt, B), stream, s->c8, rq, rqd, rfeas, ract, us, n, cnt)
 
     if (s->tree && tree_wants_split(s) && (s->split_baked || s->split_step_k.state == 1)) {
-        // one workgroup of n_parts waves per 64 envs
+        // one workgroup of n_parts (+ helper) waves per 64 envs
         const unsigned groups = blocks_for(n, 64);
         const size_t lds = split_lds_bytes(s->split_gen);
         const float h = s->tree_host.dev.h;
         const int nsub = s->tree_host.dev.nsub;
-        const unsigned threads = 64u * unsigned(s->split_gen.n_parts);
+        const unsigned threads = 64u * unsigned(s->split_gen.n_parts + s->split_gen.n_helpers);
         s->kernel = RB_KERNEL_ENV_PER_LANE_SPLIT;
         if (s->split_baked) {
             if (s->integrator == RB_EULER)
@@ -859,8 +868,12 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
             std::string why_gen;
             s->lane_ok = rblg::generate(robot, true, s->lane_gen, why_gen) == RB_OK;
             s->lane_baked = s->lane_ok && s->lane_gen.hash == RBL_TEXT_HASH && rblg::lane_lds_slots(s->lane_gen) == rbl_baked::LDS_SLOTS;
-            s->split_ok = rblg::generate_split(robot, 4, s->split_gen, why_gen) == RB_OK;
-            s->split_baked = s->split_ok && s->split_gen.hash == RBL_SPLIT_TEXT_HASH && s->split_gen.n_parts == RBL_NPARTS;
+            s->split_ok = rblg::generate_split(robot, 4, s->split_gen, why_gen, RB_SPLIT_HELPERS, RB_SPLIT_HELPER_SHARE) == RB_OK &&
+                          split_lds_bytes(s->split_gen) <= 160 * 1024;
+            if (!s->split_ok && RB_SPLIT_HELPERS > 0)        // (the exchange area of the helper form does not fit: the three-barrier-less form)
+                s->split_ok = rblg::generate_split(robot, 4, s->split_gen, why_gen, 0) == RB_OK;
+            s->split_baked = s->split_ok && s->split_gen.hash == RBL_SPLIT_TEXT_HASH && s->split_gen.n_parts == RBL_NPARTS &&
+                             s->split_gen.n_helpers == RBL_NHELPERS;
         }
         else why = "not a ball-joint robot (" + why + ") and not a supported joint tree (" + why_tree + ")";
     }
@@ -1007,6 +1020,15 @@ int rb_debug_tree_fetch(rb_sim *s, float *out, int n_floats, rbt::TreeDev *dev_o
     float *none = nullptr;
     RB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rbt::rb_tree_dbg_out), &none, sizeof(none)));
     (void)hipFree(buf);
+    return RB_OK;
+}
+#endif
+
+#ifdef RB_SPLIT_STAMPS
+// diagnostic builds only: the barrier stamps of the split kernels' workgroup 0 (tree_lane_defs.hpp), 8 waves x 128 entries
+extern "C" int rb_debug_stamps(unsigned long long *out) {
+    RB_HIP(hipDeviceSynchronize());
+    RB_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(rbl_stamp_buf), sizeof(unsigned long long) * 8 * 128));
     return RB_OK;
 }
 #endif
@@ -1446,7 +1468,7 @@ static int env_step_launch(rb_sim *s, long i0, long cnt, hipStream_t stream, con
         const size_t lds = split_lds_bytes(s->split_gen);
         const float h = s->tree_host.dev.h;
         const int nsub = s->tree_host.dev.nsub;
-        const unsigned threads = 64u * unsigned(s->split_gen.n_parts);
+        const unsigned threads = 64u * unsigned(s->split_gen.n_parts + s->split_gen.n_helpers);
 #define RB_SPLIT_ENV_ARGS s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, s->d_ep_ret, s->d_goal_count, d_act, \
                           d_obs, d_reward, d_done, s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, h, nsub, n, s->seed, uint64_t(s->env0)
         if (s->split_baked) {

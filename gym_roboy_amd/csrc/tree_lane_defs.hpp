@@ -11,7 +11,27 @@
 // split form (several waves per env group, tree_lane_split.hpp): integer tables, the exchange area, the workgroup barrier
 #define RBL_ITABLE(name, n) __device__ constexpr int name[n]
 #define RBL_X(slot) rbl_x(slot)
+#if defined(RB_SPLIT_STAMPS)
+// diagnostic builds only (tools/gpu_r4_helpers_stamps.sh): s_memtime before and after every workgroup barrier of workgroup 0,
+// per wave, into a global buffer (rb_debug_stamps fetches it); no product build defines RB_SPLIT_STAMPS
+__device__ unsigned long long rbl_stamp_buf[8 * 128];
+__device__ int rbl_stamp_cnt[8];
+__device__ __forceinline__ void rbl_stamp_mark(bool reset = false) {        // one entry: now
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+        const int k = reset ? 0 : rbl_stamp_cnt[wave];
+        if (k < 127) { rbl_stamp_buf[wave * 128 + k] = __builtin_amdgcn_s_memtime(); rbl_stamp_cnt[wave] = k + 1; }
+    }
+}
+__device__ __forceinline__ void rbl_stamped_barrier() {
+    rbl_stamp_mark();
+    __syncthreads();
+    rbl_stamp_mark();
+}
+#define RBL_PART_BARRIER rbl_stamped_barrier()
+#else
 #define RBL_PART_BARRIER __syncthreads()
+#endif
 
 RBL_FN float rbl_sin(float x) { return __sinf(x); }
 RBL_FN float rbl_cos(float x) { return __cosf(x); }

@@ -413,8 +413,11 @@ class Aba {
     }
     V3 CL3(const double *arr, int i) const { return {CL(arr, 3, i, 0), CL(arr, 3, i, 1), CL(arr, 3, i, 2)}; }
     Val CT(const double *arr, int k) const { return tmate[k] >= 0 ? Gen::K2(arr[k], arr[tmate[k]]) : Gen::K(arr[k]); }
+    std::map<std::string, Val> input_override;      // helper waves (generate_split): "q[i]" / "qd[i]" -> the value read from the exchange area
     Val in_l(const char *nm, int i) {
         const std::string a = std::string(nm) + "[" + std::to_string(i) + "]";
+        const auto ov = input_override.find(a);
+        if (ov != input_override.end()) return ov->second;
         if (mate[i] < 0) return Gen::named(a);
         return g.emit("RBL_MK2(" + a + ", " + nm + "[" + std::to_string(mate[i]) + "])", true);
     }
@@ -843,10 +846,23 @@ struct SplitGenerated {
     int max_stmt = 0;                 // statements of the longest part (what a step waits for)
     int n_stmt = 0;                   // statements of all parts together
     std::vector<int> part_of_joint;   // -1: trunk (every wave integrates it), else the part that owns the joint
+    int n_helpers = 0;                // helper waves (tendon helpers of the longest parts); the workgroup is n_parts + n_helpers waves
+    int helper_stmt = 0;              // statements of the longest helper
     uint64_t hash = 0;
 };
 
-inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated &out, std::string &err) {
+// max_helpers > 0 (round 4): the longest parts hand their TENDONS to a helper wave each.  A helper recomputes the frames and
+// velocities of the trunk and of its part's links (kinematics only: no inertias, nothing parked), evaluates the part's tendons and
+// leaves the wrench sums per link in the exchange area while the part's own wave runs its forward sweep; behind a second barrier
+// the part adds them to its bias forces and goes on with the backward pass.  Three barriers per acceleration then: S (the parts
+// have published the stage state q, qd of their joints for the helpers), T (tendon wrenches are there), X (the exports to the
+// trunk, as before); the exchange area needs no double buffer any more (between a wave's reads of one acceleration and anybody's
+// writes of the next lies at least one of them).  The critical path of the upper body's arm: 4 284 -> ~3 800 statements.
+// helper_share (percent): the share of a helped part's tendons (by crossings, proximal first) that goes to its helper; the rest stay
+// with the part, which evaluates them during its forward sweep as before.  A helper that takes everything is slower than the part's
+// forward sweep (it repeats the kinematics: barrier stamps, profiles/r4_a/helpers_stamps_first.log - the part then waits at T);
+// the balance for the upper body's arms is about half.
+inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated &out, std::string &err, int max_helpers = 0, int helper_share = 45) {
     Robot rob;
     if (int rc = build_robot(d, rob, err)) return rc;
     const int nq = rob.nq, nt = rob.nt;
@@ -910,6 +926,84 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
     }
     std::vector<int> trunk;
     for (int i = 0; i < nq; ++i) if (in_trunk[i]) trunk.push_back(i);
+    // ---- helpers: the heaviest parts (within 25 % of the heaviest) that have tendons of their own
+    std::vector<int> helper_of_part(K, -1), part_of_helper;
+    if (max_helpers > 0) {
+        double top = 0.0;
+        for (int q = 0; q < K; ++q) top = load[q] > top ? load[q] : top;
+        std::vector<std::pair<double, int>> byload;
+        for (int q = 0; q < K; ++q) byload.push_back({-load[q], q});
+        std::sort(byload.begin(), byload.end());
+        for (const auto &bl : byload) {
+            const int q = bl.second;
+            bool has_tendon = false;
+            for (int k = 0; k < nt; ++k) has_tendon = has_tendon || part_of_tendon[k] == q;
+            if (int(part_of_helper.size()) < max_helpers && load[q] >= 0.75 * top && has_tendon) {
+                helper_of_part[q] = int(part_of_helper.size());
+                part_of_helper.push_back(q);
+            }
+        }
+    }
+    const int H = int(part_of_helper.size());
+    // which of a helped part's tendons its helper takes: proximal first (by the last link they touch), up to helper_share of the crossings
+    std::vector<int> wave_of_tendon = part_of_tendon;       // K + h: helper h
+    for (int hh = 0; hh < H; ++hh) {
+        const int q = part_of_helper[hh];
+        std::vector<std::pair<int, int>> mine;              // (last link, tendon)
+        int total = 0;
+        for (int k = 0; k < nt; ++k) if (part_of_tendon[k] == q) { mine.push_back({rob.t_last[k], k}); total += int(rob.t_cross[k].size()); }
+        std::sort(mine.begin(), mine.end());
+        int taken = 0;
+        for (const auto &lk : mine) {
+            if (100 * taken >= helper_share * total) break;
+            wave_of_tendon[lk.second] = K + hh;
+            taken += int(rob.t_cross[lk.second].size());
+        }
+    }
+    // joints whose stage state the helpers need: the trunk's and the helped parts'; one exchange slot each for q and qd
+    std::vector<int> s_slot(nq, -1);
+    int n_sslot = 0;
+    for (int i = 0; i < nq && H > 0; ++i)
+        if (in_trunk[i] || helper_of_part[part_of_link[i]] >= 0) { s_slot[i] = n_sslot; n_sslot += 2; }
+
+    // ---- the helpers' text (first: it fixes the layout of the exchange area - S slots, then the T slots of every helper,
+    //      then the parts' exports).  T: the wrench sums -f_ext of the helped part's tendons on every link they touch.
+    struct Handed { int link, a; bool is_const; double cval; int slot; };
+    std::vector<std::vector<Handed>> handed(H);
+    std::vector<std::string> helper_bodies(H);
+    int n_tslot = 0;
+    out.helper_stmt = 0;
+    for (int hh = 0; hh < H; ++hh) {
+        const int q = part_of_helper[hh];
+        Gen g;
+        Aba A(rob, g, false);                               // nothing parked: the helper keeps no c
+        pair_parallel_tendons(rob, A.tmate, wave_of_tendon);
+        g.stmts.push_back({"//", "    RBL_PART_BARRIER;\n"});                            // S: the stage state is there
+        std::vector<int> links = trunk;
+        for (int i = 0; i < nq; ++i) if (part_of_link[i] == q) links.push_back(i);
+        for (int i : links) {
+            A.input_override["q[" + std::to_string(i) + "]"] = g.emit("RBL_X(" + std::to_string(s_slot[i]) + ")");
+            A.input_override["qd[" + std::to_string(i) + "]"] = g.emit("RBL_X(" + std::to_string(s_slot[i] + 1) + ")");
+        }
+        auto tendons_after = [&](int link) { for (int k = 0; k < nt; ++k) if (wave_of_tendon[k] == K + hh && rob.t_last[k] == link && !A.skip_tendon(k)) A.tendon(k); };
+        tendons_after(-1);
+        for (int i : links) { A.forward(i); tendons_after(i); g.barrier(); }
+        A.wrenches_to_links();
+        g.comment("tendon wrenches of part " + std::to_string(q) + " per link");
+        for (int i : links)
+            for (int a = 0; a < 6; ++a) {
+                const Val &v = A.pT[i][a];
+                if (Gen::is0(v)) continue;
+                handed[hh].push_back({i, a, v.k, v.c, v.k ? -1 : n_sslot + n_tslot});
+                if (!v.k) { g.store("RBL_X(" + std::to_string(n_sslot + n_tslot) + ")", v); ++n_tslot; }
+            }
+        g.stmts.push_back({"//", "    RBL_PART_BARRIER;\n"});                            // T
+        g.stmts.push_back({"//", "    RBL_PART_BARRIER;\n"});                            // X
+        int n_stmt = 0, flops = 0, live = 0;
+        helper_bodies[hh] = g.body(n_stmt, flops, live);
+        if (n_stmt > out.helper_stmt) out.helper_stmt = n_stmt;
+    }
+    const int x_base = n_sslot + n_tslot;                   // the parts' exports start here
 
     // ---- phase 1 of every part: trunk forward, own branches forward + tendons + backward, exports ----
     struct Export { int link, r, c; bool is_const; double cval; int slot; };   // c < 0: bias-force component r
@@ -917,19 +1011,38 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
     std::vector<std::unique_ptr<Aba>> abas(K);
     std::vector<std::vector<Export>> exports(K);
     std::vector<std::vector<Val>> export_vals(K);           // the part's own values, in export order (used in place of reading them back)
-    std::vector<int> x_off(K + 1, 0);
+    std::vector<int> x_off(K + 1, x_base);
     for (int q = 0; q < K; ++q) {
         Gen &g = gens[q];
         abas[q].reset(new Aba(rob, g, true));
         Aba &A = *abas[q];
-        pair_parallel_tendons(rob, A.tmate, part_of_tendon);
-        auto tendons_after = [&](int link) { for (int k = 0; k < nt; ++k) if (part_of_tendon[k] == q && rob.t_last[k] == link && !A.skip_tendon(k)) A.tendon(k); };
+        pair_parallel_tendons(rob, A.tmate, wave_of_tendon);
+        const bool helped = helper_of_part[q] >= 0;
+        if (H > 0) {
+            // the stage state of the joints this wave owns (the trunk's: part 0), for the helpers; then barrier S
+            for (int i = 0; i < nq; ++i)
+                if (s_slot[i] >= 0 && (part_of_link[i] == q || (in_trunk[i] && q == 0))) {
+                    g.store("RBL_X(" + std::to_string(s_slot[i]) + ")", Gen::named("q[" + std::to_string(i) + "]"));
+                    g.store("RBL_X(" + std::to_string(s_slot[i] + 1) + ")", Gen::named("qd[" + std::to_string(i) + "]"));
+                }
+            g.stmts.push_back({"//", "    RBL_PART_BARRIER;\n"});
+        }
+        auto tendons_after = [&](int link) { for (int k = 0; k < nt; ++k) if (wave_of_tendon[k] == q && rob.t_last[k] == link && !A.skip_tendon(k)) A.tendon(k); };
         tendons_after(-1);
         for (int j : trunk) { A.forward(j); tendons_after(j); g.barrier(); }
         std::vector<int> own;
         for (int i = 0; i < nq; ++i) if (part_of_link[i] == q) own.push_back(i);
         for (int i : own) { A.forward(i); tendons_after(i); g.barrier(); }
         A.wrenches_to_links();
+        if (H > 0) g.stmts.push_back({"//", "    RBL_PART_BARRIER;\n"});              // T: the helpers' wrench sums are there
+        if (helped) {
+            g.comment("tendon wrenches from helper " + std::to_string(helper_of_part[q]));
+            for (const Handed &hd : handed[helper_of_part[q]]) {
+                const Val v = hd.is_const ? Gen::K(hd.cval) : g.emit("RBL_X(" + std::to_string(hd.slot) + ")");
+                A.pT[hd.link][hd.a] = g.add(A.pT[hd.link][hd.a], v);
+            }
+            g.barrier();
+        }
         A.init_backward();
         // what this part hands to the trunk links: its tendons' wrenches on them, and its branches' I^a / p^a
         std::vector<Sym6> EI(nq);
@@ -978,6 +1091,7 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
     // ---- phase 2 of every part: all parts' contributions in part order, trunk backward + forward, own branches forward ----
     out.max_stmt = 0; out.n_stmt = 0; out.part_lds = 0;
     std::vector<std::string> bodies(K);
+    std::vector<int> part_stmt(K, 0);
     for (int q = 0; q < K; ++q) {
         Gen &g = gens[q];
         Aba &A = *abas[q];
@@ -1016,6 +1130,7 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
         }
         int n_stmt = 0, flops = 0, live = 0;
         bodies[q] = g.body(n_stmt, flops, live);
+        part_stmt[q] = n_stmt;
         out.n_stmt += n_stmt;
         if (n_stmt > out.max_stmt) out.max_stmt = n_stmt;
         if (g.n_lds > out.part_lds) out.part_lds = g.n_lds;
@@ -1025,8 +1140,8 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
     std::string t;
     char buf[256];
     t += "// GENERATED by gym_roboy_amd/csrc/tree_lane_gen.hpp (split form) - do not edit; the acceleration of ONE robot, one function per wave.\n";
-    std::snprintf(buf, sizeof buf, "#define RBL_NQ %d\n#define RBL_NT %d\n#define RBL_NPARTS %d\n#define RBL_PART_LDS %d\n#define RBL_X_SLOTS %d\n",
-                  nq, nt, K, out.part_lds, x_off[K]);
+    std::snprintf(buf, sizeof buf, "#define RBL_NQ %d\n#define RBL_NT %d\n#define RBL_NPARTS %d\n#define RBL_PART_LDS %d\n#define RBL_X_SLOTS %d\n#define RBL_NHELPERS %d\n",
+                  nq, nt, K, out.part_lds, x_off[K], H);
     t += buf;
     t += "namespace RBL_NS {\n";
     write_tables(t, rob);
@@ -1035,20 +1150,42 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
     t += "};\nRBL_ITABLE(PART_OF_TENDON, " + std::to_string(nt) + ") = {";
     for (int k = 0; k < nt; ++k) t += std::to_string(part_of_tendon[k]) + (k + 1 < nt ? ", " : "");
     t += "};\n";
+    // which wave of the workgroup runs which part.  With helpers the workgroup has more waves than the CU has SIMDs, and the last
+    // waves share a SIMD with the first ones (waves go to the SIMDs in turn): the SHORTEST part takes wave 0, so that the wave whose
+    // SIMD a helper joins is the one with slack (barrier stamps: a helper beside an arm ran 50 % longer than one with a SIMD of its own
+    // and the arms waited for it; profiles/r4_a/helpers_stamps.log)
+    {
+        std::vector<int> order(K);
+        for (int q = 0; q < K; ++q) order[q] = q;
+        if (H > 0) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return part_stmt[a] < part_stmt[b]; });
+        std::vector<int> wave_of(K + H, 0);
+        for (int w = 0; w < K; ++w) wave_of[order[w]] = w;
+        for (int hh = 0; hh < H; ++hh) wave_of[K + hh] = K + hh;
+        t += "RBL_ITABLE(WAVE_OF_PART, " + std::to_string(K + H) + ") = {";
+        for (int q = 0; q < K + H; ++q) t += std::to_string(wave_of[q]) + (q + 1 < K + H ? ", " : "");
+        t += "};\n";
+    }
     for (int q = 0; q < K; ++q) {
         t += "template <class RBL_L, class RBL_XA>\nRBL_FN void rbl_part" + std::to_string(q) +
              "(const float (&q)[RBL_NQ], const float (&qd)[RBL_NQ], const float (&spu)[RBL_NT], float (&qdd)[RBL_NQ], RBL_L rbl_lds, RBL_XA rbl_x) {\n";
         t += bodies[q];
         t += "}\n";
     }
+    // helper h is "part" K + h of the dispatch: same signature; it reads the stage state from the exchange area (q, qd unused) and leaves qdd alone
+    for (int hh = 0; hh < H; ++hh) {
+        t += "template <class RBL_L, class RBL_XA>\nRBL_FN void rbl_part" + std::to_string(K + hh) +
+             "(const float (&q)[RBL_NQ], const float (&qd)[RBL_NQ], const float (&spu)[RBL_NT], float (&qdd)[RBL_NQ], RBL_L rbl_lds, RBL_XA rbl_x) {\n";
+        t += helper_bodies[hh];
+        t += "}\n";
+    }
     t += "template <class RBL_L, class RBL_XA>\nRBL_FN void rbl_part(int part, const float (&q)[RBL_NQ], const float (&qd)[RBL_NQ], "
          "const float (&spu)[RBL_NT], float (&qdd)[RBL_NQ], RBL_L rbl_lds, RBL_XA rbl_x) {\n";
-    for (int q = 0; q < K; ++q)
-        t += std::string("    ") + (q ? "else " : "") + (q + 1 < K ? "if (part == " + std::to_string(q) + ") " : "") + "rbl_part" +
+    for (int q = 0; q < K + H; ++q)
+        t += std::string("    ") + (q ? "else " : "") + (q + 1 < K + H ? "if (part == " + std::to_string(q) + ") " : "") + "rbl_part" +
              std::to_string(q) + "(q, qd, spu, qdd, rbl_lds, rbl_x);\n";
     t += "}\n}  // namespace RBL_NS\n";
     out.text = t;
-    out.n_q = nq; out.n_t = nt; out.n_parts = K; out.x_slots = x_off[K];
+    out.n_q = nq; out.n_t = nt; out.n_parts = K; out.x_slots = x_off[K]; out.n_helpers = H;
     out.part_of_joint = part_of_link;
     out.hash = fnv1a(t);
     return RB_OK;

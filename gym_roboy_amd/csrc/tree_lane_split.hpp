@@ -14,12 +14,24 @@
 //                                     already writing for n + 1 cannot disturb one still reading n (it cannot reach n + 2
 //                                     before the other has passed the barrier of n + 1)
 //   per wave: RBL_PART_LDS parking slots + 2 n_q RK4 accumulators; then one flag slot per wave
+//
+// Helper waves (round 4, RBL_NHELPERS > 0): the workgroup has RBL_NPARTS + RBL_NHELPERS waves.  A helper (wave RBL_NPARTS + h) runs
+// the generated function of "part" RBL_NPARTS + h: the kinematics of the trunk and of its part's links from the stage state the
+// parts publish in the exchange area, its part's tendons, the wrench sums per link back into the exchange area - while the part's own
+// wave runs its forward sweep - with three barriers per acceleration (S, T, X: all in the generated text, the same count in every
+// wave).  It owns no joints, keeps no state between accelerations (no parking slots, no accumulators) and shares a SIMD with one of
+// the parts - which costs that part nothing: a wave issues one vector instruction per 5.5 cycles at best, a SIMD takes one per 2.8
+// from two.  With helpers the exchange area is SINGLE-buffered (between a wave's reads of one acceleration and anybody's writes
+// of the next lies at least one barrier).
 #pragma once
 #include "env_common.hpp"
 #include "philox.hpp"
 
 #ifndef RBL_NPARTS
 #error "include the generated split-form header (tree_lane_gen.hpp: generate_split) first"
+#endif
+#ifndef RBL_NHELPERS
+#define RBL_NHELPERS 0
 #endif
 
 namespace RBL_NS {
@@ -32,8 +44,10 @@ struct SplitLds {
 constexpr int SP_IMG_SLOTS = 5 * RBL_NQ > 3 * RBL_NQ + RBL_NT ? 5 * RBL_NQ : 3 * RBL_NQ + RBL_NT;
 constexpr int SP_WAVE_SLOTS = RBL_PART_LDS + 2 * RBL_NQ;
 constexpr int SP_ACC_SLOT = RBL_PART_LDS;
+constexpr int SP_NWAVES = RBL_NPARTS + RBL_NHELPERS;
+constexpr int SP_X_BUFFERS = RBL_NHELPERS > 0 ? 1 : 2;
 constexpr int SP_X_OFF = SP_IMG_SLOTS;
-constexpr int SP_WAVE_OFF = SP_X_OFF + 2 * RBL_X_SLOTS;
+constexpr int SP_WAVE_OFF = SP_X_OFF + SP_X_BUFFERS * RBL_X_SLOTS;
 constexpr int SP_FLAG_OFF = SP_WAVE_OFF + RBL_NPARTS * SP_WAVE_SLOTS;
 constexpr int SP_LDS_SLOTS = SP_FLAG_OFF + 3 * RBL_NPARTS + 1;    // per part: limit flag, and (env layer) its joints' shares of |dq|^2, |qd|^2; then the "a goal changed" word
 constexpr int SP_LDS_BYTES = SP_LDS_SLOTS * 64 * 4;
@@ -54,26 +68,50 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sp_rows_rsrc(const float *g, l
 template <int W>
 __device__ __forceinline__ void sp_load_image(const float *__restrict__ g, long env0, int live, float *img, int wave, int lane) {
     const __amdgpu_buffer_rsrc_t r = sp_rows_rsrc(g, env0, W, live);
-    constexpr int PER = (W + RBL_NPARTS - 1) / RBL_NPARTS;
+    constexpr int PER = (W + SP_NWAVES - 1) / SP_NWAVES;
     float t[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-        const int k = wave + u * RBL_NPARTS;
+        const int k = wave + u * SP_NWAVES;
         t[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, (k < W ? k : W - 1) * 256, 0));
     }
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-        const int k = wave + u * RBL_NPARTS;
+        const int k = wave + u * SP_NWAVES;
         if (k < W) img[k * 64 + lane] = t[u];
     }
 }
+// The input images of a step at once: EVERY load of every image is in flight before the first is waited for - one memory round
+// trip per step instead of one per image (round 4, barrier stamps of workgroup 0: 4 200 cycles from the wave's start to "rows in
+// LDS" with the images loaded one after the other - three round trips - of a 24 000-cycle Euler step).
+template <int W>
+struct SpImageLoad {
+    static constexpr int PER = (W + SP_NWAVES - 1) / SP_NWAVES;
+    float t[PER];
+    __device__ __forceinline__ void issue(const float *__restrict__ g, long env0, int live, int wave, int lane) {
+        const __amdgpu_buffer_rsrc_t r = sp_rows_rsrc(g, env0, W, live);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int k = wave + u * SP_NWAVES;
+            t[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, (k < W ? k : W - 1) * 256, 0));
+        }
+    }
+    __device__ __forceinline__ void land(float *img, int wave, int lane) const {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int k = wave + u * SP_NWAVES;
+            if (k < W) img[k * 64 + lane] = t[u];
+        }
+    }
+};
+
 template <int W>
 __device__ __forceinline__ void sp_store_image(float *__restrict__ g, long env0, int live, const float *img, int wave, int lane) {
     const __amdgpu_buffer_rsrc_t r = sp_rows_rsrc(g, env0, W, live);
-    constexpr int PER = (W + RBL_NPARTS - 1) / RBL_NPARTS;
+    constexpr int PER = (W + SP_NWAVES - 1) / SP_NWAVES;
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-        const int k = wave + u * RBL_NPARTS;
+        const int k = wave + u * SP_NWAVES;
         if (k < W) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(img[k * 64 + lane]), r, lane * 4, k * 256, 0);
     }
 }
@@ -89,7 +127,7 @@ __device__ __forceinline__ bool split_step(const SplitLds &L, float *xbase, int 
     bool ok = true;
     int n_acc = 0;                                   // accelerations so far: selects the exchange buffer
     auto accel = [&](const float (&qq)[RBL_NQ], const float (&vv)[RBL_NQ], float (&out)[RBL_NQ]) {
-        const SplitLds X{xbase + (n_acc & 1) * (RBL_X_SLOTS * 64) + lane};
+        const SplitLds X{xbase + (SP_X_BUFFERS == 2 ? (n_acc & 1) * (RBL_X_SLOTS * 64) : 0) + lane};
         ++n_acc;
         sp_fence_code();
         rbl_part(PART, qq, vv, spu, out, L, X);
@@ -184,18 +222,56 @@ __device__ __forceinline__ void split_wave(float *lds, int lane, int live, float
     }
 }
 
+// a helper wave: one call of its generated function per acceleration of the step (the parts' count: n_sub x 1 or 4); it needs the
+// activation offsets of its part's tendons and nothing else of the inputs - state comes from the exchange area, nothing goes out
+// but the wrench sums it leaves there
+template <int INTEG, int HELPER>
+__device__ __forceinline__ void split_helper(float *lds, int lane, int live, float act_scale, int nsub, bool env_layer, const rbe::EnvParams *ep) {
+    float *img = lds;
+    const int row = sp_opaque(lane < live ? lane : live - 1);
+    constexpr int OA = 2 * RBL_NQ * 64;
+    float spu[RBL_NT], none_q[RBL_NQ], none_a[RBL_NQ];
+#pragma unroll
+    for (int j = 0; j < RBL_NQ; ++j) { none_q[j] = 0.0f; none_a[j] = 0.0f; }
+#pragma unroll
+    for (int k = 0; k < RBL_NT; ++k) {
+        const float a = img[OA + row * RBL_NT + k];
+        if (env_layer) {
+            const float x = fminf(fmaxf(a, -1.0f), 1.0f);
+            spu[k] = rbe::mul_then_add(ep->slope, x - 1.0f, ep->act_hi) * KSG[k];
+        } else {
+            spu[k] = (a * act_scale) * KSG[k];
+        }
+    }
+#if !defined(RB_SPLIT_NO_HELPER_PRIO)
+    __builtin_amdgcn_s_setprio(2);                      // a helper that shares a SIMD goes first: the wave beside it is the one with slack
+#endif
+    const SplitLds L{lds + lane};                       // (unused: a helper parks nothing)
+    const SplitLds X{lds + SP_X_OFF * 64 + lane};
+    const int n_acc = nsub * (INTEG == 0 ? 1 : 4);
+#pragma unroll 1
+    for (int a = 0; a < n_acc; ++a) {
+        sp_fence_code();
+        rbl_part(RBL_NPARTS + HELPER, none_q, none_q, spu, none_a, L, X);
+        sp_fence_code();
+    }
+}
+
 template <int INTEG, int PART>
 __device__ __forceinline__ void split_dispatch(int wave, float *lds, int lane, int live, float act_scale, float h, int nsub, bool env_layer,
                                                const rbe::EnvParams *ep) {
     if constexpr (PART < RBL_NPARTS) {
-        if (wave == PART) split_wave<INTEG, PART>(lds, lane, live, act_scale, h, nsub, env_layer, ep);
+        if (wave == WAVE_OF_PART[PART]) split_wave<INTEG, PART>(lds, lane, live, act_scale, h, nsub, env_layer, ep);
+        else split_dispatch<INTEG, PART + 1>(wave, lds, lane, live, act_scale, h, nsub, env_layer, ep);
+    } else if constexpr (PART < SP_NWAVES) {
+        if (wave == WAVE_OF_PART[PART]) split_helper<INTEG, PART - RBL_NPARTS>(lds, lane, live, act_scale, nsub, env_layer, ep);
         else split_dispatch<INTEG, PART + 1>(wave, lds, lane, live, act_scale, h, nsub, env_layer, ep);
     }
 }
 
 // forward_step_command for a batch (the contract of tree_lane_step / tree_step_aba)
 template <int INTEG>
-__global__ void __launch_bounds__(64 * RBL_NPARTS)
+__global__ void __launch_bounds__(64 * SP_NWAVES)
 tree_split_step(float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas, const float *__restrict__ act,
                 float act_scale, float h, int nsub, long n) {
     extern __shared__ float lds_split[];
@@ -204,11 +280,23 @@ tree_split_step(float *__restrict__ q, float *__restrict__ qd, uint32_t *__restr
     if (env0 >= n) return;                          // (the whole workgroup: no barrier is left behind)
     const int live = n - env0 < 64 ? int(n - env0) : 64;
     float *lds = lds_split;
-    sp_load_image<RBL_NQ>(q, env0, live, lds, wave, lane);
-    sp_load_image<RBL_NQ>(qd, env0, live, lds + RBL_NQ * 64, wave, lane);
-    sp_load_image<RBL_NT>(act, env0, live, lds + 2 * RBL_NQ * 64, wave, lane);
+#if defined(RB_SPLIT_STAMPS)
+    rbl_stamp_mark(true);                              // entry 0: the wave exists
+#endif
+    {
+        SpImageLoad<RBL_NQ> lq, lv;
+        SpImageLoad<RBL_NT> la;
+        lq.issue(q, env0, live, wave, lane); lv.issue(qd, env0, live, wave, lane); la.issue(act, env0, live, wave, lane);
+        lq.land(lds, wave, lane); lv.land(lds + RBL_NQ * 64, wave, lane); la.land(lds + 2 * RBL_NQ * 64, wave, lane);
+    }
     __syncthreads();
+#if defined(RB_SPLIT_STAMPS)
+    rbl_stamp_mark();                                  // entry 1: the rows are in LDS
+#endif
     split_dispatch<INTEG, 0>(wave, lds, lane, live, act_scale, h, nsub, false, nullptr);
+#if defined(RB_SPLIT_STAMPS)
+    rbl_stamp_mark();                                  // the wave's share of the step is done
+#endif
     __syncthreads();
     sp_store_image<RBL_NQ>(q, env0, live, lds, wave, lane);
     sp_store_image<RBL_NQ>(qd, env0, live, lds + RBL_NQ * 64, wave, lane);
@@ -218,13 +306,16 @@ tree_split_step(float *__restrict__ q, float *__restrict__ qd, uint32_t *__restr
         for (int p = 0; p < RBL_NPARTS; ++p) ok = ok && lds[(SP_FLAG_OFF + 3 * p) * 64 + lane] != 0.0f;
         feas[env0 + lane] = ok ? 1u : 0u;
     }
+#if defined(RB_SPLIT_STAMPS)
+    rbl_stamp_mark();                                  // last entry: stores issued
+#endif
 }
 
 // RoboyEnv.step fused around the split step (semantics of tree_lane_env_step / msj_env_step_kernel).  The waves
 // step their joints; wave 0 then is the envs' accountant (one env per lane): reward and done from the waves' partial sums,
 // goal redraw (and reset) on done, the observation rows; all waves write the row images back together.
 template <int INTEG>
-__global__ void __launch_bounds__(64 * RBL_NPARTS)
+__global__ void __launch_bounds__(64 * SP_NWAVES)
 tree_split_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__restrict__ q, float *__restrict__ qd,
                     uint32_t *__restrict__ feas, float *__restrict__ goal, uint32_t *__restrict__ step_num,
                     float *__restrict__ ep_ret, uint32_t *__restrict__ goal_count, const float *__restrict__ act,
@@ -239,10 +330,13 @@ tree_split_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__re
     float *lds = lds_split;
     constexpr int OV = RBL_NQ * 64, OA = 2 * RBL_NQ * 64, OG = (2 * RBL_NQ + RBL_NT) * 64;
     constexpr int OO = 2 * RBL_NQ * 64;                    // the observation image takes the place of the action and goal images
-    sp_load_image<RBL_NQ>(q, env0, live, lds, wave, lane);
-    sp_load_image<RBL_NQ>(qd, env0, live, lds + OV, wave, lane);
-    sp_load_image<RBL_NT>(act, env0, live, lds + OA, wave, lane);
-    sp_load_image<RBL_NQ>(goal, env0, live, lds + OG, wave, lane);
+    {
+        SpImageLoad<RBL_NQ> lq, lv, lg;
+        SpImageLoad<RBL_NT> la;
+        lq.issue(q, env0, live, wave, lane); lv.issue(qd, env0, live, wave, lane); la.issue(act, env0, live, wave, lane);
+        lg.issue(goal, env0, live, wave, lane);
+        lq.land(lds, wave, lane); lv.land(lds + OV, wave, lane); la.land(lds + OA, wave, lane); lg.land(lds + OG, wave, lane);
+    }
     // the accountant's counters, requested now (their latency passes behind the step)
     const bool mine = wave == 0 && lane < live;
     const long me = env0 + (lane < live ? lane : live - 1);

@@ -31,8 +31,11 @@ inline float rbl_max(float a, float b) { return std::fmax(a, b); }
 #include "rbl_pair_host.hpp"
 
 #include RBL_GENERATED
+#ifndef RBL_NHELPERS
+#define RBL_NHELPERS 0
+#endif
 
-extern "C" int tl_dims(int *out) { out[0] = RBL_NQ; out[1] = RBL_NT; out[2] = RBL_NPARTS; out[3] = RBL_PART_LDS; out[4] = RBL_X_SLOTS; return 0; }
+extern "C" int tl_dims(int *out) { out[0] = RBL_NQ; out[1] = RBL_NT; out[2] = RBL_NPARTS; out[3] = RBL_PART_LDS; out[4] = RBL_X_SLOTS; out[5] = RBL_NHELPERS; return 0; }
 // qdd of n envs; returns the number of trunk accelerations that differ between two parts (must be 0)
 extern "C" int tl_accel(const float *q, const float *qd, const float *sp, float *qdd, int n) {
     int mismatches = 0;
@@ -43,12 +46,15 @@ extern "C" int tl_accel(const float *q, const float *qd, const float *sp, float 
         float x[RBL_X_SLOTS + 1];
         float a[RBL_NPARTS][RBL_NQ];
         std::memset(a, 0, sizeof a);
-        pthread_barrier_init(&g_barrier, nullptr, RBL_NPARTS);
+        // (helper waves - "parts" RBL_NPARTS .. - take their state from the exchange area: they get zeros for q / qd)
+        pthread_barrier_init(&g_barrier, nullptr, RBL_NPARTS + RBL_NHELPERS);
         std::vector<std::thread> th;
-        for (int p = 0; p < RBL_NPARTS; ++p)
+        for (int p = 0; p < RBL_NPARTS + RBL_NHELPERS; ++p)
             th.emplace_back([&, p] {
                 float lds[RBL_PART_LDS + 1];
-                rbl_host::rbl_part(p, qq, vv, spu, a[p], lds, x);
+                if (p < RBL_NPARTS) { rbl_host::rbl_part(p, qq, vv, spu, a[p], lds, x); return; }
+                float zq[RBL_NQ] = {}, za[RBL_NQ] = {};
+                rbl_host::rbl_part(p, zq, zq, spu, za, lds, x);
             });
         for (auto &t : th) t.join();
         pthread_barrier_destroy(&g_barrier);

@@ -147,7 +147,7 @@ def test_in_tree_generated_headers_are_current():
     fresh = os.path.join(BUILD, "tree_lane_baked_fresh.hpp")
     gen.generate(UpperBodyRobot().get_description(), fresh)
     assert open(fresh).read() == open(os.path.join(csrc, "tree_lane_baked.hpp")).read(), "run make -C gym_roboy_amd/csrc"
-    gen.generate_split(UpperBodyRobot().get_description(), fresh)
+    gen.generate_split(UpperBodyRobot().get_description(), fresh, max_helpers=gen.SPLIT_HELPERS, helper_share=gen.SPLIT_HELPER_SHARE)
     assert open(fresh).read() == open(os.path.join(csrc, "tree_lane_split_baked.hpp")).read(), "run make -C gym_roboy_amd/csrc"
 
 
@@ -224,19 +224,20 @@ def test_hiprtc_builds_the_kernels_of_a_random_robot():
         assert size > 10000
 
 
-def host_split_accel(desc, tag, max_parts=4):
-    """generate_split -> g++ -> ctypes; returns (accel(q, qd, sp) -> (qdd, trunk mismatches), info)."""
+def host_split_accel(desc, tag, max_parts=4, max_helpers=0):
+    """generate_split -> g++ -> ctypes; returns (accel(q, qd, sp) -> (qdd, trunk mismatches), info).  Every part - and every
+    helper wave - runs in a thread of its own; the barriers of the text are pthread barriers."""
     import gen_tree_lane_baked as gen
     os.makedirs(BUILD, exist_ok=True)
     hdr = os.path.join(BUILD, "lane_split_%s.hpp" % tag)
-    info = gen.generate_split(desc, hdr, max_parts)
+    info = gen.generate_split(desc, hdr, max_parts, max_helpers)
     so = os.path.join(BUILD, "liblane_split_%s.so" % tag)
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", '-DRBL_GENERATED="%s"' % hdr,
                            "-o", so, os.path.join(ROOT, "tests", "hostmath", "tree_lane_split_host.cpp")])
     lib = ctypes.CDLL(so)
-    dims = (ctypes.c_int * 5)()
+    dims = (ctypes.c_int * 6)()
     lib.tl_dims(dims)
-    assert (dims[0], dims[1], dims[2]) == (desc.n_q, desc.n_t, info["n_parts"])
+    assert (dims[0], dims[1], dims[2], dims[5]) == (desc.n_q, desc.n_t, info["n_parts"], info["n_helpers"])
 
     def accel(q, qd, sp):
         q = np.ascontiguousarray(q, np.float32); qd = np.ascontiguousarray(qd, np.float32)
@@ -247,9 +248,9 @@ def host_split_accel(desc, tag, max_parts=4):
     return accel, info
 
 
-def check_split(desc, tag, n=12, tol=2e-4, max_parts=4):
+def check_split(desc, tag, n=12, tol=2e-4, max_parts=4, max_helpers=0):
     from oracle.physics_np import TendonRobotOracle
-    accel, info = host_split_accel(desc, tag, max_parts)
+    accel, info = host_split_accel(desc, tag, max_parts, max_helpers)
     rng = np.random.default_rng(11)
     q = rng.uniform(0.9 * desc.q_lo, 0.9 * desc.q_hi, (n, desc.n_q)).astype(np.float32)
     qd = rng.uniform(-desc.qd_max, desc.qd_max, (n, desc.n_q)).astype(np.float32)
@@ -272,6 +273,23 @@ def test_upper_body_split_form_matches_oracle():
     assert info["max_stmt"] < 0.5 * 11408                     # a step waits for less than half the one-wave stream
 
 
+def test_upper_body_split_form_with_tendon_helpers_matches_oracle():
+    """The library's form (round 4): the two arms hand their tendons to a helper wave each - kinematics of the spine and the arm
+    from the stage state the parts publish, the arm's 13 tendons, wrench sums per link back through the exchange area, three
+    barriers per acceleration - which takes the tendons off the longest parts' path."""
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    import gen_tree_lane_baked as gen
+    plain = check_split(UpperBodyRobot().get_description(), "upper_body")
+    info = check_split(UpperBodyRobot().get_description(), "upper_body_h2", max_helpers=2)       # the generator's default share of the tendons
+    assert info["n_parts"] == 3 and info["n_helpers"] == 2
+    assert info["max_stmt"] < 0.95 * plain["max_stmt"] and info["helper_stmt"] < 0.2 * info["max_stmt"]
+    # every tendon of the arms to the helpers (share 100 %): 4 284 -> 3 529 statements on the longest part, 1 198 per helper
+    accel, all_ = host_split_accel(UpperBodyRobot().get_description(), "upper_body_h2_all", 4, 2 | (100 << 8))
+    assert all_["max_stmt"] < 0.85 * plain["max_stmt"] and all_["helper_stmt"] > info["helper_stmt"]
+    one = check_split(UpperBodyRobot().get_description(), "upper_body_h1", max_helpers=1)
+    assert one["n_helpers"] == 1
+
+
 def test_upper_body_split_in_two_parts():
     from gym_roboy_amd.envs.robots import UpperBodyRobot
     assert check_split(UpperBodyRobot().get_description(), "upper_body2", max_parts=2)["n_parts"] == 2
@@ -286,6 +304,7 @@ def test_random_robots_split_form(seed):
     desc = RobotDescription(random_tree_spec(seed))
     try:
         check_split(desc, "random%d" % seed, n=6, tol=5e-4)
+        check_split(desc, "random%dh" % seed, n=6, tol=5e-4, max_helpers=2)      # ... and with tendon helpers for the longest parts
     except RuntimeError as exc:                                # no split form for this robot: a chain, or everything tied into one group
         assert "rb_gen_tree_lane_split failed" in str(exc)
         pytest.skip("robot %d has no split form" % seed)
@@ -301,3 +320,5 @@ def test_star_robot_splits_into_the_maximum_number_of_parts():
         t["via_points"] = [{"link": -1, "pos": t["via_points"][0]["pos"]}, {"link": link, "pos": t["via_points"][-1]["pos"]}]
     info = check_split(RobotDescription(spec), "star9", n=6, tol=5e-4)
     assert info["n_parts"] == 4 and info["part_of_joint"][0] == -1
+    info = check_split(RobotDescription(spec), "star9h", n=6, tol=5e-4, max_helpers=3)
+    assert info["n_parts"] == 4 and 1 <= info["n_helpers"] <= 3
