@@ -49,8 +49,13 @@ extern "C" int rb_gen_tree_lane_split_h(const rb_robot_desc *d, int max_parts, i
     rblg::SplitGenerated g;
     std::string err;
     // max_helpers: low byte = helper waves at most; bits 8-15 = the helpers' share of their parts' tendons in percent (0: the default)
+    // ... bit 16 = the backward pass in two sweeps (inertias before barrier T, bias forces behind it)
     const int share = (max_helpers >> 8) & 0xff;
-    const int rc = share ? rblg::generate_split(d, max_parts, g, err, max_helpers & 0xff, share) : rblg::generate_split(d, max_parts, g, err, max_helpers & 0xff);
+    const bool two_sweeps = ((max_helpers >> 16) & 1) != 0;
+    // ... bit 17 = the CUT form instead (generate_split_cut: max_helpers parts cut in two, share = the distal waves' share of the tendons)
+    const bool cut = ((max_helpers >> 17) & 1) != 0;
+    const int rc = cut ? rblg::generate_split_cut(d, max_parts, g, err, max_helpers & 0xff, share)
+                       : rblg::generate_split(d, max_parts, g, err, max_helpers & 0xff, share ? share : 45, two_sweeps);
     if (rc) { std::fprintf(stderr, "rb_gen_tree_lane_split: %s\n", err.c_str()); return rc; }
     FILE *f = std::fopen(path, "w");
     if (!f) return RB_EINVAL;

@@ -126,7 +126,19 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #endif
 // ... and the share (percent, proximal first) of a helped part's tendons its helper takes (SPLIT_HELPER_SHARE there)
 #ifndef RB_SPLIT_HELPER_SHARE
-#define RB_SPLIT_HELPER_SHARE 45
+#define RB_SPLIT_HELPER_SHARE 70
+#endif
+// ... and whether the parts run their backward pass in two sweeps around barrier T (SPLIT_TWO_SWEEPS there): everything but the tendon
+// wrenches' part before it, beside the helpers (upper body, 8 192 envs: 9.15 -> 8.84 us Euler, 26.5 -> 25.1 us RK4 at a share of 70 %)
+#ifndef RB_SPLIT_TWO_SWEEPS
+#define RB_SPLIT_TWO_SWEEPS 1
+#endif
+// ... or the CUT form instead (generate_split_cut: the RB_SPLIT_HELPERS heaviest parts as a proximal and a distal wave each;
+// RB_SPLIT_HELPER_SHARE is then the distal waves' share of the tendons).  SPLIT_CUT there.  Measured and NOT selected: 22 % fewer
+// vector instructions on the longest path of the upper body, and 10.2 / 30.1 us against 8.84 / 25.1 - all five waves are busy at once
+// there, and the two that share a SIMD run at 7 cycles per instruction instead of 5.5 (profiles/r4_a/cut_form.log).
+#ifndef RB_SPLIT_CUT
+#define RB_SPLIT_CUT 0
 #endif
 // the two-lanes-per-env form launches one-wave workgroups up to this many envs (spread over the CUs), 256-thread ones above
 #ifndef RB_PAIR_SMALL_BATCH
@@ -498,7 +510,7 @@ bool tree_wants_split(const rb_sim *s) {
 }
 size_t split_lds_bytes(const rblg::SplitGenerated &g) {      // the formula of tree_lane_split.hpp: SP_LDS_BYTES
     const int img = 5 * g.n_q > 3 * g.n_q + g.n_t ? 5 * g.n_q : 3 * g.n_q + g.n_t;
-    return size_t(img + (g.n_helpers > 0 ? 1 : 2) * g.x_slots + g.n_parts * (g.part_lds + 2 * g.n_q) + 3 * g.n_parts + 1) * 64 * 4;
+    return size_t(img + g.x_buffers * g.x_slots + g.n_parts * (g.part_lds + (g.acc_slots ? g.acc_slots : 2 * g.n_q)) + 3 * g.n_parts + 1) * 64 * 4;
 }
 // the hiprtc-built split kernels of a robot without ahead-of-time instances (explicit choice only); kind: 0 = step, 1 = env step
 bool build_split_kernel(rb_sim *s, int kind = 0) {
@@ -868,7 +880,8 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
             std::string why_gen;
             s->lane_ok = rblg::generate(robot, true, s->lane_gen, why_gen) == RB_OK;
             s->lane_baked = s->lane_ok && s->lane_gen.hash == RBL_TEXT_HASH && rblg::lane_lds_slots(s->lane_gen) == rbl_baked::LDS_SLOTS;
-            s->split_ok = rblg::generate_split(robot, 4, s->split_gen, why_gen, RB_SPLIT_HELPERS, RB_SPLIT_HELPER_SHARE) == RB_OK &&
+            s->split_ok = (RB_SPLIT_CUT ? rblg::generate_split_cut(robot, 4, s->split_gen, why_gen, RB_SPLIT_HELPERS, RB_SPLIT_HELPER_SHARE)
+                                        : rblg::generate_split(robot, 4, s->split_gen, why_gen, RB_SPLIT_HELPERS, RB_SPLIT_HELPER_SHARE, RB_SPLIT_TWO_SWEEPS != 0)) == RB_OK &&
                           split_lds_bytes(s->split_gen) <= 160 * 1024;
             if (!s->split_ok && RB_SPLIT_HELPERS > 0)        // (the exchange area of the helper form does not fit: the three-barrier-less form)
                 s->split_ok = rblg::generate_split(robot, 4, s->split_gen, why_gen, 0) == RB_OK;

@@ -414,6 +414,8 @@ class Aba {
     V3 CL3(const double *arr, int i) const { return {CL(arr, 3, i, 0), CL(arr, 3, i, 1), CL(arr, 3, i, 2)}; }
     Val CT(const double *arr, int k) const { return tmate[k] >= 0 ? Gen::K2(arr[k], arr[tmate[k]]) : Gen::K(arr[k]); }
     std::map<std::string, Val> input_override;      // helper waves (generate_split): "q[i]" / "qd[i]" -> the value read from the exchange area
+    std::vector<char> light;                        // forward(i) of a light link: frame, axis and velocity only (another wave owns the link)
+    std::vector<Val> qddv;                          // the joint accelerations as accel() wrote them
     Val in_l(const char *nm, int i) {
         const std::string a = std::string(nm) + "[" + std::to_string(i) + "]";
         const auto ov = input_override.find(a);
@@ -435,6 +437,7 @@ class Aba {
         R.resize(nq); p.resize(nq); w.resize(nq); vo.resize(nq); z.resize(nq); sl.resize(nq);
         cacc.resize(nq); bown.resize(nq); pT.resize(nq); pA.resize(nq); U.resize(nq); acc.resize(nq); cpre.resize(nq);
         cslot.resize(nq); cpair.resize(nq); Iown.resize(nq); IA.resize(nq); invD.resize(nq); uu.resize(nq); cpre_ok.assign(nq, 0);
+        light.assign(nq, 0); qddv.assign(nq, K(0.0));
     }
     static Val K(double c) { return Gen::K(c); }
     V3 link_w(int l) const { return l < 0 ? Gen::zero3() : w[l]; }
@@ -518,6 +521,12 @@ class Aba {
         sl[i] = g.cross(p[i], z[i]);
         w[i] = g.vfma(z[i], qdi, wp);
         vo[i] = g.vfma(sl[i], qdi, vop);
+        if (light[i]) {
+            for (int a = 0; a < 6; ++a) { cacc[i][a] = K(0.0); cpair[i][a] = 0; cslot[i][a] = -1; }
+            for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) Iown[i].m[r][c] = K(0.0);
+            bown[i] = {K(0), K(0), K(0), K(0), K(0), K(0)};
+            return;
+        }
         const V3 ca = g.vscale(g.cross(wp, z[i]), qdi);                          // (w_i x z_i = w_p x z_i)
         const V3 wxsl = g.cross(w[i], sl[i]);
         const V3 voxz = g.cross(vo[i], z[i]);
@@ -648,6 +657,76 @@ class Aba {
                 for (int cc = r; cc < 6; ++cc) par_I->m[r][cc] = g.add(par_I->m[r][cc], arrive(Ia.m[r][cc], i, rob.parent[i]));
         }
     }
+    // ---- the backward pass in two sweeps (split form with tendon helpers).  The bias-force recursion is LINEAR in the forces:
+    //      p^a_i = P_i (b_i^own + f_i + sum_c p^a_c) + k_i.  So everything is evaluated WITHOUT the tendon wrenches before barrier T -
+    //      inertias, U, 1/D, I^a c, the bias forces p0 of the link's own inertia, u0 = -(d qd + s.p0) - and behind it only the
+    //      tendons' part is propagated: y_i = f_i + sum_c t_c, u_i = u0_i - s.y_i, t_i = y_i - U_i (s.y_i)/D_i  (26 statements per
+    //      link instead of 245).  Nothing but u0 (one value per link) has to survive the barrier that would not anyway (U and 1/D
+    //      are needed by the acceleration sweep). ----
+    std::vector<Val> uu0;
+    std::vector<std::array<Val, 6>> yT;
+    void init_backward_pre() {
+        uu0.assign(rob.nq, K(0.0));
+        yT.assign(rob.nq, {K(0), K(0), K(0), K(0), K(0), K(0)});
+        for (int i = 0; i < rob.nq; ++i) {
+            if (skip_link(i)) continue;
+            for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) IA[i].m[r][c] = K(0.0);
+            pA[i] = bown[i];                                       // (no tendon wrenches yet)
+        }
+    }
+    // par_I / par_p: the parent's accumulators (inertia, force-free bias force), or a part's export accumulators
+    void backward_pre(int i, Sym6 *par_I, std::array<Val, 6> *par_p) {
+        const rb_robot_desc *d = rob.d;
+        Sym6 &I = IA[i];
+        for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) I.m[r][c] = g.add(I.m[r][c], Iown[i].m[r][c]);
+        const std::array<Val, 6> s = {z[i][0], z[i][1], z[i][2], sl[i][0], sl[i][1], sl[i][2]};
+        for (int r = 0; r < 6; ++r) {
+            std::vector<std::pair<Val, Val>> terms;
+            for (int c = 0; c < 6; ++c) terms.push_back({I.at(r, c), s[c]});
+            U[i][r] = g.dot(terms);
+        }
+        std::vector<std::pair<Val, Val>> sU, sP;
+        for (int r = 0; r < 6; ++r) { sU.push_back({s[r], U[i][r]}); sP.push_back({s[r], pA[i][r]}); }
+        const Val D = g.add(g.dot(sU), CL(d->armature, 1, i));
+        invD[i] = g.call1("rbl_rcp", D);
+        const Val dqd = g.mul(in_l("qd", i), CL(d->damping, 1, i));
+        const Val spa = g.dot(sP);
+        uu0[i] = Gen::negv(g.add(dqd, spa));
+        if (par_I) {
+            const std::array<Val, 6> c = take_c(i);
+            std::array<Val, 6> Kk;
+            for (int r = 0; r < 6; ++r) Kk[r] = g.mul(U[i][r], invD[i]);
+            Sym6 Ia;
+            for (int r = 0; r < 6; ++r) for (int cc = r; cc < 6; ++cc) Ia.m[r][cc] = g.sub(I.m[r][cc], g.mul(Kk[r], U[i][cc]));
+            const Val ud = g.mul(uu0[i], invD[i]);
+            for (int r = 0; r < 6; ++r) {
+                std::vector<std::pair<Val, Val>> terms;
+                for (int cc = 0; cc < 6; ++cc) terms.push_back({Ia.at(r, cc), c[cc]});
+                const Val pu = g.fma(U[i][r], ud, pA[i][r]);
+                const Val pa = g.add(pu, g.dot(terms));
+                (*par_p)[r] = g.add((*par_p)[r], arrive(pa, i, rob.parent[i]));
+            }
+            for (int r = 0; r < 6; ++r)
+                for (int cc = r; cc < 6; ++cc) par_I->m[r][cc] = g.add(par_I->m[r][cc], arrive(Ia.m[r][cc], i, rob.parent[i]));
+        }
+    }
+    // the tendon wrenches' part: yT[i] holds what arrived from the children so far; par_y: the parent's yT or an export accumulator
+    void backward_post(int i, std::array<Val, 6> *par_y) {
+        const std::array<Val, 6> s = {z[i][0], z[i][1], z[i][2], sl[i][0], sl[i][1], sl[i][2]};
+        std::array<Val, 6> y;
+        for (int a = 0; a < 6; ++a) y[a] = g.add(yT[i][a], pT[i][a]);
+        std::vector<std::pair<Val, Val>> sY;
+        for (int r = 0; r < 6; ++r) sY.push_back({s[r], y[r]});
+        const Val sy = g.dot(sY);
+        uu[i] = g.sub(uu0[i], sy);
+        if (par_y) {
+            const Val syd = g.mul(sy, invD[i]);
+            for (int r = 0; r < 6; ++r) {
+                const Val t = g.sub(y[r], g.mul(U[i][r], syd));
+                (*par_y)[r] = g.add((*par_y)[r], arrive(t, i, rob.parent[i]));
+            }
+        }
+    }
     // ---- forward accelerations of one link; qdd goes to `qdd[slot]` ----
     void accel(int i, int slot) {
         const rb_robot_desc *d = rob.d;
@@ -659,6 +738,7 @@ class Aba {
         std::vector<std::pair<Val, Val>> terms;
         for (int r = 0; r < 6; ++r) terms.push_back({U[i][r], ap[r]});
         const Val qdd = g.mul(g.sub(uu[i], g.dot(terms)), invD[i]);
+        qddv[i] = qdd;
         if (mate[i] >= 0) g.store2("qdd[" + std::to_string(slot) + "]", "qdd[" + std::to_string(slot + (mate[i] - i)) + "]", qdd);
         else g.store("qdd[" + std::to_string(slot) + "]", qdd);
         if (!rob.children[i].empty()) {
@@ -848,26 +928,24 @@ struct SplitGenerated {
     std::vector<int> part_of_joint;   // -1: trunk (every wave integrates it), else the part that owns the joint
     int n_helpers = 0;                // helper waves (tendon helpers of the longest parts); the workgroup is n_parts + n_helpers waves
     int helper_stmt = 0;              // statements of the longest helper
+    int x_buffers = 2;                // buffers of the exchange area (1: three or more barriers per acceleration keep reads and writes apart)
+    int acc_slots = 0;                // RK4 accumulator slots a part needs: 2 x the most joints one part integrates (0: 2 n_q, the forms before the cut)
     uint64_t hash = 0;
 };
 
-// max_helpers > 0 (round 4): the longest parts hand their TENDONS to a helper wave each.  A helper recomputes the frames and
-// velocities of the trunk and of its part's links (kinematics only: no inertias, nothing parked), evaluates the part's tendons and
-// leaves the wrench sums per link in the exchange area while the part's own wave runs its forward sweep; behind a second barrier
-// the part adds them to its bias forces and goes on with the backward pass.  Three barriers per acceleration then: S (the parts
-// have published the stage state q, qd of their joints for the helpers), T (tendon wrenches are there), X (the exports to the
-// trunk, as before); the exchange area needs no double buffer any more (between a wave's reads of one acceleration and anybody's
-// writes of the next lies at least one of them).  The critical path of the upper body's arm: 4 284 -> ~3 800 statements.
-// helper_share (percent): the share of a helped part's tendons (by crossings, proximal first) that goes to its helper; the rest stay
-// with the part, which evaluates them during its forward sweep as before.  A helper that takes everything is slower than the part's
-// forward sweep (it repeats the kinematics: barrier stamps, profiles/r4_a/helpers_stamps_first.log - the part then waits at T);
-// the balance for the upper body's arms is about half.
-inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated &out, std::string &err, int max_helpers = 0, int helper_share = 45) {
-    Robot rob;
-    if (int rc = build_robot(d, rob, err)) return rc;
+// The partition of a robot for the split forms: trunk, branches merged where tendons tie them, packed into parts; the heaviest
+// parts that have tendons of their own are the ones that get help (a tendon helper, or a distal wave: generate_split_cut).
+struct SplitPlan {
+    std::vector<char> in_trunk;
+    std::vector<int> trunk, part_of_link, part_of_tendon, helper_of_part, part_of_helper;
+    std::vector<double> load;
+    int K = 0;
+};
+inline int plan_split(const Robot &rob, int max_parts, int max_helpers, SplitPlan &pl, std::string &err) {
     const int nq = rob.nq, nt = rob.nt;
     // ---- trunk: the shallowest link with two or more children, and its ancestors (a forest: no trunk, the trees are the branches)
-    std::vector<char> in_trunk(nq, 0);
+    std::vector<char> &in_trunk = pl.in_trunk;
+    in_trunk.assign(nq, 0);
     int n_roots = 0;
     for (int i = 0; i < nq; ++i) n_roots += rob.parent[i] < 0;
     if (n_roots == 1) {
@@ -909,14 +987,16 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
     std::vector<std::pair<double, int>> groups;
     for (const auto &kv : cost) groups.push_back({-kv.second, kv.first});
     std::sort(groups.begin(), groups.end());
-    std::vector<double> load(K, 0.0);
+    std::vector<double> &load = pl.load;
+    load.assign(K, 0.0);
     std::map<int, int> part_of_group;
     for (const auto &gr : groups) {
         int best = 0;
         for (int q = 1; q < K; ++q) if (load[q] < load[best]) best = q;
         part_of_group[gr.second] = best; load[best] -= gr.first;
     }
-    std::vector<int> part_of_link(nq, -1), part_of_tendon(nt, -1);
+    std::vector<int> &part_of_link = pl.part_of_link, &part_of_tendon = pl.part_of_tendon;
+    part_of_link.assign(nq, -1); part_of_tendon.assign(nt, -1);
     for (int i = 0; i < nq; ++i) if (!in_trunk[i]) part_of_link[i] = part_of_group[find(branch[i])];
     for (int k = 0; k < nt; ++k) {
         if (t_group[k] >= 0) { part_of_tendon[k] = part_of_group[t_group[k]]; continue; }
@@ -924,10 +1004,12 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
         for (int q = 1; q < K; ++q) if (load[q] < load[best]) best = q;
         part_of_tendon[k] = best; load[best] += 65.0 * double(rob.t_cross[k].size());
     }
-    std::vector<int> trunk;
+    std::vector<int> &trunk = pl.trunk;
+    trunk.clear();
     for (int i = 0; i < nq; ++i) if (in_trunk[i]) trunk.push_back(i);
     // ---- helpers: the heaviest parts (within 25 % of the heaviest) that have tendons of their own
-    std::vector<int> helper_of_part(K, -1), part_of_helper;
+    std::vector<int> &helper_of_part = pl.helper_of_part, &part_of_helper = pl.part_of_helper;
+    helper_of_part.assign(K, -1); part_of_helper.clear();
     if (max_helpers > 0) {
         double top = 0.0;
         for (int q = 0; q < K; ++q) top = load[q] > top ? load[q] : top;
@@ -944,6 +1026,32 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
             }
         }
     }
+    pl.K = K;
+    return RB_OK;
+}
+
+// max_helpers > 0 (round 4): the longest parts hand their TENDONS to a helper wave each.  A helper recomputes the frames and
+// velocities of the trunk and of its part's links (kinematics only: no inertias, nothing parked), evaluates the part's tendons and
+// leaves the wrench sums per link in the exchange area while the part's own wave runs its forward sweep; behind a second barrier
+// the part adds them to its bias forces and goes on with the backward pass.  Three barriers per acceleration then: S (the parts
+// have published the stage state q, qd of their joints for the helpers), T (tendon wrenches are there), X (the exports to the
+// trunk, as before); the exchange area needs no double buffer any more (between a wave's reads of one acceleration and anybody's
+// writes of the next lies at least one of them).  The critical path of the upper body's arm: 4 284 -> ~3 800 statements.
+// helper_share (percent): the share of a helped part's tendons (by crossings, proximal first) that goes to its helper; the rest stay
+// with the part, which evaluates them during its forward sweep as before.  A helper that takes everything is slower than the part's
+// forward sweep (it repeats the kinematics: barrier stamps, profiles/r4_a/helpers_stamps_first.log - the part then waits at T);
+// the balance for the upper body's arms is about half.
+inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated &out, std::string &err, int max_helpers = 0, int helper_share = 45,
+                          bool split_backward = false) {
+    Robot rob;
+    if (int rc = build_robot(d, rob, err)) return rc;
+    const int nq = rob.nq, nt = rob.nt;
+    SplitPlan pl;
+    if (int rc = plan_split(rob, max_parts, max_helpers, pl, err)) return rc;
+    const std::vector<char> &in_trunk = pl.in_trunk;
+    const std::vector<int> &trunk = pl.trunk, &part_of_link = pl.part_of_link, &part_of_tendon = pl.part_of_tendon;
+    const std::vector<int> &helper_of_part = pl.helper_of_part, &part_of_helper = pl.part_of_helper;
+    const int K = pl.K;
     const int H = int(part_of_helper.size());
     // which of a helped part's tendons its helper takes: proximal first (by the last link they touch), up to helper_share of the crossings
     std::vector<int> wave_of_tendon = part_of_tendon;       // K + h: helper h
@@ -1033,6 +1141,28 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
         std::vector<int> own;
         for (int i = 0; i < nq; ++i) if (part_of_link[i] == q) own.push_back(i);
         for (int i : own) { A.forward(i); tendons_after(i); g.barrier(); }
+        // what this part hands to the trunk links: its tendons' wrenches on them, and its branches' I^a / p^a
+        std::vector<Sym6> EI(nq);
+        std::vector<std::array<Val, 6>> Ep(nq), Ep0(nq);
+        for (int j : trunk) for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) EI[j].m[r][c] = Gen::K(0.0);
+        auto next_user = [&](int pos) { return pos + 1 < int(own.size()) ? own[own.size() - 2 - pos] : -1; };
+        if (H > 0 && split_backward) {
+            // With helpers the backward pass runs in two sweeps: what does not depend on the forces BEFORE barrier T - beside the
+            // helpers' tendon work - and only the bias forces behind it
+            A.init_backward_pre();
+            for (int j : trunk) Ep0[j] = {Gen::K(0), Gen::K(0), Gen::K(0), Gen::K(0), Gen::K(0), Gen::K(0)};
+            if (!own.empty()) A.prefetch_c(own.back());
+            for (int pos = 0; pos < int(own.size()); ++pos) {
+                const int i = own[own.size() - 1 - pos];
+                g.comment("link " + std::to_string(i) + ": backward pass without the tendon wrenches");
+                A.prefetch_c(next_user(pos));
+                const int par = rob.parent[i];
+                if (par < 0) A.backward_pre(i, nullptr, nullptr);
+                else if (in_trunk[par]) A.backward_pre(i, &EI[par], &Ep0[par]);
+                else A.backward_pre(i, &A.IA[par], &A.pA[par]);
+                g.barrier();
+            }
+        }
         A.wrenches_to_links();
         if (H > 0) g.stmts.push_back({"//", "    RBL_PART_BARRIER;\n"});              // T: the helpers' wrench sums are there
         if (helped) {
@@ -1043,25 +1173,29 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
             }
             g.barrier();
         }
-        A.init_backward();
-        // what this part hands to the trunk links: its tendons' wrenches on them, and its branches' I^a / p^a
-        std::vector<Sym6> EI(nq);
-        std::vector<std::array<Val, 6>> Ep(nq);
-        for (int j : trunk) {
-            for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) EI[j].m[r][c] = Gen::K(0.0);
-            Ep[j] = A.pT[j];
-        }
-        auto next_user = [&](int pos) { return pos + 1 < int(own.size()) ? own[own.size() - 2 - pos] : -1; };
-        if (!own.empty()) A.prefetch_c(own.back());
-        for (int pos = 0; pos < int(own.size()); ++pos) {
-            const int i = own[own.size() - 1 - pos];
-            g.comment("link " + std::to_string(i) + ": backward pass");
-            A.prefetch_c(next_user(pos));
-            const int par = rob.parent[i];
-            if (par < 0) A.backward(i, nullptr, nullptr);
-            else if (in_trunk[par]) A.backward(i, &EI[par], &Ep[par]);
-            else A.backward(i, &A.IA[par], &A.pA[par]);
-            g.barrier();
+        for (int j : trunk) Ep[j] = A.pT[j];
+        if (H > 0 && split_backward) {
+            for (int pos = 0; pos < int(own.size()); ++pos) {
+                const int i = own[own.size() - 1 - pos];
+                g.comment("link " + std::to_string(i) + ": backward pass, the tendon wrenches' part");
+                const int par = rob.parent[i];
+                A.backward_post(i, par < 0 ? nullptr : (in_trunk[par] ? &Ep[par] : &A.yT[par]));
+                g.barrier();
+            }
+            for (int j : trunk) for (int a = 0; a < 6; ++a) Ep[j][a] = g.add(Ep[j][a], Ep0[j][a]);
+        } else {
+            A.init_backward();
+            if (!own.empty()) A.prefetch_c(own.back());
+            for (int pos = 0; pos < int(own.size()); ++pos) {
+                const int i = own[own.size() - 1 - pos];
+                g.comment("link " + std::to_string(i) + ": backward pass");
+                A.prefetch_c(next_user(pos));
+                const int par = rob.parent[i];
+                if (par < 0) A.backward(i, nullptr, nullptr);
+                else if (in_trunk[par]) A.backward(i, &EI[par], &Ep[par]);
+                else A.backward(i, &A.IA[par], &A.pA[par]);
+                g.barrier();
+            }
         }
         g.comment("exports of part " + std::to_string(q));
         int n_slot = 0;
@@ -1186,6 +1320,382 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
     t += "}\n}  // namespace RBL_NS\n";
     out.text = t;
     out.n_q = nq; out.n_t = nt; out.n_parts = K; out.x_slots = x_off[K]; out.n_helpers = H;
+    out.x_buffers = H > 0 ? 1 : 2; out.acc_slots = 0;
+    out.part_of_joint = part_of_link;
+    out.hash = fnv1a(t);
+    return RB_OK;
+}
+
+// The CUT form (round 4): the heaviest parts are cut in two along their chain - a PROXIMAL wave P (the part: it keeps the links between
+// the trunk and the cut, and the part's tendons) and a DISTAL wave D (the subtree below the cut; a part of its own: it owns and
+// integrates its joints).  The tendon helpers of generate_split took 1 000 of an arm's 4 300 statements off its path; what is left there
+// is the backward pass, serial along the chain - but only from the first link whose inertia is KNOWN: the distal half needs nothing from
+// the proximal one but frames and velocities (29 statements per link, against 130 for a link's full forward sweep and 236 for its
+// backward step), so D runs forward + backward of its links while P runs forward + the tendons.  Per acceleration and cut part:
+//   S   every wave has published the stage state q, qd of its joints             P reads D's, D reads P's (frames of the other's links)
+//   T   tendon wrenches on the other wave's links are in the exchange area        D finishes its backward pass with them (the force-free
+//                                                                                 sweep - backward_pre - ran before T, beside P's tendons)
+//   M   D's articulated inertia and bias force for the link above the cut         P runs the backward pass of its links, exports to the trunk
+//   X   the top parts' exports to the trunk (as in generate_split)                every top part finishes the trunk and its own links;
+//   Z   P has published the acceleration of the link above the cut and the trunk's joint accelerations; D runs its links' accelerations
+// Five barriers; the exchange area is single-buffered (every region is written in one phase and read in the next).  Upper body: the
+// longest wave's statements between S and Z drop from 3 941 (helpers, two sweeps) to ~3 200.
+// max_cuts: parts cut at most (the heaviest, as the helpers were chosen); distal_share: percent of a cut part's tendons (by crossings,
+// distal first) that D evaluates instead of P.
+inline int generate_split_cut(const rb_robot_desc *d, int max_parts, SplitGenerated &out, std::string &err, int max_cuts, int distal_share = 0) {
+    Robot rob;
+    if (int rc = build_robot(d, rob, err)) return rc;
+    const int nq = rob.nq, nt = rob.nt;
+    SplitPlan pl;
+    if (int rc = plan_split(rob, max_parts, max_cuts, pl, err)) return rc;
+    const std::vector<char> &in_trunk = pl.in_trunk;
+    const std::vector<int> &trunk = pl.trunk;
+    const int K = pl.K, NTR = int(trunk.size());
+    const std::vector<int> top_of_link = pl.part_of_link;      // the top part of a link (-1: trunk)
+    std::vector<int> part_of_link = pl.part_of_link;           // ... and the wave that owns it (a distal wave: K + h)
+    auto below = [&](int i, int c) { for (int j = i; j >= 0; j = rob.parent[j]) if (j == c) return true; return false; };
+    // ---- where to cut: the link c (its parent stays with P) that makes the longest wave shortest; statement costs as measured on the
+    //      upper body: full forward sweep of a link 130, frame + velocity 29, backward step 236 (+ 30 behind T), acceleration 33
+    std::vector<int> cut_link, cut_part, dist_of(K, -1);
+    for (int q : pl.part_of_helper) {
+        std::vector<int> own;
+        for (int i = 0; i < nq; ++i) if (top_of_link[i] == q) own.push_back(i);
+        double tq = 0.0;
+        for (int k = 0; k < nt; ++k) if (pl.part_of_tendon[k] == q) tq += 65.0 * double(rob.t_cross[k].size());
+        int best = -1;
+        double best_cost = 0.0;
+        for (int c : own) {
+            const int par = rob.parent[c];
+            if (par < 0 || in_trunk[par]) continue;
+            int nD = 0;
+            for (int i : own) nD += below(i, c);
+            const int nP = int(own.size()) - nD;
+            const double p_pre = 130.0 * (NTR + nP) + 29.0 * nD + tq, d_pre = 29.0 * (NTR + nP) + 366.0 * nD;
+            const double cost = (p_pre > d_pre ? p_pre : d_pre) + 30.0 * nD + 245.0 * nP + 33.0 * (nP + nD);
+            if (best < 0 || cost < best_cost) { best = c; best_cost = cost; }
+        }
+        if (best < 0) continue;
+        dist_of[q] = K + int(cut_link.size());
+        for (int i : own) if (below(i, best)) part_of_link[i] = dist_of[q];
+        cut_link.push_back(best); cut_part.push_back(q);
+    }
+    const int H = int(cut_link.size());
+    if (H == 0) return generate_split(d, max_parts, out, err, 0);
+    const int NP = K + H;
+    auto top_of = [&](int w) { return w < K ? w : cut_part[w - K]; };
+    auto is_cut = [&](int w) { return w < K && dist_of[w] >= 0; };
+    // tendons: the part's wave, or (distal_share) the distal one
+    std::vector<int> wave_of_tendon = pl.part_of_tendon;
+    for (int hh = 0; hh < H && distal_share > 0; ++hh) {
+        std::vector<std::pair<int, int>> mine;
+        int total = 0, taken = 0;
+        for (int k = 0; k < nt; ++k) if (pl.part_of_tendon[k] == cut_part[hh]) { mine.push_back({-rob.t_last[k], k}); total += int(rob.t_cross[k].size()); }
+        std::sort(mine.begin(), mine.end());
+        for (const auto &lk : mine) {
+            if (100 * taken >= distal_share * total) break;
+            wave_of_tendon[lk.second] = K + hh;
+            taken += int(rob.t_cross[lk.second].size());
+        }
+    }
+    // ---- exchange area: S slots (q, qd of the trunk's joints and of the cut parts'), then whatever the phases allocate
+    int n_x = 0;
+    std::vector<int> s_slot(nq, -1);
+    for (int i = 0; i < nq; ++i)
+        if (in_trunk[i] || dist_of[top_of_link[i]] >= 0) { s_slot[i] = n_x; n_x += 2; }
+    auto X = [](int slot) { return "RBL_X(" + std::to_string(slot) + ")"; };
+    struct Slot { int link, r, c; bool is_const; double cval; int slot; Val own; };     // a value on its way to another wave
+    auto publish = [&](Gen &g, std::vector<Slot> &list, int link, int r, int c, const Val &v) {
+        if (Gen::is0(v)) return;
+        list.push_back({link, r, c, v.k, v.c, v.k ? -1 : n_x, v});
+        if (!v.k) { g.store(X(n_x), v); ++n_x; }
+    };
+    auto fetch = [&](Gen &g, const Slot &sl) { return sl.is_const ? Gen::K(sl.cval) : g.emit(X(sl.slot)); };
+    auto part_barrier = [](Gen &g) { g.stmts.push_back({"//", "    RBL_PART_BARRIER;\n"}); };
+
+    std::vector<Gen> gens(NP);
+    std::vector<std::unique_ptr<Aba>> abas(NP);
+    std::vector<std::vector<int>> mine(NP), kin(NP);                  // links a wave owns; links whose frames it needs (index order)
+    for (int w = 0; w < NP; ++w) {
+        for (int i = 0; i < nq; ++i) {
+            if (part_of_link[i] == w) mine[w].push_back(i);
+            if (in_trunk[i] || top_of_link[i] == top_of(w)) kin[w].push_back(i);
+        }
+    }
+    std::vector<std::vector<Slot>> handed(NP);                         // tendon wrenches for the other wave of a cut part (link, component)
+    std::vector<std::vector<Slot>> m_exports(NP);                      // a distal wave's I^a (r, c) / p^a (r, c = -1) for the link above the cut
+    std::vector<std::vector<Slot>> x_exports(K);                       // a top part's contributions to the trunk links
+    std::vector<std::vector<Slot>> z_exports(NP);                      // a cut part's: acceleration of the link above the cut (r), trunk qdd (link, r = -1)
+    std::vector<std::vector<Sym6>> EI(NP, std::vector<Sym6>(nq));
+    std::vector<std::vector<std::array<Val, 6>>> Ep(NP, std::vector<std::array<Val, 6>>(nq)), Ep0 = Ep;
+    const std::array<Val, 6> zero6 = {Gen::K(0), Gen::K(0), Gen::K(0), Gen::K(0), Gen::K(0), Gen::K(0)};
+    auto backward_sweep = [&](int w, int mode) {                       // mode 0: backward, 1: backward_pre, 2: backward_post
+        Gen &g = gens[w];
+        Aba &A = *abas[w];
+        const std::vector<int> &own = mine[w];
+        auto next_user = [&](int pos) { return pos + 1 < int(own.size()) ? own[own.size() - 2 - pos] : -1; };
+        if (mode != 2 && !own.empty()) A.prefetch_c(own.back());
+        for (int pos = 0; pos < int(own.size()); ++pos) {
+            const int i = own[own.size() - 1 - pos], par = rob.parent[i];
+            g.comment("link " + std::to_string(i) + (mode == 0 ? ": backward pass" : mode == 1 ? ": backward pass without the tendon wrenches" : ": backward pass, the tendon wrenches' part"));
+            if (mode != 2) A.prefetch_c(next_user(pos));
+            const bool out_of_wave = par >= 0 && part_of_link[par] != w;   // (the parent is a trunk link, or - distal wave - the link above the cut)
+            if (mode == 0) {
+                if (par < 0) A.backward(i, nullptr, nullptr);
+                else if (out_of_wave) A.backward(i, &EI[w][par], &Ep[w][par]);
+                else A.backward(i, &A.IA[par], &A.pA[par]);
+            } else if (mode == 1) {
+                if (par < 0) A.backward_pre(i, nullptr, nullptr);
+                else if (out_of_wave) A.backward_pre(i, &EI[w][par], &Ep0[w][par]);
+                else A.backward_pre(i, &A.IA[par], &A.pA[par]);
+            } else {
+                A.backward_post(i, par < 0 ? nullptr : (out_of_wave ? &Ep[w][par] : &A.yT[par]));
+            }
+            g.barrier();
+        }
+    };
+    // ---- phase A: S, forward sweeps and tendons; the distal waves' force-free backward sweep; wrenches for the other wave; T
+    for (int w = 0; w < NP; ++w) {
+        Gen &g = gens[w];
+        abas[w].reset(new Aba(rob, g, true));
+        Aba &A = *abas[w];
+        pair_parallel_tendons(rob, A.tmate, wave_of_tendon);
+        for (int i = 0; i < nq; ++i)
+            if (s_slot[i] >= 0 && (part_of_link[i] == w || (in_trunk[i] && w == 0))) {
+                g.store(X(s_slot[i]), Gen::named("q[" + std::to_string(i) + "]"));
+                g.store(X(s_slot[i] + 1), Gen::named("qd[" + std::to_string(i) + "]"));
+            }
+        part_barrier(g);                                                                  // S
+        for (int i : kin[w]) {
+            if (part_of_link[i] == w) continue;
+            if (in_trunk[i]) { A.light[i] = w >= K; continue; }          // (a distal wave needs the trunk's frames only; its own registers hold the trunk's state)
+            A.light[i] = 1;
+            A.input_override["q[" + std::to_string(i) + "]"] = g.emit(X(s_slot[i]));
+            A.input_override["qd[" + std::to_string(i) + "]"] = g.emit(X(s_slot[i] + 1));
+        }
+        auto tendons_after = [&](int link) { for (int k = 0; k < nt; ++k) if (wave_of_tendon[k] == w && rob.t_last[k] == link && !A.skip_tendon(k)) A.tendon(k); };
+        tendons_after(-1);
+        for (int i : kin[w]) { A.forward(i); tendons_after(i); g.barrier(); }
+        A.wrenches_to_links();
+        for (int j = 0; j < nq; ++j) { for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) EI[w][j].m[r][c] = Gen::K(0.0); Ep[w][j] = zero6; Ep0[w][j] = zero6; }
+        if (w >= K) {                                                    // distal: everything that does not wait for P's tendons
+            A.init_backward_pre();
+            backward_sweep(w, 1);
+        }
+        if (w >= K || is_cut(w)) {
+            g.comment("tendon wrenches on the other wave's links");
+            for (int i : kin[w]) {
+                if (part_of_link[i] == w || (in_trunk[i] && w < K)) continue;           // (a top part keeps the trunk's share: it goes out with its exports)
+                for (int a = 0; a < 6; ++a) publish(g, handed[w], i, a, -1, A.pT[i][a]);
+            }
+        }
+        if (w >= K || is_cut(w)) part_barrier(g);                                         // T
+    }
+    // a plain part (not cut) runs its backward pass where it delays nobody: before T if it is there before the cut parts' waves are
+    // (their longest stretch is S..T), else between T and M
+    auto count_stmts = [](const Gen &g) { int n = 0; for (const auto &st : g.stmts) n += st.target != "//"; return n; };
+    int longest_a = 0;
+    for (int w = 0; w < NP; ++w) if (w >= K || is_cut(w)) longest_a = count_stmts(gens[w]) > longest_a ? count_stmts(gens[w]) : longest_a;
+    std::vector<char> early(NP, 0);
+    for (int w = 0; w < K; ++w) {
+        if (is_cut(w)) continue;
+        Gen &g = gens[w];
+        Aba &A = *abas[w];
+        early[w] = count_stmts(g) + 245 * int(mine[w].size()) <= longest_a;
+        if (early[w]) {
+            for (int j : trunk) Ep[w][j] = A.pT[j];
+            A.init_backward();
+            backward_sweep(w, 0);
+        }
+        part_barrier(g);                                                                  // T
+    }
+    // ---- phase B: the other wave's wrenches; the distal waves finish their backward pass and export; the plain parts run theirs; M
+    for (int w = 0; w < NP; ++w) {
+        Gen &g = gens[w];
+        Aba &A = *abas[w];
+        const int other = w >= K ? cut_part[w - K] : (is_cut(w) ? dist_of[w] : -1);
+        if (other >= 0) {
+            g.comment("tendon wrenches from wave " + std::to_string(other));
+            for (const Slot &sl : handed[other]) {
+                if (part_of_link[sl.link] != w && !(in_trunk[sl.link] && w < K)) continue;
+                A.pT[sl.link][sl.r] = g.add(A.pT[sl.link][sl.r], fetch(g, sl));
+            }
+            g.barrier();
+        }
+        if (w >= K) {
+            backward_sweep(w, 2);
+            g.comment("exports of distal wave " + std::to_string(w));
+            for (int j = 0; j < nq; ++j) {
+                if (part_of_link[j] == w) continue;
+                for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) publish(g, m_exports[w], j, r, c, EI[w][j].m[r][c]);
+                for (int r = 0; r < 6; ++r) publish(g, m_exports[w], j, r, -1, g.add(Ep[w][j][r], Ep0[w][j][r]));
+            }
+        } else if (!is_cut(w) && !early[w]) {
+            for (int j : trunk) Ep[w][j] = A.pT[j];
+            A.init_backward();
+            backward_sweep(w, 0);
+        }
+        part_barrier(g);                                                                  // M
+    }
+    // ---- phase C: the cut parts' backward pass over their proximal links; every top part's exports to the trunk; X
+    for (int w = 0; w < NP; ++w) {
+        Gen &g = gens[w];
+        Aba &A = *abas[w];
+        if (is_cut(w)) {
+            for (int j : trunk) Ep[w][j] = A.pT[j];
+            A.init_backward();
+            g.comment("from distal wave " + std::to_string(dist_of[w]));
+            for (const Slot &sl : m_exports[dist_of[w]]) {
+                const Val v = fetch(g, sl);
+                if (sl.c >= 0) A.IA[sl.link].m[sl.r][sl.c] = g.add(A.IA[sl.link].m[sl.r][sl.c], v);
+                else A.pA[sl.link][sl.r] = g.add(A.pA[sl.link][sl.r], v);
+            }
+            g.barrier();
+            backward_sweep(w, 0);
+        }
+        if (w < K) {
+            g.comment("exports of part " + std::to_string(w));
+            for (int j : trunk) {
+                for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) publish(g, x_exports[w], j, r, c, EI[w][j].m[r][c]);
+                for (int r = 0; r < 6; ++r) publish(g, x_exports[w], j, r, -1, Ep[w][j][r]);
+            }
+        }
+        part_barrier(g);                                                                  // X
+    }
+    // ---- phase D: the trunk and the top parts' own links; the cut parts publish what their distal waves go on from; Z
+    for (int w = 0; w < NP; ++w) {
+        Gen &g = gens[w];
+        Aba &A = *abas[w];
+        if (w < K) {
+            for (int j : trunk) {
+                for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) A.IA[j].m[r][c] = Gen::K(0.0);
+                A.pA[j] = A.bown[j];
+            }
+            for (int src = 0; src < K; ++src)
+                for (const Slot &sl : x_exports[src]) {
+                    const Val v = sl.is_const ? Gen::K(sl.cval) : (src == w ? sl.own : g.emit(X(sl.slot)));
+                    if (sl.c >= 0) A.IA[sl.link].m[sl.r][sl.c] = g.add(A.IA[sl.link].m[sl.r][sl.c], v);
+                    else A.pA[sl.link][sl.r] = g.add(A.pA[sl.link][sl.r], v);
+                }
+            g.barrier();
+            for (int i = 0; i < nq; ++i) A.cpre_ok[i] = 0;
+            for (int pos = NTR - 1; pos >= 0; --pos) {
+                const int j = trunk[pos], par = rob.parent[j];
+                g.comment("trunk link " + std::to_string(j) + ": backward pass");
+                if (par >= 0) A.prefetch_c(j);
+                A.backward(j, par >= 0 ? &A.IA[par] : nullptr, par >= 0 ? &A.pA[par] : nullptr);
+                g.barrier();
+            }
+            std::vector<int> order = trunk;
+            for (int i : mine[w]) order.push_back(i);
+            for (int i = 0; i < nq; ++i) A.cpre_ok[i] = 0;
+            if (!order.empty()) A.prefetch_c(order[0]);
+            for (size_t pos = 0; pos < order.size(); ++pos) {
+                g.comment("link " + std::to_string(order[pos]) + ": acceleration");
+                if (pos + 1 < order.size()) A.prefetch_c(order[pos + 1]);
+                A.accel(order[pos], order[pos]);
+                g.barrier();
+            }
+            if (is_cut(w)) {
+                g.comment("for distal wave " + std::to_string(dist_of[w]));
+                for (int i : mine[dist_of[w]]) {
+                    const int par = rob.parent[i];
+                    if (part_of_link[par] == dist_of[w]) continue;
+                    bool done = false;
+                    for (const Slot &sl : z_exports[w]) done = done || (sl.link == par && sl.r >= 0);
+                    if (!done) for (int r = 0; r < 6; ++r) publish(g, z_exports[w], par, r, 0, A.acc[par][r]);
+                }
+                for (int j : trunk) publish(g, z_exports[w], j, -1, 0, A.qddv[j]);
+            }
+        }
+        part_barrier(g);                                                                  // Z
+    }
+    // ---- phase E: the distal waves' accelerations
+    for (int w = K; w < NP; ++w) {
+        Gen &g = gens[w];
+        Aba &A = *abas[w];
+        g.comment("from part " + std::to_string(cut_part[w - K]));
+        for (int j = 0; j < nq; ++j) if (part_of_link[j] != w) A.acc[j] = zero6;
+        for (const Slot &sl : z_exports[cut_part[w - K]]) {
+            if (sl.r >= 0) A.acc[sl.link][sl.r] = fetch(g, sl);
+            else g.store("qdd[" + std::to_string(sl.link) + "]", fetch(g, sl));
+        }
+        for (int j : trunk) {                                            // (a trunk acceleration that is a constant zero was not published)
+            bool got = false;
+            for (const Slot &sl : z_exports[cut_part[w - K]]) got = got || (sl.r < 0 && sl.link == j);
+            if (!got) g.store("qdd[" + std::to_string(j) + "]", Gen::K(0.0));
+        }
+        for (int i = 0; i < nq; ++i) A.cpre_ok[i] = 0;
+        const std::vector<int> &order = mine[w];
+        if (!order.empty()) A.prefetch_c(order[0]);
+        for (size_t pos = 0; pos < order.size(); ++pos) {
+            g.comment("link " + std::to_string(order[pos]) + ": acceleration");
+            if (pos + 1 < order.size()) A.prefetch_c(order[pos + 1]);
+            A.accel(order[pos], order[pos]);
+            g.barrier();
+        }
+    }
+    // ---- the header ----
+    out.max_stmt = 0; out.n_stmt = 0; out.part_lds = 0;
+    std::vector<std::string> bodies(NP);
+    std::vector<int> part_stmt(NP, 0);
+    for (int w = 0; w < NP; ++w) {
+        int n_stmt = 0, flops = 0, live = 0;
+        bodies[w] = gens[w].body(n_stmt, flops, live);
+        part_stmt[w] = n_stmt;
+        out.n_stmt += n_stmt;
+        if (n_stmt > out.max_stmt) out.max_stmt = n_stmt;
+        if (gens[w].n_lds > out.part_lds) out.part_lds = gens[w].n_lds;
+    }
+    int most_joints = 0;
+    for (int w = 0; w < NP; ++w) most_joints = int(mine[w].size()) + NTR > most_joints ? int(mine[w].size()) + NTR : most_joints;
+    std::string t;
+    char buf[320];
+    t += "// GENERATED by gym_roboy_amd/csrc/tree_lane_gen.hpp (split form, heavy parts cut in two) - do not edit; the acceleration of ONE robot, one function per wave.\n";
+    std::snprintf(buf, sizeof buf, "#define RBL_NQ %d\n#define RBL_NT %d\n#define RBL_NPARTS %d\n#define RBL_PART_LDS %d\n#define RBL_X_SLOTS %d\n#define RBL_NHELPERS 0\n"
+                  "#define RBL_X_SINGLE 1\n#define RBL_ACC_JOINTS %d\n", nq, nt, NP, out.part_lds, n_x, most_joints);
+    t += buf;
+    t += "namespace RBL_NS {\n";
+    write_tables(t, rob);
+    t += "RBL_ITABLE(PART_OF_JOINT, " + std::to_string(nq) + ") = {";
+    for (int i = 0; i < nq; ++i) t += std::to_string(part_of_link[i]) + (i + 1 < nq ? ", " : "");
+    t += "};\nRBL_ITABLE(PART_OF_TENDON, " + std::to_string(nt) + ") = {";
+    for (int k = 0; k < nt; ++k) t += std::to_string(wave_of_tendon[k]) + (k + 1 < nt ? ", " : "");
+    t += "};\n";
+    // which wave runs which part: waves w and w + 4 share a SIMD (waves go to the four SIMDs in turn) - the shortest top parts pair up
+    // there; the distal waves, whose S..T stretch is the longest of all, come last
+    {
+        std::vector<int> order(NP);
+        for (int w = 0; w < NP; ++w) order[w] = w;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return (a >= K) != (b >= K) ? b >= K : part_stmt[a] < part_stmt[b]; });
+        std::vector<int> wave_of(NP, -1), free_waves;
+        const int n_shared = NP > 4 ? NP - 4 : 0;
+        int next = 0;
+        for (int p = 0; p < n_shared && p < 4; ++p) { wave_of[order[next++]] = p; wave_of[order[next++]] = p + 4; }
+        for (int wv = 0; wv < NP; ++wv) {
+            bool used = false;
+            for (int x = 0; x < NP; ++x) used = used || wave_of[x] == wv;
+            if (!used) free_waves.push_back(wv);
+        }
+        for (int wv : free_waves) wave_of[order[next++]] = wv;
+        t += "RBL_ITABLE(WAVE_OF_PART, " + std::to_string(NP) + ") = {";
+        for (int w = 0; w < NP; ++w) t += std::to_string(wave_of[w]) + (w + 1 < NP ? ", " : "");
+        t += "};\n";
+    }
+    for (int w = 0; w < NP; ++w) {
+        t += "template <class RBL_L, class RBL_XA>\nRBL_FN void rbl_part" + std::to_string(w) +
+             "(const float (&q)[RBL_NQ], const float (&qd)[RBL_NQ], const float (&spu)[RBL_NT], float (&qdd)[RBL_NQ], RBL_L rbl_lds, RBL_XA rbl_x) {\n";
+        t += bodies[w];
+        t += "}\n";
+    }
+    t += "template <class RBL_L, class RBL_XA>\nRBL_FN void rbl_part(int part, const float (&q)[RBL_NQ], const float (&qd)[RBL_NQ], "
+         "const float (&spu)[RBL_NT], float (&qdd)[RBL_NQ], RBL_L rbl_lds, RBL_XA rbl_x) {\n";
+    for (int w = 0; w < NP; ++w)
+        t += std::string("    ") + (w ? "else " : "") + (w + 1 < NP ? "if (part == " + std::to_string(w) + ") " : "") + "rbl_part" +
+             std::to_string(w) + "(q, qd, spu, qdd, rbl_lds, rbl_x);\n";
+    t += "}\n}  // namespace RBL_NS\n";
+    out.text = t;
+    out.n_q = nq; out.n_t = nt; out.n_parts = NP; out.x_slots = n_x; out.n_helpers = 0; out.helper_stmt = 0;
+    out.x_buffers = 1; out.acc_slots = 2 * most_joints;
     out.part_of_joint = part_of_link;
     out.hash = fnv1a(t);
     return RB_OK;

@@ -23,6 +23,11 @@
 // the parts - which costs that part nothing: a wave issues one vector instruction per 5.5 cycles at best, a SIMD takes one per 2.8
 // from two.  With helpers the exchange area is SINGLE-buffered (between a wave's reads of one acceleration and anybody's writes
 // of the next lies at least one barrier).
+//
+// The cut form (round 4, generate_split_cut; RBL_X_SINGLE, RBL_ACC_JOINTS): the heaviest parts are two waves each - the part's own
+// (proximal links, tendons) and a distal one, which is a part like any other here (it owns and integrates its joints, and the trunk's
+// like everybody); five barriers per acceleration, all in the generated text; single-buffered exchange area; the RK4 accumulators
+// take a slot per joint a part integrates instead of one per joint of the robot.
 #pragma once
 #include "env_common.hpp"
 #include "philox.hpp"
@@ -42,10 +47,17 @@ struct SplitLds {
 };
 
 constexpr int SP_IMG_SLOTS = 5 * RBL_NQ > 3 * RBL_NQ + RBL_NT ? 5 * RBL_NQ : 3 * RBL_NQ + RBL_NT;
-constexpr int SP_WAVE_SLOTS = RBL_PART_LDS + 2 * RBL_NQ;
+#ifndef RBL_ACC_JOINTS
+#define RBL_ACC_JOINTS RBL_NQ        // joints a part integrates at most (the cut form says; else a slot per joint of the robot)
+#endif
+#ifndef RBL_X_SINGLE
+#define RBL_X_SINGLE (RBL_NHELPERS > 0)
+#endif
+constexpr int SP_ACC_JOINTS = RBL_ACC_JOINTS;
+constexpr int SP_WAVE_SLOTS = RBL_PART_LDS + 2 * SP_ACC_JOINTS;
 constexpr int SP_ACC_SLOT = RBL_PART_LDS;
 constexpr int SP_NWAVES = RBL_NPARTS + RBL_NHELPERS;
-constexpr int SP_X_BUFFERS = RBL_NHELPERS > 0 ? 1 : 2;
+constexpr int SP_X_BUFFERS = RBL_X_SINGLE ? 1 : 2;
 constexpr int SP_X_OFF = SP_IMG_SLOTS;
 constexpr int SP_WAVE_OFF = SP_X_OFF + SP_X_BUFFERS * RBL_X_SLOTS;
 constexpr int SP_FLAG_OFF = SP_WAVE_OFF + RBL_NPARTS * SP_WAVE_SLOTS;
@@ -119,6 +131,15 @@ __device__ __forceinline__ void sp_store_image(float *__restrict__ g, long env0,
 __device__ __forceinline__ float sp_sat(float v, int j) { return __builtin_amdgcn_fmed3f(v, -VMAX[j], VMAX[j]); }
 template <int PART>
 __device__ __forceinline__ constexpr bool sp_mine(int j) { return PART_OF_JOINT[j] < 0 || PART_OF_JOINT[j] == PART; }
+// the RK4 accumulator slot of joint j in part PART's region: one per joint the part integrates (the cut form: five waves' regions
+// of 2 n_q slots each would not fit the LDS), or simply j
+template <int PART>
+__device__ __forceinline__ constexpr int sp_acc(int j) {
+    if (SP_ACC_JOINTS == RBL_NQ) return j;
+    int n = 0;
+    for (int i = 0; i < j; ++i) n += sp_mine<PART>(i) ? 1 : 0;
+    return n;
+}
 
 // One env step of the joints part PART integrates (the trunk's and its own); the other entries of q / v are not touched.
 template <int INTEG, int PART>
@@ -144,7 +165,10 @@ __device__ __forceinline__ bool split_step(const SplitLds &L, float *xbase, int 
             const float h6 = h * (1.0f / 6.0f);
             float kq[RBL_NQ], kv[RBL_NQ];
 #pragma unroll
-            for (int j = 0; j < RBL_NQ; ++j) { kq[j] = 0.0f; kv[j] = 0.0f; L(SP_ACC_SLOT + j) = 0.0f; L(SP_ACC_SLOT + RBL_NQ + j) = 0.0f; }
+            for (int j = 0; j < RBL_NQ; ++j) {
+                kq[j] = 0.0f; kv[j] = 0.0f;
+                if (sp_mine<PART>(j)) { L(SP_ACC_SLOT + sp_acc<PART>(j)) = 0.0f; L(SP_ACC_SLOT + SP_ACC_JOINTS + sp_acc<PART>(j)) = 0.0f; }
+            }
 #pragma unroll 1
             for (int st = 0; st < 4; ++st) {
                 const float wgt = (st == 0 || st == 3) ? 1.0f : 2.0f, cst = st == 0 ? 0.0f : (st == 3 ? h : 0.5f * h);
@@ -155,14 +179,14 @@ __device__ __forceinline__ bool split_step(const SplitLds &L, float *xbase, int 
                     if (sp_mine<PART>(j)) { qs[j] = q[j] + cst * kq[j]; kq[j] = sp_sat(v[j] + cst * kv[j], j); }
                 }
 #pragma unroll
-                for (int j = 0; j < RBL_NQ; ++j) if (sp_mine<PART>(j)) L(SP_ACC_SLOT + j) += wgt * kq[j];
+                for (int j = 0; j < RBL_NQ; ++j) if (sp_mine<PART>(j)) L(SP_ACC_SLOT + sp_acc<PART>(j)) += wgt * kq[j];
                 accel(qs, kq, kv);
 #pragma unroll
-                for (int j = 0; j < RBL_NQ; ++j) if (sp_mine<PART>(j)) L(SP_ACC_SLOT + RBL_NQ + j) += wgt * kv[j];
+                for (int j = 0; j < RBL_NQ; ++j) if (sp_mine<PART>(j)) L(SP_ACC_SLOT + SP_ACC_JOINTS + sp_acc<PART>(j)) += wgt * kv[j];
             }
 #pragma unroll
             for (int j = 0; j < RBL_NQ; ++j)
-                if (sp_mine<PART>(j)) { q[j] = q[j] + h6 * L(SP_ACC_SLOT + j); v[j] = v[j] + h6 * L(SP_ACC_SLOT + RBL_NQ + j); }
+                if (sp_mine<PART>(j)) { q[j] = q[j] + h6 * L(SP_ACC_SLOT + sp_acc<PART>(j)); v[j] = v[j] + h6 * L(SP_ACC_SLOT + SP_ACC_JOINTS + sp_acc<PART>(j)); }
         }
 #pragma unroll
         for (int j = 0; j < RBL_NQ; ++j) {

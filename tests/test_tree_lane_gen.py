@@ -147,7 +147,7 @@ def test_in_tree_generated_headers_are_current():
     fresh = os.path.join(BUILD, "tree_lane_baked_fresh.hpp")
     gen.generate(UpperBodyRobot().get_description(), fresh)
     assert open(fresh).read() == open(os.path.join(csrc, "tree_lane_baked.hpp")).read(), "run make -C gym_roboy_amd/csrc"
-    gen.generate_split(UpperBodyRobot().get_description(), fresh, max_helpers=gen.SPLIT_HELPERS, helper_share=gen.SPLIT_HELPER_SHARE)
+    gen.generate_split(UpperBodyRobot().get_description(), fresh, max_helpers=gen.SPLIT_HELPERS, helper_share=gen.SPLIT_HELPER_SHARE, two_sweeps=gen.SPLIT_TWO_SWEEPS, cut=gen.SPLIT_CUT)
     assert open(fresh).read() == open(os.path.join(csrc, "tree_lane_split_baked.hpp")).read(), "run make -C gym_roboy_amd/csrc"
 
 
@@ -288,6 +288,61 @@ def test_upper_body_split_form_with_tendon_helpers_matches_oracle():
     assert all_["max_stmt"] < 0.85 * plain["max_stmt"] and all_["helper_stmt"] > info["helper_stmt"]
     one = check_split(UpperBodyRobot().get_description(), "upper_body_h1", max_helpers=1)
     assert one["n_helpers"] == 1
+
+
+TWO_SWEEPS, CUT = 1 << 16, 1 << 17          # bits of the generator entry's max_helpers word (csrc/gen_tree_lane.cpp)
+
+
+def test_upper_body_split_form_with_the_backward_pass_in_two_sweeps_matches_oracle():
+    """The library's form: the bias-force recursion is linear in the forces, so the arms run the whole backward pass WITHOUT the
+    tendon wrenches before barrier T (beside the helpers' tendon work) and propagate only the wrenches' part behind it."""
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    import gen_tree_lane_baked as gen
+    desc = UpperBodyRobot().get_description()
+    lib_form = gen.SPLIT_HELPERS | (gen.SPLIT_HELPER_SHARE << 8) | (TWO_SWEEPS if gen.SPLIT_TWO_SWEEPS else 0) | (CUT if gen.SPLIT_CUT else 0)
+    info = check_split(desc, "upper_body_lib_form", max_helpers=lib_form)
+    one = check_split(desc, "upper_body_h2_s70", max_helpers=2 | (70 << 8))
+    two = check_split(desc, "upper_body_h2_s70_t", max_helpers=2 | (70 << 8) | TWO_SWEEPS)
+    assert info["n_parts"] == 3 and two["n_helpers"] == 2
+    # what is left behind T: the text of the longest part between its second and third workgroup barrier
+    def behind_t(tag):
+        text = open(os.path.join(BUILD, "lane_split_%s.hpp" % tag)).read()
+        body = text.split("RBL_FN void rbl_part0(")[1].split("\n}\n")[0].split("RBL_PART_BARRIER;")
+        return sum(1 for line in body[2].split("\n") if " = " in line and not line.strip().startswith("//"))
+    assert behind_t("upper_body_h2_s70_t") < 0.25 * behind_t("upper_body_h2_s70")
+
+
+@pytest.mark.parametrize("seed", [4, 9, 10])
+def test_random_robots_split_form_in_two_sweeps(seed):
+    from gym_roboy_amd.envs.robots import RobotDescription
+    from random_robots import random_tree_spec
+    check_split(RobotDescription(random_tree_spec(seed)), "random%dt" % seed, n=6, tol=5e-4, max_helpers=2 | (100 << 8) | TWO_SWEEPS)
+
+
+def test_upper_body_cut_form_matches_oracle():
+    """The cut form (measured, not selected: csrc/roboy_sim.hip RB_SPLIT_CUT): each arm as a proximal wave (three links, the tendons) and
+    a distal one (four links) that is a part of its own; five barriers per acceleration."""
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    desc = UpperBodyRobot().get_description()
+    info = check_split(desc, "upper_body_cut", max_helpers=2 | CUT)
+    assert info["n_parts"] == 5 and info["n_helpers"] == 0
+    assert info["part_of_joint"][6:13] == [0, 0, 0, 3, 3, 3, 3] and info["part_of_joint"][13:20] == [1, 1, 1, 4, 4, 4, 4]
+    assert info["max_stmt"] < 0.7 * 3941                      # ... of the helper form's longest part
+    text = open(os.path.join(BUILD, "lane_split_upper_body_cut.hpp")).read()
+    assert "#define RBL_X_SINGLE 1" in text and "#define RBL_ACC_JOINTS 7" in text
+    for part in range(5):                                     # the same number of workgroup barriers in every wave
+        body = text.split("RBL_FN void rbl_part%d(" % part)[1].split("\n}\n")[0]
+        assert body.count("RBL_PART_BARRIER;") == 5
+    check_split(desc, "upper_body_cut_s40", max_helpers=2 | (40 << 8) | CUT)      # the distal waves take 40 % of the tendons
+
+
+@pytest.mark.parametrize("seed", [4, 5, 9, 10])
+def test_random_robots_cut_form(seed):
+    from gym_roboy_amd.envs.robots import RobotDescription
+    from random_robots import random_tree_spec
+    desc = RobotDescription(random_tree_spec(seed))
+    check_split(desc, "random%dc" % seed, n=6, tol=5e-4, max_helpers=2 | CUT)
+    check_split(desc, "random%dcs" % seed, n=6, tol=5e-4, max_helpers=2 | (40 << 8) | CUT)
 
 
 def test_upper_body_split_in_two_parts():

@@ -8,7 +8,7 @@ import sys,json
 d=json.loads(sys.stdin.read().strip().split(chr(10))[-1]); print('$lib $w envs $n: %.2f us per step (events)' % (d['roofline']['launch_us_events']))"
 }
 {
-for lib in gym_roboy_amd/csrc/variants/lib_s35.so gym_roboy_amd/csrc/variants/lib_s45.so gym_roboy_amd/csrc/variants/lib_s55.so gym_roboy_amd/csrc/variants/lib_s62.so gym_roboy_amd/csrc/libroboy_sim.so; do
+for lib in gym_roboy_amd/csrc/libroboy_sim.so gym_roboy_amd/csrc/variants/lib_s70_t1.so gym_roboy_amd/csrc/variants/lib_s45_u.so gym_roboy_amd/csrc/variants/lib_s70_u.so gym_roboy_amd/csrc/variants/lib_s85_u.so gym_roboy_amd/csrc/variants/lib_s100_u.so; do
  run $lib upper-body-8192-euler 8192; run $lib upper-body-8192-rk4 8192
 done
-} 2>&1 | tee gpurun_out/r4_a/helpers_share.log
+} 2>&1 | tee gpurun_out/r4_a/helpers_sweeps.log
