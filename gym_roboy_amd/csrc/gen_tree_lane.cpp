@@ -54,8 +54,9 @@ extern "C" int rb_gen_tree_lane_split_h(const rb_robot_desc *d, int max_parts, i
     const bool two_sweeps = ((max_helpers >> 16) & 1) != 0;
     // ... bit 17 = the CUT form instead (generate_split_cut: max_helpers parts cut in two, share = the distal waves' share of the tendons)
     const bool cut = ((max_helpers >> 17) & 1) != 0;
+    const bool share_trunk = ((max_helpers >> 18) & 1) != 0;        // bit 18: one part evaluates the trunk links' inertias for all
     const int rc = cut ? rblg::generate_split_cut(d, max_parts, g, err, max_helpers & 0xff, share)
-                       : rblg::generate_split(d, max_parts, g, err, max_helpers & 0xff, share ? share : 45, two_sweeps);
+                       : rblg::generate_split(d, max_parts, g, err, max_helpers & 0xff, share ? share : 45, two_sweeps, share_trunk);
     if (rc) { std::fprintf(stderr, "rb_gen_tree_lane_split: %s\n", err.c_str()); return rc; }
     FILE *f = std::fopen(path, "w");
     if (!f) return RB_EINVAL;

@@ -133,6 +133,10 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #ifndef RB_SPLIT_TWO_SWEEPS
 #define RB_SPLIT_TWO_SWEEPS 1
 #endif
+// ... and whether ONE part evaluates the trunk links' inertias / bias forces for all (SPLIT_SHARE_TRUNK there)
+#ifndef RB_SPLIT_SHARE_TRUNK
+#define RB_SPLIT_SHARE_TRUNK 0
+#endif
 // ... or the CUT form instead (generate_split_cut: the RB_SPLIT_HELPERS heaviest parts as a proximal and a distal wave each;
 // RB_SPLIT_HELPER_SHARE is then the distal waves' share of the tendons).  SPLIT_CUT there.  Measured and NOT selected: 22 % fewer
 // vector instructions on the longest path of the upper body, and 10.2 / 30.1 us against 8.84 / 25.1 - all five waves are busy at once
@@ -509,7 +513,7 @@ bool tree_wants_split(const rb_sim *s) {
     return s->kernel_choice == RB_KERNEL_AUTO && s->split_baked && s->n <= RB_TREE_SPLIT_BATCH;
 }
 size_t split_lds_bytes(const rblg::SplitGenerated &g) {      // the formula of tree_lane_split.hpp: SP_LDS_BYTES
-    const int img = 5 * g.n_q > 3 * g.n_q + g.n_t ? 5 * g.n_q : 3 * g.n_q + g.n_t;
+    const int img = 3 * g.n_q + (3 * g.n_q > g.n_t ? 3 * g.n_q : g.n_t);
     return size_t(img + g.x_buffers * g.x_slots + g.n_parts * (g.part_lds + (g.acc_slots ? g.acc_slots : 2 * g.n_q)) + 3 * g.n_parts + 1) * 64 * 4;
 }
 // the hiprtc-built split kernels of a robot without ahead-of-time instances (explicit choice only); kind: 0 = step, 1 = env step
@@ -881,7 +885,7 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
             s->lane_ok = rblg::generate(robot, true, s->lane_gen, why_gen) == RB_OK;
             s->lane_baked = s->lane_ok && s->lane_gen.hash == RBL_TEXT_HASH && rblg::lane_lds_slots(s->lane_gen) == rbl_baked::LDS_SLOTS;
             s->split_ok = (RB_SPLIT_CUT ? rblg::generate_split_cut(robot, 4, s->split_gen, why_gen, RB_SPLIT_HELPERS, RB_SPLIT_HELPER_SHARE)
-                                        : rblg::generate_split(robot, 4, s->split_gen, why_gen, RB_SPLIT_HELPERS, RB_SPLIT_HELPER_SHARE, RB_SPLIT_TWO_SWEEPS != 0)) == RB_OK &&
+                                        : rblg::generate_split(robot, 4, s->split_gen, why_gen, RB_SPLIT_HELPERS, RB_SPLIT_HELPER_SHARE, RB_SPLIT_TWO_SWEEPS != 0, RB_SPLIT_SHARE_TRUNK != 0)) == RB_OK &&
                           split_lds_bytes(s->split_gen) <= 160 * 1024;
             if (!s->split_ok && RB_SPLIT_HELPERS > 0)        // (the exchange area of the helper form does not fit: the three-barrier-less form)
                 s->split_ok = rblg::generate_split(robot, 4, s->split_gen, why_gen, 0) == RB_OK;

@@ -866,7 +866,7 @@ tree_env_step_aba(const TreeDev tg, const rbe::EnvParams ep, const rbe::GoalBox 
             ret = 0.0f;
         }
         feas[me] = fz; step_num[me] = sn; ep_ret[me] = ret; reward[me] = r; done[me] = dn ? 1u : 0u;
-        if (!all_ok) infeas_n[me] += 1u;
+        if (!all_ok) __hip_atomic_fetch_add(&infeas_n[me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (returns nothing: no load to wait for)
     }
 }
 

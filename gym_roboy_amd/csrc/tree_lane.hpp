@@ -318,7 +318,8 @@ tree_lane_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__res
     if (__builtin_amdgcn_ballot_w64(dn && mine) != 0ull) store_rows<RBL_NQ>(goal, env0, live, region, lane, gn);
     if (mine) {
         feas[me] = fz; step_num[me] = sn; ep_ret[me] = ret; reward[me] = r; done[me] = dn ? 1u : 0u;
-        if (!ok) infeas_n[me] += 1u;
+        // (an atomic that returns nothing: a load-add-store here is a memory latency the wave - alone on its SIMD - sits out)
+        if (!ok) __hip_atomic_fetch_add(&infeas_n[me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -1042,7 +1042,7 @@ inline int plan_split(const Robot &rob, int max_parts, int max_helpers, SplitPla
 // forward sweep (it repeats the kinematics: barrier stamps, profiles/r4_a/helpers_stamps_first.log - the part then waits at T);
 // the balance for the upper body's arms is about half.
 inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated &out, std::string &err, int max_helpers = 0, int helper_share = 45,
-                          bool split_backward = false) {
+                          bool split_backward = false, bool share_trunk = false) {
     Robot rob;
     if (int rc = build_robot(d, rob, err)) return rc;
     const int nq = rob.nq, nt = rob.nt;
@@ -1111,7 +1111,30 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
         helper_bodies[hh] = g.body(n_stmt, flops, live);
         if (n_stmt > out.helper_stmt) out.helper_stmt = n_stmt;
     }
-    const int x_base = n_sslot + n_tslot;                   // the parts' exports start here
+    // ---- share_trunk: ONE part - the lightest - evaluates the trunk links' inertias, bias forces and velocity-product accelerations
+    //      (100 of the 130 statements of a link's forward sweep) and leaves them in the exchange area; the others run the trunk's frames
+    //      only and fetch those 33 values per link behind barrier X, where they finish the trunk.  Same values in every part.
+    struct TrunkVal { int link, kind, r, c; bool is_const; double cval; int slot; };      // kind 0: inertia (r, c), 1: bias force r, 2: c r
+    std::vector<TrunkVal> trunk_vals;
+    int trunk_owner = -1, n_trunk_slot = 0;
+    if (share_trunk && !trunk.empty()) {
+        trunk_owner = 0;
+        for (int q = 1; q < K; ++q) if (pl.load[q] < pl.load[trunk_owner]) trunk_owner = q;
+        Gen g0;                                             // (a dry run of the trunk's forward sweep: which of the values are constants)
+        Aba A0(rob, g0, false);
+        for (int j : trunk) {
+            A0.forward(j);
+            auto add = [&](int kind, int r, int c, const Val &v) {
+                if (Gen::is0(v)) return;
+                trunk_vals.push_back({j, kind, r, c, v.k, v.c, v.k ? -1 : n_sslot + n_tslot + n_trunk_slot});
+                if (!v.k) ++n_trunk_slot;
+            };
+            for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) add(0, r, c, A0.Iown[j].m[r][c]);
+            for (int a = 0; a < 6; ++a) add(1, a, 0, A0.bown[j][a]);
+            for (int a = 0; a < 6; ++a) add(2, a, 0, A0.cacc[j][a]);
+        }
+    }
+    const int x_base = n_sslot + n_tslot + n_trunk_slot;    // the parts' exports start here
 
     // ---- phase 1 of every part: trunk forward, own branches forward + tendons + backward, exports ----
     struct Export { int link, r, c; bool is_const; double cval; int slot; };   // c < 0: bias-force component r
@@ -1137,7 +1160,15 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
         }
         auto tendons_after = [&](int link) { for (int k = 0; k < nt; ++k) if (wave_of_tendon[k] == q && rob.t_last[k] == link && !A.skip_tendon(k)) A.tendon(k); };
         tendons_after(-1);
-        for (int j : trunk) { A.forward(j); tendons_after(j); g.barrier(); }
+        for (int j : trunk) {
+            A.light[j] = trunk_owner >= 0 && q != trunk_owner;
+            A.forward(j);
+            if (q == trunk_owner)
+                for (const TrunkVal &tv : trunk_vals)
+                    if (tv.link == j && !tv.is_const)
+                        g.store("RBL_X(" + std::to_string(tv.slot) + ")", tv.kind == 0 ? A.Iown[j].m[tv.r][tv.c] : (tv.kind == 1 ? A.bown[j][tv.r] : A.cacc[j][tv.r]));
+            tendons_after(j); g.barrier();
+        }
         std::vector<int> own;
         for (int i = 0; i < nq; ++i) if (part_of_link[i] == q) own.push_back(i);
         for (int i : own) { A.forward(i); tendons_after(i); g.barrier(); }
@@ -1230,6 +1261,15 @@ inline int generate_split(const rb_robot_desc *d, int max_parts, SplitGenerated 
         Gen &g = gens[q];
         Aba &A = *abas[q];
         g.stmts.push_back({"//", "    RBL_PART_BARRIER;\n"});
+        if (trunk_owner >= 0 && q != trunk_owner) {
+            g.comment("the trunk links' inertias, bias forces and velocity products from part " + std::to_string(trunk_owner));
+            for (const TrunkVal &tv : trunk_vals) {
+                const Val v = tv.is_const ? Gen::K(tv.cval) : g.emit("RBL_X(" + std::to_string(tv.slot) + ")");
+                if (tv.kind == 0) A.Iown[tv.link].m[tv.r][tv.c] = v;
+                else if (tv.kind == 1) A.bown[tv.link][tv.r] = v;
+                else A.cacc[tv.link][tv.r] = v;
+            }
+        }
         for (int j : trunk) {
             for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) A.IA[j].m[r][c] = Gen::K(0.0);
             A.pA[j] = A.bown[j];

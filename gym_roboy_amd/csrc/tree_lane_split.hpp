@@ -9,7 +9,8 @@
 //
 // Included after the generated split header (RBL_NS, RBL_NQ, RBL_NT, RBL_NPARTS, RBL_PART_LDS, RBL_X_SLOTS, the tables
 // KSG / QLO / QHI / VMAX / PART_OF_JOINT and RBL_NS::rbl_part).  LDS of a workgroup, in 64-float slots:
-//   image   max(2 n_q + n_t, 5 n_q)   the rows of the 64 envs, transposed in / out cooperatively by all waves
+//   image   3 n_q + max(3 n_q, n_t)   the rows of the 64 envs (q | qd | goal | action, the observation rows over the action's),
+//                                     transposed in / out cooperatively by all waves
 //   X       2 x RBL_X_SLOTS           exchange area, double-buffered: acceleration n uses buffer n & 1, so a wave that is
 //                                     already writing for n + 1 cannot disturb one still reading n (it cannot reach n + 2
 //                                     before the other has passed the barrier of n + 1)
@@ -46,7 +47,11 @@ struct SplitLds {
     __device__ __forceinline__ float &operator()(int slot) const { return p[slot * 64]; }
 };
 
-constexpr int SP_IMG_SLOTS = 5 * RBL_NQ > 3 * RBL_NQ + RBL_NT ? 5 * RBL_NQ : 3 * RBL_NQ + RBL_NT;
+// row images: q | qd | goal | action, the observation image [q | qd | goal as observed] over the action image (dead after a wave's
+// first lines); the goal image stays readable to the end of the step (the waves fetch their joints' goals AFTER the step: ten values
+// fewer alive across it in kernels that sit at their 256 registers)
+constexpr int SP_IMG_SLOTS = 3 * RBL_NQ + (3 * RBL_NQ > RBL_NT ? 3 * RBL_NQ : RBL_NT);
+constexpr int SP_OV = RBL_NQ * 64, SP_OG = 2 * RBL_NQ * 64, SP_OA = 3 * RBL_NQ * 64, SP_OO = SP_OA;
 #ifndef RBL_ACC_JOINTS
 #define RBL_ACC_JOINTS RBL_NQ        // joints a part integrates at most (the cut form says; else a slot per joint of the robot)
 #endif
@@ -127,6 +132,29 @@ __device__ __forceinline__ void sp_store_image(float *__restrict__ g, long env0,
         if (k < W) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(img[k * 64 + lane]), r, lane * 4, k * 256, 0);
     }
 }
+
+// The output images of a step at once: every LDS read of every image first, then the stores back to back (one after the other the
+// images cost an LDS latency per store: barrier stamps, 150-200 cycles per store of a wave that is alone on its SIMD)
+template <int W>
+struct SpImageStore {
+    static constexpr int PER = (W + SP_NWAVES - 1) / SP_NWAVES;
+    float t[PER];
+    __device__ __forceinline__ void read(const float *img, int wave, int lane) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int k = wave + u * SP_NWAVES;
+            t[u] = img[(k < W ? k : W - 1) * 64 + lane];
+        }
+    }
+    __device__ __forceinline__ void store(float *__restrict__ g, long env0, int live, int wave, int lane) const {
+        const __amdgpu_buffer_rsrc_t r = sp_rows_rsrc(g, env0, W, live);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int k = wave + u * SP_NWAVES;
+            if (k < W) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t[u]), r, lane * 4, k * 256, 0);
+        }
+    }
+};
 
 __device__ __forceinline__ float sp_sat(float v, int j) { return __builtin_amdgcn_fmed3f(v, -VMAX[j], VMAX[j]); }
 template <int PART>
@@ -209,7 +237,7 @@ __device__ __forceinline__ void split_wave(float *lds, int lane, int live, float
     float *img = lds;
     const int row = sp_opaque(lane < live ? lane : live - 1);
     float q[RBL_NQ], v[RBL_NQ], spu[RBL_NT];
-    constexpr int OV = RBL_NQ * 64, OA = 2 * RBL_NQ * 64;
+    constexpr int OV = SP_OV, OA = SP_OA, OG = SP_OG;
 #pragma unroll
     for (int j = 0; j < RBL_NQ; ++j) { q[j] = img[row * RBL_NQ + j]; v[j] = img[OV + row * RBL_NQ + j]; }
 #pragma unroll
@@ -223,24 +251,25 @@ __device__ __forceinline__ void split_wave(float *lds, int lane, int live, float
             spu[k] = (a * act_scale) * KSG[k];
         }
     }
-    // env layer: the goals of the joints this wave accounts for (it sums their squared distances), read before the image is reused
-    constexpr int OG = (2 * RBL_NQ + RBL_NT) * 64;
-    float gl[RBL_NQ];
-#pragma unroll
-    for (int j = 0; j < RBL_NQ; ++j) gl[j] = (env_layer && (PART_OF_JOINT[j] == PART || (PART_OF_JOINT[j] < 0 && PART == 0))) ? img[OG + row * RBL_NQ + j] : 0.0f;
     const SplitLds L{lds + (SP_WAVE_OFF + PART * SP_WAVE_SLOTS) * 64 + lane};
     const bool ok = split_step<INTEG, PART>(L, lds + SP_X_OFF * 64, lane, spu, h, nsub, q, v);
     // (the accelerations' barriers lie between every wave's reads of the input image above and these writes)
     const int wl = sp_opaque(lane);
 #pragma unroll
     for (int j = 0; j < RBL_NQ; ++j)
-        if (PART_OF_JOINT[j] == PART || (PART_OF_JOINT[j] < 0 && PART == 0)) { img[wl * RBL_NQ + j] = q[j]; img[OV + wl * RBL_NQ + j] = v[j]; }
+        if (PART_OF_JOINT[j] == PART || (PART_OF_JOINT[j] < 0 && PART == 0)) {
+            img[wl * RBL_NQ + j] = q[j]; img[OV + wl * RBL_NQ + j] = v[j];
+            // env layer: and into the observation rows [q | qd | goal] (the image over the action image, which every wave has read
+            // before its first acceleration barrier); the accountant adds the goals
+            if (env_layer) { img[OA + wl * (3 * RBL_NQ) + j] = q[j]; img[OA + wl * (3 * RBL_NQ) + RBL_NQ + j] = v[j]; }
+        }
     lds[(SP_FLAG_OFF + 3 * PART) * 64 + lane] = ok ? 1.0f : 0.0f;
     if (env_layer) {
+        // the goals of the joints this wave accounts for (it sums their squared distances)
         float dq2 = 0.0f, dv2 = 0.0f;
 #pragma unroll
         for (int j = 0; j < RBL_NQ; ++j)
-            if (PART_OF_JOINT[j] == PART || (PART_OF_JOINT[j] < 0 && PART == 0)) { const float dq = q[j] - gl[j]; dq2 += dq * dq; dv2 += v[j] * v[j]; }
+            if (PART_OF_JOINT[j] == PART || (PART_OF_JOINT[j] < 0 && PART == 0)) { const float dq = q[j] - img[OG + row * RBL_NQ + j]; dq2 += dq * dq; dv2 += v[j] * v[j]; }
         lds[(SP_FLAG_OFF + 3 * PART + 1) * 64 + lane] = dq2;
         lds[(SP_FLAG_OFF + 3 * PART + 2) * 64 + lane] = dv2;
     }
@@ -253,7 +282,7 @@ template <int INTEG, int HELPER>
 __device__ __forceinline__ void split_helper(float *lds, int lane, int live, float act_scale, int nsub, bool env_layer, const rbe::EnvParams *ep) {
     float *img = lds;
     const int row = sp_opaque(lane < live ? lane : live - 1);
-    constexpr int OA = 2 * RBL_NQ * 64;
+    constexpr int OA = SP_OA;
     float spu[RBL_NT], none_q[RBL_NQ], none_a[RBL_NQ];
 #pragma unroll
     for (int j = 0; j < RBL_NQ; ++j) { none_q[j] = 0.0f; none_a[j] = 0.0f; }
@@ -311,7 +340,7 @@ tree_split_step(float *__restrict__ q, float *__restrict__ qd, uint32_t *__restr
         SpImageLoad<RBL_NQ> lq, lv;
         SpImageLoad<RBL_NT> la;
         lq.issue(q, env0, live, wave, lane); lv.issue(qd, env0, live, wave, lane); la.issue(act, env0, live, wave, lane);
-        lq.land(lds, wave, lane); lv.land(lds + RBL_NQ * 64, wave, lane); la.land(lds + 2 * RBL_NQ * 64, wave, lane);
+        lq.land(lds, wave, lane); lv.land(lds + SP_OV, wave, lane); la.land(lds + SP_OA, wave, lane);
     }
     __syncthreads();
 #if defined(RB_SPLIT_STAMPS)
@@ -322,8 +351,11 @@ tree_split_step(float *__restrict__ q, float *__restrict__ qd, uint32_t *__restr
     rbl_stamp_mark();                                  // the wave's share of the step is done
 #endif
     __syncthreads();
-    sp_store_image<RBL_NQ>(q, env0, live, lds, wave, lane);
-    sp_store_image<RBL_NQ>(qd, env0, live, lds + RBL_NQ * 64, wave, lane);
+    {
+        SpImageStore<RBL_NQ> sq, sv;
+        sq.read(lds, wave, lane); sv.read(lds + SP_OV, wave, lane);
+        sq.store(q, env0, live, wave, lane); sv.store(qd, env0, live, wave, lane);
+    }
     if (wave == 0 && lane < live) {
         bool ok = true;
 #pragma unroll
@@ -352,33 +384,47 @@ tree_split_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__re
     if (env0 >= n) return;
     const int live = n - env0 < 64 ? int(n - env0) : 64;
     float *lds = lds_split;
-    constexpr int OV = RBL_NQ * 64, OA = 2 * RBL_NQ * 64, OG = (2 * RBL_NQ + RBL_NT) * 64;
-    constexpr int OO = 2 * RBL_NQ * 64;                    // the observation image takes the place of the action and goal images
+#if defined(RB_SPLIT_STAMPS)
+    rbl_stamp_mark(true);
+#endif
+    constexpr int OV = SP_OV, OA = SP_OA, OG = SP_OG, OO = SP_OO;     // (the observation image takes the place of the action image)
+    const bool mine = wave == 0 && lane < live;
+    const long me = env0 + (lane < live ? lane : live - 1);
+    uint32_t sn_old = 0u;
+    float ret_old = 0.0f;
     {
         SpImageLoad<RBL_NQ> lq, lv, lg;
         SpImageLoad<RBL_NT> la;
         lq.issue(q, env0, live, wave, lane); lv.issue(qd, env0, live, wave, lane); la.issue(act, env0, live, wave, lane);
         lg.issue(goal, env0, live, wave, lane);
+        // the accountant's counters ride on the same round trip: requested BEFORE the images are waited for (behind them they cost a
+        // second memory latency in front of the barrier below, whose fence waits for every load: 2 000 cycles by the barrier stamps)
+        if (wave == 0) { sn_old = step_num[me]; ret_old = ep_ret[me]; }
         lq.land(lds, wave, lane); lv.land(lds + OV, wave, lane); la.land(lds + OA, wave, lane); lg.land(lds + OG, wave, lane);
     }
-    // the accountant's counters, requested now (their latency passes behind the step)
-    const bool mine = wave == 0 && lane < live;
-    const long me = env0 + (lane < live ? lane : live - 1);
-    uint32_t sn_old = 0u;
-    float ret_old = 0.0f;
-    if (wave == 0) { sn_old = step_num[me]; ret_old = ep_ret[me]; }
     __syncthreads();
-    // the old goal row of the accountant's env, for the observation (the image is overwritten below)
-    float gg[RBL_NQ];
-    if (wave == 0) {
-        const int row = sp_opaque(lane < live ? lane : live - 1);
-#pragma unroll
-        for (int j = 0; j < RBL_NQ; ++j) gg[j] = lds[OG + row * RBL_NQ + j];
-    }
+#if defined(RB_SPLIT_STAMPS)
+    rbl_stamp_mark();                                  // rows in LDS
+#endif
     split_dispatch<INTEG, 0>(wave, lds, lane, live, 1.0f, h, nsub, true, &ep);
+#if defined(RB_SPLIT_STAMPS)
+    rbl_stamp_mark();                                  // the wave's share of the step is done
+#endif
     __syncthreads();
+#if defined(RB_SPLIT_STAMPS)
+    rbl_stamp_mark();                                  // every wave's is
+#endif
     if (wave == 0) {
         const int wl = sp_opaque(lane);
+        // the old goal row of the accountant's env, for the observation: read HERE, not in front of the step - a value defined under
+        // `wave == 0` before the dispatch is alive, as far as the register allocator can tell, through every other wave's code (20
+        // registers in kernels that sit at their 256)
+        float gg[RBL_NQ];
+        {
+            const int row = sp_opaque(lane < live ? lane : live - 1);
+#pragma unroll
+            for (int j = 0; j < RBL_NQ; ++j) gg[j] = lds[OG + row * RBL_NQ + j];
+        }
         bool ok = true;
         float dq2 = 0.0f, dv2 = 0.0f;
 #pragma unroll
@@ -412,7 +458,10 @@ tree_split_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__re
             if (ep.auto_reset) {                           // VecEnv worker: env.reset() (:82-87): the reset observation replaces it
                 draw_goals(draw++);
 #pragma unroll
-                for (int j = 0; j < RBL_NQ; ++j) { lds[wl * RBL_NQ + j] = 0.0f; lds[OV + wl * RBL_NQ + j] = 0.0f; gg[j] = gn[j]; }
+                for (int j = 0; j < RBL_NQ; ++j) {
+                    lds[wl * RBL_NQ + j] = 0.0f; lds[OV + wl * RBL_NQ + j] = 0.0f; gg[j] = gn[j];
+                    lds[OO + wl * (3 * RBL_NQ) + j] = 0.0f; lds[OO + wl * (3 * RBL_NQ) + RBL_NQ + j] = 0.0f;
+                }
             }
             if (mine) {
                 ep_sum[me] += double(ret); ep_sum[n + me] += double(ret) * double(ret);
@@ -424,12 +473,7 @@ tree_split_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__re
         }
         // observation row [q | qd | goal as observed] and the goal row after the step (a second image behind the rows' own)
 #pragma unroll
-        for (int j = 0; j < RBL_NQ; ++j) {
-            const float oq = lds[wl * RBL_NQ + j], ov = lds[OV + wl * RBL_NQ + j];
-            lds[OO + wl * (3 * RBL_NQ) + j] = oq;
-            lds[OO + wl * (3 * RBL_NQ) + RBL_NQ + j] = ov;
-            lds[OO + wl * (3 * RBL_NQ) + 2 * RBL_NQ + j] = gg[j];
-        }
+        for (int j = 0; j < RBL_NQ; ++j) lds[OO + wl * (3 * RBL_NQ) + 2 * RBL_NQ + j] = gg[j];      // (q and qd: the waves' own writes)
         const bool any = __builtin_amdgcn_ballot_w64(dn && mine) != 0ull;
         if (lane == 0) lds[(SP_FLAG_OFF + 3 * RBL_NPARTS) * 64] = any ? 1.0f : 0.0f;
         if (any) {
@@ -440,14 +484,29 @@ tree_split_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__re
         }
         if (mine) {
             feas[me] = fz; step_num[me] = sn; ep_ret[me] = ret; reward[me] = r; done[me] = dn ? 1u : 0u;
-            if (!ok) infeas_n[me] += 1u;
+            // (an atomic that returns nothing: a load-add-store here is a memory latency on the accountant's serial stretch - 1 500 cycles
+            // by the barrier stamps)
+            if (!ok) __hip_atomic_fetch_add(&infeas_n[me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+#if defined(RB_SPLIT_STAMPS)
+    rbl_stamp_mark();                                  // (wave 0: the accountant is done)
+#endif
     __syncthreads();
-    sp_store_image<RBL_NQ>(q, env0, live, lds, wave, lane);
-    sp_store_image<RBL_NQ>(qd, env0, live, lds + OV, wave, lane);
-    sp_store_image<3 * RBL_NQ>(obs, env0, live, lds + OO, wave, lane);
-    if (lds[(SP_FLAG_OFF + 3 * RBL_NPARTS) * 64] != 0.0f) sp_store_image<RBL_NQ>(goal, env0, live, lds + SP_WAVE_OFF * 64, wave, lane);
+#if defined(RB_SPLIT_STAMPS)
+    rbl_stamp_mark();
+#endif
+    {
+        SpImageStore<RBL_NQ> sq, sv;
+        SpImageStore<3 * RBL_NQ> so;
+        sq.read(lds, wave, lane); sv.read(lds + OV, wave, lane); so.read(lds + OO, wave, lane);
+        const bool new_goals = lds[(SP_FLAG_OFF + 3 * RBL_NPARTS) * 64] != 0.0f;
+        sq.store(q, env0, live, wave, lane); sv.store(qd, env0, live, wave, lane); so.store(obs, env0, live, wave, lane);
+        if (new_goals) sp_store_image<RBL_NQ>(goal, env0, live, lds + SP_WAVE_OFF * 64, wave, lane);
+    }
+#if defined(RB_SPLIT_STAMPS)
+    rbl_stamp_mark();                                  // stores issued
+#endif
 }
 
 }  // namespace RBL_NS

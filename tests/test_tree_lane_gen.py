@@ -147,7 +147,7 @@ def test_in_tree_generated_headers_are_current():
     fresh = os.path.join(BUILD, "tree_lane_baked_fresh.hpp")
     gen.generate(UpperBodyRobot().get_description(), fresh)
     assert open(fresh).read() == open(os.path.join(csrc, "tree_lane_baked.hpp")).read(), "run make -C gym_roboy_amd/csrc"
-    gen.generate_split(UpperBodyRobot().get_description(), fresh, max_helpers=gen.SPLIT_HELPERS, helper_share=gen.SPLIT_HELPER_SHARE, two_sweeps=gen.SPLIT_TWO_SWEEPS, cut=gen.SPLIT_CUT)
+    gen.generate_split(UpperBodyRobot().get_description(), fresh, max_helpers=gen.SPLIT_HELPERS, helper_share=gen.SPLIT_HELPER_SHARE, two_sweeps=gen.SPLIT_TWO_SWEEPS, cut=gen.SPLIT_CUT, share_trunk=gen.SPLIT_SHARE_TRUNK)
     assert open(fresh).read() == open(os.path.join(csrc, "tree_lane_split_baked.hpp")).read(), "run make -C gym_roboy_amd/csrc"
 
 

@@ -50,10 +50,11 @@ def mates(desc):
 SPLIT_HELPERS = 2      # helper waves of the library's ahead-of-time split form (csrc/roboy_sim.hip: RB_SPLIT_HELPERS)
 SPLIT_HELPER_SHARE = 70    # percent of a helped part's tendons its helper takes (RB_SPLIT_HELPER_SHARE)
 SPLIT_TWO_SWEEPS = 1       # the parts' backward pass in two sweeps around barrier T (RB_SPLIT_TWO_SWEEPS)
+SPLIT_SHARE_TRUNK = 0      # one part evaluates the trunk links' inertias / bias forces for all (RB_SPLIT_SHARE_TRUNK)
 SPLIT_CUT = 0              # the cut form instead: SPLIT_HELPERS parts as a proximal and a distal wave each (RB_SPLIT_CUT)
 
 
-def generate_split(desc, path, max_parts=4, max_helpers=0, helper_share=0, two_sweeps=0, cut=0):
+def generate_split(desc, path, max_parts=4, max_helpers=0, helper_share=0, two_sweeps=0, cut=0, share_trunk=0):
     """Write the split-form header (one function per wave) of `desc` to `path`; returns a dict of its figures.
     max_helpers: tendon-helper waves for the longest parts (generate_split in csrc/tree_lane_gen.hpp)."""
     lib = load_generator()
@@ -61,7 +62,7 @@ def generate_split(desc, path, max_parts=4, max_helpers=0, helper_share=0, two_s
     n_parts, part_lds, x_slots, max_stmt, n_stmt, h = c.c_int(0), c.c_int(0), c.c_int(0), c.c_int(0), c.c_int(0), c.c_ulonglong(0)
     n_helpers, helper_stmt = c.c_int(0), c.c_int(0)
     parts = (c.c_int * desc.n_q)()
-    rc = lib.rb_gen_tree_lane_split_h(c.byref(desc.as_c_struct()), int(max_parts), int(max_helpers) | (int(helper_share) << 8) | (int(bool(two_sweeps)) << 16) | (int(bool(cut)) << 17), path.encode(), c.byref(n_parts),
+    rc = lib.rb_gen_tree_lane_split_h(c.byref(desc.as_c_struct()), int(max_parts), int(max_helpers) | (int(helper_share) << 8) | (int(bool(two_sweeps)) << 16) | (int(bool(cut)) << 17) | (int(bool(share_trunk)) << 18), path.encode(), c.byref(n_parts),
                                       c.byref(part_lds), c.byref(x_slots), c.byref(max_stmt), c.byref(n_stmt), parts, c.byref(h),
                                       c.byref(n_helpers), c.byref(helper_stmt))
     if rc:
@@ -76,4 +77,4 @@ if __name__ == "__main__":
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gym_roboy_amd", "csrc", "tree_lane_baked.hpp")
     print("wrote", out, generate(UpperBodyRobot().get_description(), out))
     out = os.path.join(os.path.dirname(out), "tree_lane_split_baked.hpp")
-    print("wrote", out, generate_split(UpperBodyRobot().get_description(), out, max_helpers=SPLIT_HELPERS, helper_share=SPLIT_HELPER_SHARE, two_sweeps=SPLIT_TWO_SWEEPS, cut=SPLIT_CUT))
+    print("wrote", out, generate_split(UpperBodyRobot().get_description(), out, max_helpers=SPLIT_HELPERS, helper_share=SPLIT_HELPER_SHARE, two_sweeps=SPLIT_TWO_SWEEPS, cut=SPLIT_CUT, share_trunk=SPLIT_SHARE_TRUNK))
