@@ -15,7 +15,10 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2_a"
+if len(sys.argv) < 2:
+    sys.exit("usage: summarize_profile.py <raw run tag under gpurun_out/> [<directory under profiles/>]   (no default: an earlier round's "
+             "committed summaries are not to be overwritten by accident)")
+tag = sys.argv[1]
 SRC = os.path.join(ROOT, "gpurun_out", tag)
 DST = os.path.join(ROOT, "profiles", sys.argv[2] if len(sys.argv) > 2 else tag)       # (raw run directory, committed directory)
 os.makedirs(DST, exist_ok=True)
