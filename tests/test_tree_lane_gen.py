@@ -290,7 +290,7 @@ def test_upper_body_split_form_with_tendon_helpers_matches_oracle():
     assert one["n_helpers"] == 1
 
 
-TWO_SWEEPS, CUT = 1 << 16, 1 << 17          # bits of the generator entry's max_helpers word (csrc/gen_tree_lane.cpp)
+TWO_SWEEPS, CUT, SHARE_TRUNK = 1 << 16, 1 << 17, 1 << 18          # bits of the generator entry's max_helpers word (csrc/gen_tree_lane.cpp)
 
 
 def test_upper_body_split_form_with_the_backward_pass_in_two_sweeps_matches_oracle():
@@ -317,6 +317,21 @@ def test_random_robots_split_form_in_two_sweeps(seed):
     from gym_roboy_amd.envs.robots import RobotDescription
     from random_robots import random_tree_spec
     check_split(RobotDescription(random_tree_spec(seed)), "random%dt" % seed, n=6, tol=5e-4, max_helpers=2 | (100 << 8) | TWO_SWEEPS)
+
+
+def test_one_part_can_evaluate_the_trunk_links_inertias_for_all():
+    """share_trunk (measured, within the noise, not enabled in the library): the lightest part publishes the trunk links' inertias, bias
+    forces and velocity products; the others run the trunk's frames only and fetch them behind barrier X - the same values in every
+    part, so the trunk's accelerations still come out bit-identical (check_split counts mismatches)."""
+    from gym_roboy_amd.envs.robots import UpperBodyRobot, RobotDescription
+    from random_robots import random_tree_spec
+    desc = UpperBodyRobot().get_description()
+    base = check_split(desc, "upper_body_h2_s70_t", max_helpers=2 | (70 << 8) | TWO_SWEEPS)
+    shared = check_split(desc, "upper_body_h2_s70_t_st", max_helpers=2 | (70 << 8) | TWO_SWEEPS | SHARE_TRUNK)
+    assert shared["max_stmt"] < base["max_stmt"] and shared["x_slots"] > base["x_slots"]
+    check_split(desc, "upper_body_st", max_helpers=SHARE_TRUNK)                       # ... and without helpers (one barrier per acceleration)
+    for seed in (4, 9):
+        check_split(RobotDescription(random_tree_spec(seed)), "random%dst" % seed, n=6, tol=5e-4, max_helpers=2 | (70 << 8) | TWO_SWEEPS | SHARE_TRUNK)
 
 
 def test_upper_body_cut_form_matches_oracle():
