@@ -17,6 +17,12 @@ __device__ __forceinline__ float mul_then_add(float a, float b, float c) {
 __device__ __forceinline__ float goal_value(float lo, float hi, uint32_t u) {
     return mul_then_add(hi - lo, rb::u01(u), lo);
 }
+// Per-env episode statistics, touched when an episode ends: sums of returns in fp64, counts as integers, each slot by its own env's
+// lane only (so the sums are reproducible) - as atomics that RETURN NOTHING: `x[me] += v` is a load the lane has to wait for before it
+// can store, i.e. a full memory latency on the serial tail of a kernel whose waves are alone on their SIMDs (fused env step of the
+// upper body at 8 192 envs with the episodes spread out, as in training: 14.1 us per step against 12.2 in lock-step)
+__device__ __forceinline__ void stat_add(double *p, double v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void stat_add(uint32_t *p, uint32_t v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 struct GoalBox { float lo[32]; float hi[32]; };
 
 struct EnvParams {

@@ -356,13 +356,15 @@ msj_env_step_kernel(const CONST c_arg, const EnvParams e, const GoalBox box,
         // rb_env_stats reduces them (no atomics in the step kernel).  Sums of returns
         // in fp64 (a return carries the +1000 bonus, its square overflows fp32's 24 bits
         // after a few episodes), counts as integers (fp32 counters stop at 2^24)
-        ep_sum[i] += double(ret); ep_sum[n + i] += double(ret) * double(ret);
-        ep_cnt[i] += 1u; ep_cnt[n + i] += sn - 1u; ep_cnt[2 * n + i] += reached ? 1u : 0u;
+        rbe::stat_add(&ep_sum[i], double(ret)); rbe::stat_add(&ep_sum[n + i], double(ret) * double(ret));
+        rbe::stat_add(&ep_cnt[i], 1u); rbe::stat_add(&ep_cnt[n + i], sn - 1u); rbe::stat_add(&ep_cnt[2 * n + i], reached ? 1u : 0u);
         const uint64_t gid = env0 + uint64_t(i);
         uint32_t draw = goal_count[i];
-        draw_goal3(box, seed, gid, draw++, gg);          // RoboyEnv.step: _set_new_goal (:67-68)
-        if (e.auto_reset) {                              // VecEnv worker: env.reset() (:82-87)
-            draw_goal3(box, seed, gid, draw++, gg);
+        // RoboyEnv.step draws a goal (_set_new_goal, :67-68); the VecEnv worker's env.reset() (:82-87) then draws another one, which
+        // replaces it before anybody saw it: the counter advances by two, only the SECOND draw is evaluated
+        draw_goal3(box, seed, gid, draw + (e.auto_reset ? 1u : 0u), gg);
+        draw += e.auto_reset ? 2u : 1u;
+        if (e.auto_reset) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) { qq[j] = 0.0f; vv[j] = 0.0f; o[j] = 0.0f; o[3 + j] = 0.0f; o[6 + j] = gg[j]; }
             sn = 1u; fz = 1u;

@@ -843,9 +843,10 @@ tree_env_step_aba(const TreeDev tg, const rbe::EnvParams ep, const rbe::GoalBox 
                 const rb::Philox4 rnd = rb::philox_draw(seed, gid, d, rb::STREAM_GOALS, uint32_t(j >> 2));
                 return rbe::goal_value(box.lo[j], box.hi[j], rnd.v[j & 3]);
             };
-            gj[p] = draw_goal(draw);                        // RoboyEnv.step: _set_new_goal (:67-68)
-            if (ep.auto_reset) {                            // VecEnv worker: env.reset() (:82-87)
-                gj[p] = draw_goal(draw + 1u);
+            // RoboyEnv.step: _set_new_goal (:67-68); with the VecEnv worker's env.reset() (:82-87) a second draw replaces the first
+            // unseen: only that one is evaluated (the counter still advances by two)
+            gj[p] = draw_goal(draw + (ep.auto_reset ? 1u : 0u));
+            if (ep.auto_reset) {
                 qj[p] = 0.0f; vj[p] = 0.0f; oq = 0.0f; ov = 0.0f; og = gj[p];
             }
             goal[env * nq + j] = gj[p];
@@ -859,9 +860,9 @@ tree_env_step_aba(const TreeDev tg, const rbe::EnvParams ep, const rbe::GoalBox 
         float ret = ep_ret[me] + r;
         uint32_t fz = all_ok ? 1u : 0u;
         if (dn) {
-            ep_sum[me] += double(ret); ep_sum[n + me] += double(ret) * double(ret);
-            ep_cnt[me] += 1u; ep_cnt[n + me] += sn - 1u; ep_cnt[2 * n + me] += reached ? 1u : 0u;
-            goal_count[me] += ep.auto_reset ? 2u : 1u;
+            rbe::stat_add(&ep_sum[me], double(ret)); rbe::stat_add(&ep_sum[n + me], double(ret) * double(ret));
+            rbe::stat_add(&ep_cnt[me], 1u); rbe::stat_add(&ep_cnt[n + me], sn - 1u); rbe::stat_add(&ep_cnt[2 * n + me], reached ? 1u : 0u);
+            rbe::stat_add(&goal_count[me], ep.auto_reset ? 2u : 1u);
             if (ep.auto_reset) { sn = 1u; fz = 1u; }
             ret = 0.0f;
         }

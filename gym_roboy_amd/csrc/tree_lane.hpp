@@ -261,6 +261,7 @@ tree_lane_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__res
     const long me = env0 + (mine ? lane : live - 1);
     const uint32_t sn_old = step_num[me];
     const float ret_old = ep_ret[me];
+    const uint32_t draw_old = goal_count[me];       // (needed when the episode ends only - but then it would be a memory latency of its own)
 #pragma unroll
     for (int k = 0; k < RBL_NT; ++k) {
         // clamp to the action box, then slope * (x - in_high) + out_high with two roundings (roboy_env.py:157-158)
@@ -289,7 +290,7 @@ tree_lane_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__res
     for (int j = 0; j < RBL_NQ; ++j) gn[j] = o[2 * RBL_NQ + j];
     if (dn) {
         const uint64_t gid = env_id0 + uint64_t(me);
-        uint32_t draw = goal_count[me];
+        uint32_t draw = draw_old;
         auto draw_goals = [&](uint32_t dnum) {
 #pragma unroll
             for (int b = 0; 4 * b < RBL_NQ; ++b) {
@@ -299,15 +300,19 @@ tree_lane_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__res
                     if (4 * b + k < RBL_NQ) gn[4 * b + k] = rbe::goal_value(box.lo[4 * b + k], box.hi[4 * b + k], rnd.v[k]);
             }
         };
-        draw_goals(draw++);                               // RoboyEnv.step: _set_new_goal (:67-68), AFTER the observation was made (:60)
-        if (ep.auto_reset) {                              // VecEnv worker: env.reset() (:82-87): the reset observation replaces it
-            draw_goals(draw++);
+        // RoboyEnv.step: _set_new_goal (:67-68), AFTER the observation was made (:60); the VecEnv worker's env.reset() (:82-87) draws
+        // again and the reset observation replaces the step's: the first draw is never seen - the counter advances by two, only the
+        // second draw is evaluated (380 instead of 751 integer instructions in every wave that has a finished episode - and a launch
+        // waits for its slowest wave)
+        draw_goals(draw + (ep.auto_reset ? 1u : 0u));
+        draw += ep.auto_reset ? 2u : 1u;
+        if (ep.auto_reset) {
 #pragma unroll
             for (int j = 0; j < RBL_NQ; ++j) { qq[j] = 0.0f; vv[j] = 0.0f; o[j] = 0.0f; o[RBL_NQ + j] = 0.0f; o[2 * RBL_NQ + j] = gn[j]; }
         }
         if (mine) {
-            ep_sum[me] += double(ret); ep_sum[stat_stride + me] += double(ret) * double(ret);
-            ep_cnt[me] += 1u; ep_cnt[stat_stride + me] += sn - 1u; ep_cnt[2 * stat_stride + me] += reached ? 1u : 0u;
+            rbe::stat_add(&ep_sum[me], double(ret)); rbe::stat_add(&ep_sum[stat_stride + me], double(ret) * double(ret));
+            rbe::stat_add(&ep_cnt[me], 1u); rbe::stat_add(&ep_cnt[stat_stride + me], sn - 1u); rbe::stat_add(&ep_cnt[2 * stat_stride + me], reached ? 1u : 0u);
             goal_count[me] = draw;
         }
         if (ep.auto_reset) { sn = 1u; fz = 1u; }

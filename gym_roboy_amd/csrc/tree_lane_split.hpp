@@ -390,7 +390,7 @@ tree_split_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__re
     constexpr int OV = SP_OV, OA = SP_OA, OG = SP_OG, OO = SP_OO;     // (the observation image takes the place of the action image)
     const bool mine = wave == 0 && lane < live;
     const long me = env0 + (lane < live ? lane : live - 1);
-    uint32_t sn_old = 0u;
+    uint32_t sn_old = 0u, draw_old = 0u;
     float ret_old = 0.0f;
     {
         SpImageLoad<RBL_NQ> lq, lv, lg;
@@ -399,7 +399,7 @@ tree_split_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__re
         lg.issue(goal, env0, live, wave, lane);
         // the accountant's counters ride on the same round trip: requested BEFORE the images are waited for (behind them they cost a
         // second memory latency in front of the barrier below, whose fence waits for every load: 2 000 cycles by the barrier stamps)
-        if (wave == 0) { sn_old = step_num[me]; ret_old = ep_ret[me]; }
+        if (wave == 0) { sn_old = step_num[me]; ret_old = ep_ret[me]; draw_old = goal_count[me]; }
         lq.land(lds, wave, lane); lv.land(lds + OV, wave, lane); la.land(lds + OA, wave, lane); lg.land(lds + OG, wave, lane);
     }
     __syncthreads();
@@ -444,7 +444,7 @@ tree_split_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__re
         for (int j = 0; j < RBL_NQ; ++j) gn[j] = gg[j];
         if (dn) {
             const uint64_t gid = env_id0 + uint64_t(me);
-            uint32_t draw = goal_count[me];
+            uint32_t draw = draw_old;
             auto draw_goals = [&](uint32_t dnum) {
 #pragma unroll
                 for (int b = 0; 4 * b < RBL_NQ; ++b) {
@@ -454,9 +454,11 @@ tree_split_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__re
                         if (4 * b + k < RBL_NQ) gn[4 * b + k] = rbe::goal_value(box.lo[4 * b + k], box.hi[4 * b + k], rnd.v[k]);
                 }
             };
-            draw_goals(draw++);                            // RoboyEnv.step: _set_new_goal (:67-68), AFTER the observation was made (:60)
-            if (ep.auto_reset) {                           // VecEnv worker: env.reset() (:82-87): the reset observation replaces it
-                draw_goals(draw++);
+            // RoboyEnv.step: _set_new_goal (:67-68), AFTER the observation was made (:60); with the VecEnv worker's env.reset() (:82-87)
+            // a second draw replaces the first unseen: only that one is evaluated (the counter still advances by two)
+            draw_goals(draw + (ep.auto_reset ? 1u : 0u));
+            draw += ep.auto_reset ? 2u : 1u;
+            if (ep.auto_reset) {
 #pragma unroll
                 for (int j = 0; j < RBL_NQ; ++j) {
                     lds[wl * RBL_NQ + j] = 0.0f; lds[OV + wl * RBL_NQ + j] = 0.0f; gg[j] = gn[j];
@@ -464,8 +466,8 @@ tree_split_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__re
                 }
             }
             if (mine) {
-                ep_sum[me] += double(ret); ep_sum[n + me] += double(ret) * double(ret);
-                ep_cnt[me] += 1u; ep_cnt[n + me] += sn - 1u; ep_cnt[2 * n + me] += reached ? 1u : 0u;
+                rbe::stat_add(&ep_sum[me], double(ret)); rbe::stat_add(&ep_sum[n + me], double(ret) * double(ret));
+                rbe::stat_add(&ep_cnt[me], 1u); rbe::stat_add(&ep_cnt[n + me], sn - 1u); rbe::stat_add(&ep_cnt[2 * n + me], reached ? 1u : 0u);
                 goal_count[me] = draw;
             }
             if (ep.auto_reset) { sn = 1u; fz = 1u; }

@@ -7,10 +7,20 @@ from gym_roboy_amd.envs.vec_env import RoboyVecEnv
 ROBOT = UpperBodyRobot() if os.environ.get("VECENV_ROBOT", "msj") == "upper" else MsjRobot()
 INTEG = os.environ.get("VECENV_INTEGRATOR", "euler")
 SIZES = [int(x) for x in os.environ.get("VECENV_SIZES", "4096,65536,262144,2097152").split(",")]
+# VECENV_DESYNC=1: the envs' episode counters start uniformly spread over an episode, as they are in training once goals have been
+# reached here and there - every step then ends one episode in 400 (a launch waits for the waves that redraw a goal); default: all
+# episodes in lock-step (they end together every 400 steps)
+DESYNC = os.environ.get("VECENV_DESYNC", "0") == "1"
 for n in SIZES:
     with torch.cuda.stream(torch.cuda.Stream()):
         env = RoboyVecEnv(ROBOT, n, integrator=INTEG)
         st = torch.cuda.current_stream(); env.sim.set_stream(st.cuda_stream)
+        if DESYNC:
+            import numpy as np
+            rng = np.random.default_rng(3)
+            lo, hi = ROBOT.get_joint_angles_space().low, ROBOT.get_joint_angles_space().high
+            env.reset()
+            env.set_goal(rng.uniform(lo, hi, (n, env.n_q)).astype(np.float32), rng.integers(1, 401, n).astype(np.uint32))
         acts = [torch.rand((n, env.n_t), device="cuda") * 2 - 1 for _ in range(4)]
         obs = torch.empty((n, 3 * env.n_q), device="cuda"); rew = torch.empty(n, device="cuda"); done = torch.empty(n, dtype=torch.int32, device="cuda")
         steps = 2000 if n <= 65536 else 300
@@ -20,5 +30,5 @@ for n in SIZES:
         for t in range(steps): env.step_dev(acts[t % 4].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
         e1.record(st); torch.cuda.synchronize(); wall = time.perf_counter() - t0
         us = e0.elapsed_time(e1) * 1e3 / steps
-        print(INTEG, "fused env step n=%d: %.2f us/step (events), %.3e env-steps/s wall, %.1f GB/s algorithmic" % (n, us, n * steps / wall, n * (4 * (4 * env.n_q + env.n_t + 1) + 4 * (4 * env.n_q + 6)) / us / 1e3))
+        print(INTEG, "desync" if DESYNC else "lockstep", "fused env step n=%d: %.2f us/step (events), %.3e env-steps/s wall, %.1f GB/s algorithmic" % (n, us, n * steps / wall, n * (4 * (4 * env.n_q + env.n_t + 1) + 4 * (4 * env.n_q + 6)) / us / 1e3))
         env.close()
