@@ -522,7 +522,9 @@ bool build_split_kernel(rb_sim *s, int kind = 0) {
     if (k.state != 0) return k.state == 1;
     if (capturing(s)) return false;                      // try again outside the capture
     if (hipSetDevice(s->device) != hipSuccess) { k.state = -1; k.why = "hipSetDevice failed"; return false; }
-    const std::string src = "#include \"tree_lane_defs.hpp\"\n#define RBL_NS rbl_jit_split\n" + s->split_gen.text + "#include \"tree_lane_split.hpp\"\n";
+    // (the static_assert: the host's LDS formula - split_lds_bytes, what the launch asks for - must be the kernels' layout)
+    const std::string src = "#include \"tree_lane_defs.hpp\"\n#define RBL_NS rbl_jit_split\n" + s->split_gen.text + "#include \"tree_lane_split.hpp\"\n" +
+                            "static_assert(rbl_jit_split::SP_LDS_BYTES == " + std::to_string(split_lds_bytes(s->split_gen)) + ", \"host and kernel LDS layouts differ\");\n";
     const std::string name = std::string(kind == 0 ? "rbl_jit_split::tree_split_step<" : "rbl_jit_split::tree_split_env_step<") + (s->integrator == RB_EULER ? "0>" : "1>");
     const char *names[1] = {name.c_str()};
     hipFunction_t *slots[1] = {&k.fn};
@@ -889,8 +891,9 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
                           split_lds_bytes(s->split_gen) <= 160 * 1024;
             if (!s->split_ok && RB_SPLIT_HELPERS > 0)        // (the exchange area of the helper form does not fit: the three-barrier-less form)
                 s->split_ok = rblg::generate_split(robot, 4, s->split_gen, why_gen, 0) == RB_OK;
+            // (... and the host's LDS formula is the kernels': a launch with less LDS than tree_lane_split.hpp lays out would write past it)
             s->split_baked = s->split_ok && s->split_gen.hash == RBL_SPLIT_TEXT_HASH && s->split_gen.n_parts == RBL_NPARTS &&
-                             s->split_gen.n_helpers == RBL_NHELPERS;
+                             s->split_gen.n_helpers == RBL_NHELPERS && split_lds_bytes(s->split_gen) == size_t(rbl_split_baked::SP_LDS_BYTES);
         }
         else why = "not a ball-joint robot (" + why + ") and not a supported joint tree (" + why_tree + ")";
     }
