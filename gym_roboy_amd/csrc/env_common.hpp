@@ -34,6 +34,48 @@ struct EnvParams {
     float a_scale, v_scale;          // 2 / (hi - lo) of the angle / velocity box
 };
 
+// The env-step kernels of the joint-tree forms take ONE kernel argument, this struct: what the accounting behind the step needs -
+// eleven pointers, the goal box (64 values), the env parameters, seed and env id - is then read from the kernel-argument segment
+// THERE, through a pointer the compiler cannot trace back across the step (late_args).  As 21 separate arguments everything was
+// loaded at the kernel's entry and kept alive across the step: 212 / 226 scalar registers of the split kernel (43 / 71 of the
+// one-wave kernel) went into vector-register lanes and back, in every wave, ~430 vector-instruction slots of a wave that gets one
+// per 5.5 cycles.
+struct TreeEnvArgs {
+    EnvParams ep;
+    GoalBox box;
+    float *q, *qd;
+    uint32_t *feas;
+    float *goal;
+    uint32_t *step_num;
+    float *ep_ret;
+    uint32_t *goal_count;
+    const float *act;
+    float *obs, *reward;
+    uint32_t *done;
+    double *ep_sum;
+    uint32_t *ep_cnt, *infeas_n;
+    float h;
+    int nsub;
+    long n;                          // the envs of this launch
+    uint64_t seed, env_id0;
+    long stat_stride;                // the batch's env count: stride of the statistics planes ep_sum[2][.], ep_cnt[3][.]
+};
+typedef const __attribute__((address_space(4))) TreeEnvArgs *tree_env_kernarg_ptr;
+__device__ __forceinline__ tree_env_kernarg_ptr late_args() {
+    tree_env_kernarg_ptr p = (tree_env_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));                      // (loads through p stay behind this point)
+    return p;
+}
+__device__ __forceinline__ EnvParams late_env_params(tree_env_kernarg_ptr p) {      // (field by field: the source lives in the constant address space)
+    EnvParams ep;
+    ep.vel_penalty = p->ep.vel_penalty; ep.bonus = p->ep.bonus; ep.max_len = p->ep.max_len; ep.auto_reset = p->ep.auto_reset;
+    ep.penalty = p->ep.penalty; ep.bonus_val = p->ep.bonus_val;
+    ep.a_lo = p->ep.a_lo; ep.a_hi = p->ep.a_hi; ep.v_lo = p->ep.v_lo; ep.v_hi = p->ep.v_hi;
+    ep.act_hi = p->ep.act_hi; ep.slope = p->ep.slope; ep.tol_a2 = p->ep.tol_a2; ep.tol_v2 = p->ep.tol_v2;
+    ep.a_scale = p->ep.a_scale; ep.v_scale = p->ep.v_scale;
+    return ep;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

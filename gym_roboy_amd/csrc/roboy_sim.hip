@@ -126,16 +126,18 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #endif
 // ... and the share (percent, proximal first) of a helped part's tendons its helper takes (SPLIT_HELPER_SHARE there)
 #ifndef RB_SPLIT_HELPER_SHARE
-#define RB_SPLIT_HELPER_SHARE 70
+#define RB_SPLIT_HELPER_SHARE 80
 #endif
 // ... and whether the parts run their backward pass in two sweeps around barrier T (SPLIT_TWO_SWEEPS there): everything but the tendon
 // wrenches' part before it, beside the helpers (upper body, 8 192 envs: 9.15 -> 8.84 us Euler, 26.5 -> 25.1 us RK4 at a share of 70 %)
 #ifndef RB_SPLIT_TWO_SWEEPS
 #define RB_SPLIT_TWO_SWEEPS 1
 #endif
-// ... and whether ONE part evaluates the trunk links' inertias / bias forces for all (SPLIT_SHARE_TRUNK there)
+// ... and whether ONE part evaluates the trunk links' inertias / bias forces for all (SPLIT_SHARE_TRUNK there): upper body, 8 192 envs,
+// share 55 ... 90 % with and without (profiles/r4_a/share_sweep_fine.log, two passes, +-0.05 us): 70 % 8.76 / 24.91 us Euler / RK4,
+// 70 % + trunk 8.62 / 24.52, 75 % + trunk 8.62 / 24.50, 80 % 8.71 / 24.37, 80 % + trunk 8.74 / 24.25, 85 % and more 9.2 / 25.6
 #ifndef RB_SPLIT_SHARE_TRUNK
-#define RB_SPLIT_SHARE_TRUNK 0
+#define RB_SPLIT_SHARE_TRUNK 1
 #endif
 // ... or the CUT form instead (generate_split_cut: the RB_SPLIT_HELPERS heaviest parts as a proximal and a distal wave each;
 // RB_SPLIT_HELPER_SHARE is then the distal waves' share of the tendons).  SPLIT_CUT there.  Measured and NOT selected: 22 % fewer
@@ -1489,23 +1491,16 @@ static int env_step_launch(rb_sim *s, long i0, long cnt, hipStream_t stream, con
         const float h = s->tree_host.dev.h;
         const int nsub = s->tree_host.dev.nsub;
         const unsigned threads = 64u * unsigned(s->split_gen.n_parts + s->split_gen.n_helpers);
-#define RB_SPLIT_ENV_ARGS s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, s->d_ep_ret, s->d_goal_count, d_act, \
-                          d_obs, d_reward, d_done, s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, h, nsub, n, s->seed, uint64_t(s->env0)
+        // (one struct argument: the kernel reads most of it behind the step - env_common.hpp, TreeEnvArgs)
+        rbe::TreeEnvArgs ka{s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, s->d_ep_ret, s->d_goal_count, d_act,
+                            d_obs, d_reward, d_done, s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, h, nsub, n, s->seed, uint64_t(s->env0), n};
         if (s->split_baked) {
-            if (s->integrator == RB_EULER) hipLaunchKernelGGL(rbl_split_baked::tree_split_env_step<0>, dim3(groups), dim3(threads), lds, stream, RB_SPLIT_ENV_ARGS);
-            else hipLaunchKernelGGL(rbl_split_baked::tree_split_env_step<1>, dim3(groups), dim3(threads), lds, stream, RB_SPLIT_ENV_ARGS);
+            if (s->integrator == RB_EULER) hipLaunchKernelGGL(rbl_split_baked::tree_split_env_step<0>, dim3(groups), dim3(threads), lds, stream, ka);
+            else hipLaunchKernelGGL(rbl_split_baked::tree_split_env_step<1>, dim3(groups), dim3(threads), lds, stream, ka);
         } else {
-            EnvParams ep = s->env;
-            GoalBox box = s->box;
-            float hh = h;
-            int ns = nsub;
-            long nn = n;
-            uint64_t seed = s->seed, env0 = uint64_t(s->env0);
-            void *args[] = {&ep, &box, &s->d_q, &s->d_qd, &s->d_feas, &s->d_goal, &s->d_step_num, &s->d_ep_ret, &s->d_goal_count, &d_act,
-                            &d_obs, &d_reward, &d_done, &s->d_ep_sum, &s->d_ep_cnt, &s->d_infeas_n, &hh, &ns, &nn, &seed, &env0};
+            void *args[] = {&ka};
             RB_HIP(hipModuleLaunchKernel(s->split_env_k.fn, groups, 1, 1, threads, 1, 1, unsigned(lds), stream, args, nullptr));
         }
-#undef RB_SPLIT_ENV_ARGS
         RB_HIP(hipGetLastError());
         return RB_OK;
     }
@@ -1522,22 +1517,15 @@ static int env_step_launch(rb_sim *s, long i0, long cnt, hipStream_t stream, con
         const float *tact = d_act + i0 * nt;
         double *tsum = s->d_ep_sum + i0;
         const uint64_t e0 = uint64_t(s->env0) + uint64_t(i0);
-#define RB_LANE_ENV_ARGS s->env, s->box, tq, tqd, tfeas, tgoal, tsn, tret, tgc, tact, tobs, trew, tdone, tsum, tcnt, tinf, h, nsub, cnt, s->seed, e0, n
+        // (one struct argument: the kernel reads most of it behind the step - env_common.hpp, TreeEnvArgs)
+        rbe::TreeEnvArgs ka{s->env, s->box, tq, tqd, tfeas, tgoal, tsn, tret, tgc, tact, tobs, trew, tdone, tsum, tcnt, tinf, h, nsub, cnt, s->seed, e0, n};
         if (s->lane_baked) {
-            if (s->integrator == RB_EULER) hipLaunchKernelGGL(rbl_baked::tree_lane_env_step<0>, dim3(waves), dim3(64), lds, stream, RB_LANE_ENV_ARGS);
-            else hipLaunchKernelGGL(rbl_baked::tree_lane_env_step<1>, dim3(waves), dim3(64), lds, stream, RB_LANE_ENV_ARGS);
+            if (s->integrator == RB_EULER) hipLaunchKernelGGL(rbl_baked::tree_lane_env_step<0>, dim3(waves), dim3(64), lds, stream, ka);
+            else hipLaunchKernelGGL(rbl_baked::tree_lane_env_step<1>, dim3(waves), dim3(64), lds, stream, ka);
         } else {
-            EnvParams ep = s->env;
-            GoalBox box = s->box;
-            float hh = h;
-            int ns = nsub;
-            long nn = cnt, stride = n;
-            uint64_t seed = s->seed, env0 = e0;
-            void *args[] = {&ep, &box, &tq, &tqd, &tfeas, &tgoal, &tsn, &tret, &tgc, &tact,
-                            &tobs, &trew, &tdone, &tsum, &tcnt, &tinf, &hh, &ns, &nn, &seed, &env0, &stride};
+            void *args[] = {&ka};
             RB_HIP(hipModuleLaunchKernel(s->lane_env_k.fn, waves, 1, 1, 64, 1, 1, unsigned(lds), stream, args, nullptr));
         }
-#undef RB_LANE_ENV_ARGS
         RB_HIP(hipGetLastError());
         return RB_OK;
     }

@@ -239,14 +239,16 @@ tree_lane_step(float *__restrict__ q, float *__restrict__ qd, uint32_t *__restri
 // RoboyEnv.step fused around the step (semantics of tree_env_step_aba / msj_env_step_kernel)
 template <int INTEG>
 __global__ void __launch_bounds__(64)
-tree_lane_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__restrict__ q, float *__restrict__ qd,
-                   uint32_t *__restrict__ feas, float *__restrict__ goal, uint32_t *__restrict__ step_num,
-                   float *__restrict__ ep_ret, uint32_t *__restrict__ goal_count, const float *__restrict__ act,
-                   float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
-                   double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt, uint32_t *__restrict__ infeas_n,
-                   float h, int nsub, long n, uint64_t seed, uint64_t env_id0, long stat_stride) {
-    // n: the envs of this launch (the whole batch, or a sub-range on shifted pointers: rb_env_step_range_dev); stat_stride: the
-    // batch's env count = the stride of the per-env statistics planes ep_sum[2][.], ep_cnt[3][.]
+tree_lane_env_step(const rbe::TreeEnvArgs a) {
+    // a.n: the envs of this launch (the whole batch, or a sub-range on shifted pointers: rb_env_step_range_dev); a.stat_stride: the
+    // batch's env count = the stride of the per-env statistics planes ep_sum[2][.], ep_cnt[3][.].  The front of the kernel takes what
+    // it needs by name; the accounting behind the step reads its arguments through `late` (env_common.hpp: TreeEnvArgs)
+    const float *__restrict__ q = a.q, *__restrict__ qd = a.qd, *__restrict__ act = a.act, *__restrict__ goal = a.goal;
+    const uint32_t *__restrict__ step_num = a.step_num, *__restrict__ goal_count = a.goal_count;
+    const float *__restrict__ ep_ret = a.ep_ret;
+    const float h = a.h, slope = a.ep.slope, act_hi = a.ep.act_hi;
+    const int nsub = a.nsub;
+    const long n = a.n;
     extern __shared__ float lds_lane[];
     const int lane = threadIdx.x;
     const long env0 = long(blockIdx.x) * 64;      // a workgroup is ONE wave: everything derived from the block index is scalar
@@ -266,9 +268,13 @@ tree_lane_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__res
     for (int k = 0; k < RBL_NT; ++k) {
         // clamp to the action box, then slope * (x - in_high) + out_high with two roundings (roboy_env.py:157-158)
         const float x = fminf(fmaxf(spu[k], -1.0f), 1.0f);
-        spu[k] = rbe::mul_then_add(ep.slope, x - 1.0f, ep.act_hi) * KSG[k];
+        spu[k] = rbe::mul_then_add(slope, x - 1.0f, act_hi) * KSG[k];
     }
     const bool ok = lane_step<INTEG>(L, spu, h, nsub, qq, vv);
+    const rbe::tree_env_kernarg_ptr late = rbe::late_args();
+    const rbe::EnvParams ep = rbe::late_env_params(late);
+    const uint64_t seed = late->seed, env_id0 = late->env_id0;
+    const long stat_stride = late->stat_stride;
     // observation [q | qd | goal], reward, done; goal redraw (and reset) on done
     float o[3 * RBL_NQ];
 #pragma unroll
@@ -297,7 +303,7 @@ tree_lane_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__res
                 const rb::Philox4 rnd = rb::philox_draw(seed, gid, dnum, rb::STREAM_GOALS, uint32_t(b));
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (4 * b + k < RBL_NQ) gn[4 * b + k] = rbe::goal_value(box.lo[4 * b + k], box.hi[4 * b + k], rnd.v[k]);
+                    if (4 * b + k < RBL_NQ) gn[4 * b + k] = rbe::goal_value(late->box.lo[4 * b + k], late->box.hi[4 * b + k], rnd.v[k]);
             }
         };
         // RoboyEnv.step: _set_new_goal (:67-68), AFTER the observation was made (:60); the VecEnv worker's env.reset() (:82-87) draws
@@ -311,20 +317,22 @@ tree_lane_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__res
             for (int j = 0; j < RBL_NQ; ++j) { qq[j] = 0.0f; vv[j] = 0.0f; o[j] = 0.0f; o[RBL_NQ + j] = 0.0f; o[2 * RBL_NQ + j] = gn[j]; }
         }
         if (mine) {
+            double *ep_sum = late->ep_sum;
+            uint32_t *ep_cnt = late->ep_cnt;
             rbe::stat_add(&ep_sum[me], double(ret)); rbe::stat_add(&ep_sum[stat_stride + me], double(ret) * double(ret));
             rbe::stat_add(&ep_cnt[me], 1u); rbe::stat_add(&ep_cnt[stat_stride + me], sn - 1u); rbe::stat_add(&ep_cnt[2 * stat_stride + me], reached ? 1u : 0u);
-            goal_count[me] = draw;
+            late->goal_count[me] = draw;
         }
         if (ep.auto_reset) { sn = 1u; fz = 1u; }
         ret = 0.0f;
     }
     // rows back: state, goal (only the lanes that redrew change it), observation
-    store_outputs<true>(q, qd, obs, env0, live, region, lane, qq, vv, o);
-    if (__builtin_amdgcn_ballot_w64(dn && mine) != 0ull) store_rows<RBL_NQ>(goal, env0, live, region, lane, gn);
+    store_outputs<true>(late->q, late->qd, late->obs, env0, live, region, lane, qq, vv, o);
+    if (__builtin_amdgcn_ballot_w64(dn && mine) != 0ull) store_rows<RBL_NQ>(late->goal, env0, live, region, lane, gn);
     if (mine) {
-        feas[me] = fz; step_num[me] = sn; ep_ret[me] = ret; reward[me] = r; done[me] = dn ? 1u : 0u;
+        late->feas[me] = fz; late->step_num[me] = sn; late->ep_ret[me] = ret; late->reward[me] = r; late->done[me] = dn ? 1u : 0u;
         // (an atomic that returns nothing: a load-add-store here is a memory latency the wave - alone on its SIMD - sits out)
-        if (!ok) __hip_atomic_fetch_add(&infeas_n[me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ok) __hip_atomic_fetch_add(&late->infeas_n[me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

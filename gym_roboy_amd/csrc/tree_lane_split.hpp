@@ -370,14 +370,19 @@ tree_split_step(float *__restrict__ q, float *__restrict__ qd, uint32_t *__restr
 // RoboyEnv.step fused around the split step (semantics of tree_lane_env_step / msj_env_step_kernel).  The waves
 // step their joints; wave 0 then is the envs' accountant (one env per lane): reward and done from the waves' partial sums,
 // goal redraw (and reset) on done, the observation rows; all waves write the row images back together.
+// (one kernel argument, rbe::TreeEnvArgs: what the accountant needs is read from the kernel-argument segment behind the step)
 template <int INTEG>
 __global__ void __launch_bounds__(64 * SP_NWAVES)
-tree_split_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__restrict__ q, float *__restrict__ qd,
-                    uint32_t *__restrict__ feas, float *__restrict__ goal, uint32_t *__restrict__ step_num,
-                    float *__restrict__ ep_ret, uint32_t *__restrict__ goal_count, const float *__restrict__ act,
-                    float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
-                    double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt, uint32_t *__restrict__ infeas_n,
-                    float h, int nsub, long n, uint64_t seed, uint64_t env_id0) {
+tree_split_env_step(const rbe::TreeEnvArgs a) {
+    // what the front of the kernel needs, by name (the rest: `late`, below)
+    const float *__restrict__ q = a.q, *__restrict__ qd = a.qd, *__restrict__ act = a.act, *__restrict__ goal = a.goal;
+    const uint32_t *__restrict__ step_num = a.step_num, *__restrict__ goal_count = a.goal_count;
+    const float *__restrict__ ep_ret = a.ep_ret;
+    const float h = a.h;
+    const int nsub = a.nsub;
+    const long n = a.n;
+    rbe::EnvParams ep_front;                         // the action transform's two constants
+    ep_front.slope = a.ep.slope; ep_front.act_hi = a.ep.act_hi;
     extern __shared__ float lds_split[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long env0 = long(blockIdx.x) * 64;
@@ -406,7 +411,7 @@ tree_split_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__re
 #if defined(RB_SPLIT_STAMPS)
     rbl_stamp_mark();                                  // rows in LDS
 #endif
-    split_dispatch<INTEG, 0>(wave, lds, lane, live, 1.0f, h, nsub, true, &ep);
+    split_dispatch<INTEG, 0>(wave, lds, lane, live, 1.0f, h, nsub, true, &ep_front);
 #if defined(RB_SPLIT_STAMPS)
     rbl_stamp_mark();                                  // the wave's share of the step is done
 #endif
@@ -414,8 +419,16 @@ tree_split_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__re
 #if defined(RB_SPLIT_STAMPS)
     rbl_stamp_mark();                                  // every wave's is
 #endif
+    const rbe::tree_env_kernarg_ptr late = rbe::late_args();
     if (wave == 0) {
         const int wl = sp_opaque(lane);
+        const rbe::EnvParams ep = rbe::late_env_params(late);
+        const uint64_t seed = late->seed, env_id0 = late->env_id0;
+        double *__restrict__ ep_sum = late->ep_sum;
+        uint32_t *__restrict__ ep_cnt = late->ep_cnt, *__restrict__ infeas_n = late->infeas_n, *__restrict__ feas = late->feas;
+        uint32_t *__restrict__ step_num = late->step_num, *__restrict__ goal_count = late->goal_count, *__restrict__ done = late->done;
+        float *__restrict__ ep_ret = late->ep_ret, *__restrict__ reward = late->reward;
+        const long n = late->n;
         // the old goal row of the accountant's env, for the observation: read HERE, not in front of the step - a value defined under
         // `wave == 0` before the dispatch is alive, as far as the register allocator can tell, through every other wave's code (20
         // registers in kernels that sit at their 256)
@@ -451,7 +464,7 @@ tree_split_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__re
                     const rb::Philox4 rnd = rb::philox_draw(seed, gid, dnum, rb::STREAM_GOALS, uint32_t(b));
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (4 * b + k < RBL_NQ) gn[4 * b + k] = rbe::goal_value(box.lo[4 * b + k], box.hi[4 * b + k], rnd.v[k]);
+                        if (4 * b + k < RBL_NQ) gn[4 * b + k] = rbe::goal_value(late->box.lo[4 * b + k], late->box.hi[4 * b + k], rnd.v[k]);
                 }
             };
             // RoboyEnv.step: _set_new_goal (:67-68), AFTER the observation was made (:60); with the VecEnv worker's env.reset() (:82-87)
@@ -503,8 +516,8 @@ tree_split_env_step(const rbe::EnvParams ep, const rbe::GoalBox box, float *__re
         SpImageStore<3 * RBL_NQ> so;
         sq.read(lds, wave, lane); sv.read(lds + OV, wave, lane); so.read(lds + OO, wave, lane);
         const bool new_goals = lds[(SP_FLAG_OFF + 3 * RBL_NPARTS) * 64] != 0.0f;
-        sq.store(q, env0, live, wave, lane); sv.store(qd, env0, live, wave, lane); so.store(obs, env0, live, wave, lane);
-        if (new_goals) sp_store_image<RBL_NQ>(goal, env0, live, lds + SP_WAVE_OFF * 64, wave, lane);
+        sq.store(late->q, env0, live, wave, lane); sv.store(late->qd, env0, live, wave, lane); so.store(late->obs, env0, live, wave, lane);
+        if (new_goals) sp_store_image<RBL_NQ>(late->goal, env0, live, lds + SP_WAVE_OFF * 64, wave, lane);
     }
 #if defined(RB_SPLIT_STAMPS)
     rbl_stamp_mark();                                  // stores issued

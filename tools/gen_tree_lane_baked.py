@@ -48,9 +48,9 @@ def mates(desc):
 
 
 SPLIT_HELPERS = 2      # helper waves of the library's ahead-of-time split form (csrc/roboy_sim.hip: RB_SPLIT_HELPERS)
-SPLIT_HELPER_SHARE = 70    # percent of a helped part's tendons its helper takes (RB_SPLIT_HELPER_SHARE)
+SPLIT_HELPER_SHARE = 80    # percent of a helped part's tendons its helper takes (RB_SPLIT_HELPER_SHARE)
 SPLIT_TWO_SWEEPS = 1       # the parts' backward pass in two sweeps around barrier T (RB_SPLIT_TWO_SWEEPS)
-SPLIT_SHARE_TRUNK = 0      # one part evaluates the trunk links' inertias / bias forces for all (RB_SPLIT_SHARE_TRUNK)
+SPLIT_SHARE_TRUNK = 1      # one part evaluates the trunk links' inertias / bias forces for all (RB_SPLIT_SHARE_TRUNK)
 SPLIT_CUT = 0              # the cut form instead: SPLIT_HELPERS parts as a proximal and a distal wave each (RB_SPLIT_CUT)
 
 
