@@ -1,0 +1,43 @@
+"""The source generator (csrc/tree_lane_gen.hpp) under AddressSanitizer + UBSan on the CPU: every form - one function, split, split with
+tendon helpers / two sweeps / shared trunk, cut - for the committed upper body, random trees and the nine-link star.  (GPU sanitizers are
+not available on the pool; the generator is host code and runs in the library at rb_create.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "tests", "_build")
+
+DRIVER = r'''
+import ctypes, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+from gym_roboy_amd.envs.robots import UpperBodyRobot, RobotDescription
+from random_robots import random_tree_spec
+lib = ctypes.CDLL(%(so)r)
+descs = [("upper", UpperBodyRobot().get_description())]
+descs += [("random%%d" %% s, RobotDescription(random_tree_spec(s))) for s in (3, 4, 9, 10)]
+descs.append(("star", RobotDescription(random_tree_spec(77, n_q=9, n_t=8, shape="star"))))
+for name, d in descs:
+    print(name, lib.gen_all_forms(ctypes.byref(d.as_c_struct())))
+'''
+
+
+def test_generator_is_clean_under_asan_and_ubsan():
+    asan = subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan not installed")
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "libgen_sanitize.so")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-I", os.path.join(ROOT, "gym_roboy_amd", "csrc"), "-I", os.path.join(ROOT, "include"), "-o", so,
+                           os.path.join(ROOT, "tests", "hostmath", "gen_sanitize.cpp")])
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    out = subprocess.run([sys.executable, "-c", DRIVER % {"root": ROOT, "tests": os.path.join(ROOT, "tests"), "so": so}],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    counts = dict(line.split() for line in out.stdout.strip().splitlines())
+    assert int(counts["upper"]) == 2 + 48 + 9 + 5              # every form exists for the upper body
+    assert int(counts["star"]) == 2 + 48 + 9 + 5
+    assert int(counts["random3"]) == 2                          # a serial chain: only the one-function forms
