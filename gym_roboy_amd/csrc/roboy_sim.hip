@@ -516,7 +516,8 @@ bool tree_wants_split(const rb_sim *s) {
 }
 size_t split_lds_bytes(const rblg::SplitGenerated &g) {      // the formula of tree_lane_split.hpp: SP_LDS_BYTES
     const int img = 3 * g.n_q + (3 * g.n_q > g.n_t ? 3 * g.n_q : g.n_t);
-    return size_t(img + g.x_buffers * g.x_slots + g.n_parts * (g.part_lds + (g.acc_slots ? g.acc_slots : 2 * g.n_q)) + 3 * g.n_parts + 1) * 64 * 4;
+    return size_t(img + g.x_buffers * g.x_slots + g.n_parts * (g.part_lds + (g.acc_slots ? g.acc_slots : 2 * g.n_q)) + 3 * g.n_parts + 1 +
+                  (g.n_helpers > 0 ? g.n_q : 0)) * 64 * 4;
 }
 // the hiprtc-built split kernels of a robot without ahead-of-time instances (explicit choice only); kind: 0 = step, 1 = env step
 bool build_split_kernel(rb_sim *s, int kind = 0) {

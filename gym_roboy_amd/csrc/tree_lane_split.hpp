@@ -66,7 +66,12 @@ constexpr int SP_X_BUFFERS = RBL_X_SINGLE ? 1 : 2;
 constexpr int SP_X_OFF = SP_IMG_SLOTS;
 constexpr int SP_WAVE_OFF = SP_X_OFF + SP_X_BUFFERS * RBL_X_SLOTS;
 constexpr int SP_FLAG_OFF = SP_WAVE_OFF + RBL_NPARTS * SP_WAVE_SLOTS;
-constexpr int SP_LDS_SLOTS = SP_FLAG_OFF + 3 * RBL_NPARTS + 1;    // per part: limit flag, and (env layer) its joints' shares of |dq|^2, |qd|^2; then the "a goal changed" word
+constexpr int SP_DRAW_OFF = SP_FLAG_OFF + 3 * RBL_NPARTS + 1;     // per part: limit flag, and (env layer) its joints' shares of |dq|^2, |qd|^2; then the "a goal changed" word
+// ... then (helper form, env layer) the goals the helpers draw ahead for every env of the group, one slot per joint: a helper is idle
+// from its last hand-over to the end of the step, the accountant's Philox draw - 450 instructions whenever ONE of its 64 envs ends an
+// episode, which with the episodes spread out as in training happens in some workgroup of every launch - is not
+constexpr int SP_DRAW_SLOTS = RBL_NHELPERS > 0 ? RBL_NQ : 0;
+constexpr int SP_LDS_SLOTS = SP_DRAW_OFF + SP_DRAW_SLOTS;
 constexpr int SP_LDS_BYTES = SP_LDS_SLOTS * 64 * 4;
 
 __device__ __forceinline__ int sp_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
@@ -302,11 +307,30 @@ __device__ __forceinline__ void split_helper(float *lds, int lane, int live, flo
     const SplitLds L{lds + lane};                       // (unused: a helper parks nothing)
     const SplitLds X{lds + SP_X_OFF * 64 + lane};
     const int n_acc = nsub * (INTEG == 0 ? 1 : 4);
+    // env layer: the goal counters of the group's envs, requested now (used behind the step)
+    const long env0 = long(blockIdx.x) * 64;
+    uint32_t draw_old = 0u;
+    if (env_layer) draw_old = rbe::late_args()->goal_count[env0 + row];
 #pragma unroll 1
     for (int a = 0; a < n_acc; ++a) {
         sp_fence_code();
         rbl_part(RBL_NPARTS + HELPER, none_q, none_q, spu, none_a, L, X);
         sp_fence_code();
+    }
+    if (env_layer) {
+        // the goals every env of the group WOULD draw if its episode ended with this step (the observable draw: the second one under
+        // auto_reset - see the accountant), left in LDS for the accountant; same Philox counters, same arithmetic: same values.  The
+        // helpers share the Philox blocks (four goals each) between them: each is done before the arms are
+        const rbe::tree_env_kernarg_ptr late = rbe::late_args();
+        const uint64_t gid = late->env_id0 + uint64_t(env0 + row), seed = late->seed;
+        const uint32_t dnum = draw_old + (late->ep.auto_reset ? 1u : 0u);
+#pragma unroll
+        for (int b = HELPER; 4 * b < RBL_NQ; b += RBL_NHELPERS) {
+            const rb::Philox4 rnd = rb::philox_draw(seed, gid, dnum, rb::STREAM_GOALS, uint32_t(b));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (4 * b + k < RBL_NQ) lds[(SP_DRAW_OFF + 4 * b + k) * 64 + lane] = rbe::goal_value(late->box.lo[4 * b + k], late->box.hi[4 * b + k], rnd.v[k]);
+        }
     }
 }
 
@@ -469,7 +493,12 @@ tree_split_env_step(const rbe::TreeEnvArgs a) {
             };
             // RoboyEnv.step: _set_new_goal (:67-68), AFTER the observation was made (:60); with the VecEnv worker's env.reset() (:82-87)
             // a second draw replaces the first unseen: only that one is evaluated (the counter still advances by two)
-            draw_goals(draw + (ep.auto_reset ? 1u : 0u));
+            if (SP_DRAW_SLOTS > 0) {                       // the helpers drew them while the arms finished the step
+#pragma unroll
+                for (int j = 0; j < RBL_NQ; ++j) gn[j] = lds[(SP_DRAW_OFF + j) * 64 + lane];
+            } else {
+                draw_goals(draw + (ep.auto_reset ? 1u : 0u));
+            }
             draw += ep.auto_reset ? 2u : 1u;
             if (ep.auto_reset) {
 #pragma unroll
