@@ -307,11 +307,19 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
     }
 
 
-def run_fused_env(torch, robot, n_envs, steps=300, warmup=30):
+def run_fused_env(torch, robot, n_envs, steps=300, warmup=30, spread=False):
     """Secondary line: the fused env layer (rb_env_step_dev: rescale + physics +
-    obs/reward/done/goal, 84 + 72 algorithmic bytes per env step), eager launches."""
+    obs/reward/done/goal, 84 + 72 algorithmic bytes per env step), eager launches.
+    spread: the envs' episode counters start uniformly spread over an episode (as in training once goals have been reached
+    here and there), so every step ends one episode in 400 - and a launch waits for the waves that handle one; default: all
+    episodes in lock-step, none ends inside the timed steps."""
     from gym_roboy_amd.envs.vec_env import RoboyVecEnv
     env = RoboyVecEnv(robot, n_envs)
+    if spread:
+        rng = np.random.default_rng(3)
+        box = robot.get_joint_angles_space()
+        env.reset()
+        env.set_goal(rng.uniform(box.low, box.high, (n_envs, env.n_q)).astype(np.float32), rng.integers(1, 401, n_envs).astype(np.uint32))
     st = torch.cuda.current_stream()
     env.sim.set_stream(st.cuda_stream)
     acts = [torch.rand((n_envs, env.n_t), device="cuda") * 2 - 1 for _ in range(RING)]
@@ -336,7 +344,9 @@ def run_fused_env(torch, robot, n_envs, steps=300, warmup=30):
     env.sim_kernel = env.sim.info()["kernel"]
     env.close()
     name = "fused-env-%d" % n_envs if type(robot).__name__ == "MsjRobot" else "fused-env-%s-%d" % (type(robot).__name__, n_envs)
-    return {"workload": name, "label": "fused env layer (RoboyVecEnv.step), %s, %d envs, Euler fp32" % (type(robot).__name__, n_envs),
+    if spread:
+        name += "-spread"
+    return {"workload": name, "label": "fused env layer (RoboyVecEnv.step), %s, %d envs, Euler fp32%s" % (type(robot).__name__, n_envs, ", episodes spread out" if spread else ""),
             "value": n_envs * steps / wall, "ms_per_step": wall * 1e3 / steps, "launch_us_events": us, "steps": steps,
             "roofline": roofline(type(robot).__name__, "euler", 1, n_envs, bytes_per, us * 1e-6, name,
                                  "tree_lane_step" if env.sim_kernel == 1 and type(robot).__name__ != "MsjRobot" else None),
@@ -560,6 +570,7 @@ def main():
                     also.append(brief(run_workload(torch, rob, name, None, None, None, use_graph, rank, world, dist)))
             also.append(brief(run_fused_env(torch, MsjRobot(), 2097152)))
             also.append(brief(run_fused_env(torch, UpperBodyRobot(), 8192)))
+            also.append(brief(run_fused_env(torch, UpperBodyRobot(), 8192, spread=True)))
             also.append(brief(run_fused_env(torch, UpperBodyRobot(), 65536)))
             for n_fused in (4096, 2097152):
                 also.append(brief(run_fused_rollout(torch, MsjRobot(), n_fused)))
