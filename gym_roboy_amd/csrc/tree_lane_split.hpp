@@ -439,29 +439,33 @@ tree_split_env_step(const rbe::TreeEnvArgs a) {
 #if defined(RB_SPLIT_STAMPS)
     rbl_stamp_mark();                                  // the wave's share of the step is done
 #endif
+    // The accountant (wave 0 - the shortest part: it is here first) uses its wait for the others: its arguments from the kernel-
+    // argument segment, the old goal row of its env (read HERE, not in front of the step - a value defined under `wave == 0` before
+    // the dispatch is alive, as far as the register allocator can tell, through every other wave's code: 20 registers in kernels that
+    // sit at their 256), and the goal part of the observation rows (the waves write q and qd themselves)
+    const rbe::tree_env_kernarg_ptr late = rbe::late_args();
+    rbe::EnvParams ep;
+    float gg[RBL_NQ];
+    if (wave == 0) {
+        ep = rbe::late_env_params(late);
+        const int row = sp_opaque(lane < live ? lane : live - 1), wl0 = sp_opaque(lane);
+#pragma unroll
+        for (int j = 0; j < RBL_NQ; ++j) gg[j] = lds[OG + row * RBL_NQ + j];
+#pragma unroll
+        for (int j = 0; j < RBL_NQ; ++j) lds[OO + wl0 * (3 * RBL_NQ) + 2 * RBL_NQ + j] = gg[j];
+    }
     __syncthreads();
 #if defined(RB_SPLIT_STAMPS)
     rbl_stamp_mark();                                  // every wave's is
 #endif
-    const rbe::tree_env_kernarg_ptr late = rbe::late_args();
     if (wave == 0) {
         const int wl = sp_opaque(lane);
-        const rbe::EnvParams ep = rbe::late_env_params(late);
         const uint64_t seed = late->seed, env_id0 = late->env_id0;
         double *__restrict__ ep_sum = late->ep_sum;
         uint32_t *__restrict__ ep_cnt = late->ep_cnt, *__restrict__ infeas_n = late->infeas_n, *__restrict__ feas = late->feas;
         uint32_t *__restrict__ step_num = late->step_num, *__restrict__ goal_count = late->goal_count, *__restrict__ done = late->done;
         float *__restrict__ ep_ret = late->ep_ret, *__restrict__ reward = late->reward;
         const long n = late->n;
-        // the old goal row of the accountant's env, for the observation: read HERE, not in front of the step - a value defined under
-        // `wave == 0` before the dispatch is alive, as far as the register allocator can tell, through every other wave's code (20
-        // registers in kernels that sit at their 256)
-        float gg[RBL_NQ];
-        {
-            const int row = sp_opaque(lane < live ? lane : live - 1);
-#pragma unroll
-            for (int j = 0; j < RBL_NQ; ++j) gg[j] = lds[OG + row * RBL_NQ + j];
-        }
         bool ok = true;
         float dq2 = 0.0f, dv2 = 0.0f;
 #pragma unroll
@@ -505,6 +509,7 @@ tree_split_env_step(const rbe::TreeEnvArgs a) {
                 for (int j = 0; j < RBL_NQ; ++j) {
                     lds[wl * RBL_NQ + j] = 0.0f; lds[OV + wl * RBL_NQ + j] = 0.0f; gg[j] = gn[j];
                     lds[OO + wl * (3 * RBL_NQ) + j] = 0.0f; lds[OO + wl * (3 * RBL_NQ) + RBL_NQ + j] = 0.0f;
+                    lds[OO + wl * (3 * RBL_NQ) + 2 * RBL_NQ + j] = gn[j];
                 }
             }
             if (mine) {
@@ -515,9 +520,7 @@ tree_split_env_step(const rbe::TreeEnvArgs a) {
             if (ep.auto_reset) { sn = 1u; fz = 1u; }
             ret = 0.0f;
         }
-        // observation row [q | qd | goal as observed] and the goal row after the step (a second image behind the rows' own)
-#pragma unroll
-        for (int j = 0; j < RBL_NQ; ++j) lds[OO + wl * (3 * RBL_NQ) + 2 * RBL_NQ + j] = gg[j];      // (q and qd: the waves' own writes)
+        // (observation rows [q | qd | goal as observed]: q and qd are the waves' own writes, the goals went in above)
         const bool any = __builtin_amdgcn_ballot_w64(dn && mine) != 0ull;
         if (lane == 0) lds[(SP_FLAG_OFF + 3 * RBL_NPARTS) * 64] = any ? 1.0f : 0.0f;
         if (any) {
