@@ -23,6 +23,11 @@ __device__ __forceinline__ float goal_value(float lo, float hi, uint32_t u) {
 // upper body at 8 192 envs with the episodes spread out, as in training: 14.1 us per step against 12.2 in lock-step)
 __device__ __forceinline__ void stat_add(double *p, double v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void stat_add(uint32_t *p, uint32_t v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// A value the optimiser cannot look into (no instruction; removable when unused): the set-point offsets of the env-per-lane kernels
+// pass through it, so that their last multiplication is ROUNDED in the plain step and in the fused env step alike - otherwise the
+// compiler may contract it into the first use inside the acceleration in one kernel and not in the other (different code around it),
+// and the two differ in the last bit (seen with hiprtc-built kernels of a random robot: 6e-7 after two steps)
+__device__ __forceinline__ float rounded_here(float x) { asm("" : "+v"(x)); return x; }
 struct GoalBox { float lo[32]; float hi[32]; };
 
 struct EnvParams {

@@ -227,7 +227,7 @@ tree_lane_step(float *__restrict__ q, float *__restrict__ qd, uint32_t *__restri
     float qq[RBL_NQ], vv[RBL_NQ], spu[RBL_NT], none[RBL_NQ];
     load_inputs<false>(q, qd, act, nullptr, env0, live, region, lane, qq, vv, spu, none);
 #pragma unroll
-    for (int k = 0; k < RBL_NT; ++k) spu[k] = (spu[k] * act_scale) * KSG[k];
+    for (int k = 0; k < RBL_NT; ++k) spu[k] = rbe::rounded_here((spu[k] * act_scale) * KSG[k]);
     const bool ok = lane_step<INTEG>(L, spu, h, nsub, qq, vv);
     {
         float no_obs[3 * RBL_NQ];
@@ -268,7 +268,7 @@ tree_lane_env_step(const rbe::TreeEnvArgs a) {
     for (int k = 0; k < RBL_NT; ++k) {
         // clamp to the action box, then slope * (x - in_high) + out_high with two roundings (roboy_env.py:157-158)
         const float x = fminf(fmaxf(spu[k], -1.0f), 1.0f);
-        spu[k] = rbe::mul_then_add(slope, x - 1.0f, act_hi) * KSG[k];
+        spu[k] = rbe::rounded_here(rbe::mul_then_add(slope, x - 1.0f, act_hi) * KSG[k]);
     }
     const bool ok = lane_step<INTEG>(L, spu, h, nsub, qq, vv);
     const rbe::tree_env_kernarg_ptr late = rbe::late_args();

@@ -251,9 +251,9 @@ __device__ __forceinline__ void split_wave(float *lds, int lane, int live, float
         if (env_layer) {
             // clamp to the action box, then slope * (x - in_high) + out_high with two roundings (roboy_env.py:157-158)
             const float x = fminf(fmaxf(a, -1.0f), 1.0f);
-            spu[k] = rbe::mul_then_add(ep->slope, x - 1.0f, ep->act_hi) * KSG[k];
+            spu[k] = rbe::rounded_here(rbe::mul_then_add(ep->slope, x - 1.0f, ep->act_hi) * KSG[k]);
         } else {
-            spu[k] = (a * act_scale) * KSG[k];
+            spu[k] = rbe::rounded_here((a * act_scale) * KSG[k]);
         }
     }
     const SplitLds L{lds + (SP_WAVE_OFF + PART * SP_WAVE_SLOTS) * 64 + lane};
@@ -296,9 +296,9 @@ __device__ __forceinline__ void split_helper(float *lds, int lane, int live, flo
         const float a = img[OA + row * RBL_NT + k];
         if (env_layer) {
             const float x = fminf(fmaxf(a, -1.0f), 1.0f);
-            spu[k] = rbe::mul_then_add(ep->slope, x - 1.0f, ep->act_hi) * KSG[k];
+            spu[k] = rbe::rounded_here(rbe::mul_then_add(ep->slope, x - 1.0f, ep->act_hi) * KSG[k]);
         } else {
-            spu[k] = (a * act_scale) * KSG[k];
+            spu[k] = rbe::rounded_here((a * act_scale) * KSG[k]);
         }
     }
 #if !defined(RB_SPLIT_NO_HELPER_PRIO)

@@ -383,3 +383,46 @@ def test_fused_env_layer_on_random_robots_matches_host_replay(seed):
     st = vec.stats()
     assert st["n_env_steps"] == 22 * n and st["n_episodes"] == n_done
     vec.close(); host.stepper.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [1, 4])          # RB_KERNEL_ENV_PER_LANE, RB_KERNEL_ENV_PER_LANE_SPLIT: both built by hiprtc for this robot
+def test_fused_env_layer_of_the_hiprtc_built_lane_and_split_kernels_matches_host_replay(kernel):
+    """The env-step kernels of the env-per-lane forms take ONE struct argument (env_common.hpp: TreeEnvArgs) and read most of it
+    behind the step; for a robot without ahead-of-time instances they are compiled by hiprtc and launched through
+    hipModuleLaunchKernel with that struct: the replay check of the test above on those two forms (random robot 4 has a split form
+    with tendon helpers), the host model stepping with the same kernel form.  The plain step and the fused env step of a form are
+    separate compilations of the same generated text: where a*b + c*d may be contracted either way the compiler's choice can differ
+    between them, so states are compared to 2e-6 here (they happen to agree bit for bit for the ahead-of-time kernels of the upper
+    body and for this robot's split form; the one-wave form differs by 6e-7 after two steps), goals bit for bit."""
+    from host_env_model import HipStepper, HostEnvModel
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    robot, desc = random_tree_robot(4)
+    n, env_seed, max_len = 130, 5, 7
+    vec = RoboyVecEnv(robot, n, seed=env_seed, auto_reset=True, max_episode_length=max_len, joint_vel_penalty=True)
+    vec.sim.select_kernel(kernel)
+    stepper = HipStepper(robot, n, env_seed)
+    stepper.sim.select_kernel(kernel)
+    host = HostEnvModel(robot, stepper, n, env_seed, max_len, True, True, True)
+    obs0 = vec.reset()
+    host.goal = host.draw(np.ones(n, bool))
+    nq = desc.n_q
+    assert np.array_equal(obs0[:, 2 * nq:], host.goal)
+    rng = np.random.default_rng(2)
+    n_done = 0
+    for t in range(16):
+        a = rng.uniform(-1, 1, (n, desc.n_t)).astype(np.float32)
+        obs, rew, done, _ = vec.step(a)
+        h_obs, h_rew, h_done, margin = host.step(a)
+        assert (done == h_done).all() or (margin[done != h_done] < 1e-5).all()
+        assert np.abs(obs[:, :2 * nq] - h_obs[:, :2 * nq]).max() < 2e-6
+        assert np.array_equal(obs[:, 2 * nq:], h_obs[:, 2 * nq:].astype(np.float32))
+        np.testing.assert_allclose(rew, h_rew, rtol=3e-5, atol=3e-4)
+        n_done += int(done.sum())
+        if not np.array_equal(obs[:, :2 * nq], h_obs[:, :2 * nq].astype(np.float32)):
+            stepper.sim.set_state(obs[:, :nq].copy(), obs[:, nq:2 * nq].copy())     # (keep the replay on the kernel's own trajectory)
+    assert n_done >= 2 * n
+    assert vec.sim.info()["kernel"] == kernel
+    st = vec.stats()
+    assert st["n_env_steps"] == 16 * n and st["n_episodes"] == n_done
+    vec.close(); stepper.close()
