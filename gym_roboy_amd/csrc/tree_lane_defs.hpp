@@ -40,6 +40,7 @@ RBL_FN float rbl_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 RBL_FN float rbl_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 RBL_FN float rbl_med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 RBL_FN float rbl_max(float a, float b) { return fmaxf(a, b); }
+RBL_FN float rbl_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 // Pair values (tree_lane_gen.hpp: Val::pair - a subtree and its structurally identical mate, e.g. the two arms, written
 // as ONE instruction stream): arithmetic on rbl_f2 becomes v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, a plain float
@@ -57,3 +58,4 @@ RBL_FN rbl_f2 rbl_rcp(rbl_f2 v) { return rbl_f2{rbl_rcp(v.x), rbl_rcp(v.y)}; }
 RBL_FN rbl_f2 rbl_exp2(rbl_f2 v) { return rbl_f2{rbl_exp2(v.x), rbl_exp2(v.y)}; }
 RBL_FN rbl_f2 rbl_med3(rbl_f2 v, float lo, float hi) { return rbl_f2{rbl_med3(v.x, lo, hi), rbl_med3(v.y, lo, hi)}; }
 RBL_FN rbl_f2 rbl_max(rbl_f2 a, float b) { return rbl_f2{rbl_max(a.x, b), rbl_max(a.y, b)}; }
+RBL_FN rbl_f2 rbl_fma(rbl_f2 a, rbl_f2 b, rbl_f2 c) { return __builtin_elementwise_fma(a, b, c); }

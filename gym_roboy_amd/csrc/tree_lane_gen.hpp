@@ -182,7 +182,7 @@ class Gen {
                 ++n_stmt;
                 // arithmetic = a kept temporary that is not an LDS read-back
                 if (!stmts[k].target.empty() && stmts[k].text.find("RBL_LDS(") == std::string::npos)
-                    flops += stmts[k].text.compare(0, 17, "    const rbl_f2 ") == 0 ? 2 : 1;
+                    flops += (stmts[k].text.compare(0, 17, "    const rbl_f2 ") == 0 ? 2 : 1) * (stmts[k].text.find("rbl_fma(") != std::string::npos ? 2 : 1);
             }
         return out;
     }
@@ -228,7 +228,19 @@ class Gen {
         r.neg = a.neg != b.neg;
         return r;
     }
-    Val fma(const Val &a, const Val &b, const Val &c) { return add(mul(a, b), c); }
+    // a * b + c as ONE fused operation, written as such (rbl_fma): where the addend is a product itself (the second term of every dot
+    // product, a cross product's a1 b2 - a2 b1) a compiler that is merely ALLOWED to contract may fuse either product, and it chooses
+    // differently in different kernels around the same text - the plain step and the fused env step of one robot then differ in
+    // the last bit.  Products with constants 0 / +-1 and sums with 0 fold as before.
+    Val fma(const Val &a, const Val &b, const Val &c) {
+        if ((a.k && b.k) || is0(a) || is0(b) || is1(a) || is1(b) || ism1(a) || ism1(b) || is0(c)) return add(mul(a, b), c);
+        const bool pr = a.pair || b.pair || c.pair;
+        auto operand = [&](const Val &v) {
+            if (!pr || v.pair) return S(v);
+            return "RBL_MK2(" + S(v) + ", " + S(v) + ")";      // (a plain value in a pair operation: both halves)
+        };
+        return emit("rbl_fma(" + operand(a) + ", " + operand(b) + ", " + operand(c) + ")", pr);
+    }
     // sum of products, accumulated left to right
     Val dot(const std::vector<std::pair<Val, Val>> &terms) {
         Val acc = K(0.0);
@@ -267,9 +279,8 @@ class Gen {
         V3 o;
         for (int k = 0; k < 3; ++k) {
             const int n1 = (k + 1) % 3, n2 = (k + 2) % 3;
-            const Val l = mul(a[n1], b[n2]);
             const Val r = mul(a[n2], b[n1]);
-            o[k] = sub(l, r);
+            o[k] = fma(a[n1], b[n2], negv(r));
         }
         return o;
     }
@@ -477,7 +488,7 @@ class Aba {
         // Hill-type force, scaled forms as in tree_aba.hpp p2_tendon / msj_math.hpp
         const Val es = g.fma(len, CT(rob.il0s.data(), k), CT(rob.elcs.data(), k));
         const Val spu = in_t("spu", k);
-        const Val act = g.call3("rbl_med3", g.sub(g.mul(es, K(rob.kps)), spu), K(0.0), K(1.0));
+        const Val act = g.call3("rbl_med3", g.fma(es, K(rob.kps), Gen::negv(spu)), K(0.0), K(1.0));
         const Val fl = g.call1("rbl_exp2", Gen::negv(g.mul(es, es)));
         const Val v = g.mul(ldot, CT(rob.inv_vl0.data(), k));
         const Val vp = g.call2("rbl_max", v, K(0.0)), pq = g.call3("rbl_med3", g.add(v, K(1.0)), K(0.0), K(1.0));

@@ -20,6 +20,7 @@ inline float rbl_hi(rbl_f2 v) { return v.y; }
 inline float rbl_lo(float v) { return v; }
 inline float rbl_hi(float v) { return v; }
 inline float rbl_hsum(rbl_f2 v) { return v.x + v.y; }
+inline rbl_f2 rbl_fma(rbl_f2 a, rbl_f2 b, rbl_f2 c) { return rbl_f2{std::fma(a.x, b.x, c.x), std::fma(a.y, b.y, c.y)}; }
 inline rbl_f2 rbl_sin(rbl_f2 v) { return rbl_f2{rbl_sin(v.x), rbl_sin(v.y)}; }
 inline rbl_f2 rbl_cos(rbl_f2 v) { return rbl_f2{rbl_cos(v.x), rbl_cos(v.y)}; }
 inline rbl_f2 rbl_rsq(rbl_f2 v) { return rbl_f2{rbl_rsq(v.x), rbl_rsq(v.y)}; }

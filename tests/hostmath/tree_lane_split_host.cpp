@@ -27,6 +27,7 @@ inline float rbl_rcp(float x) { return 1.0f / x; }
 inline float rbl_exp2(float x) { return std::exp2(x); }
 inline float rbl_med3(float x, float lo, float hi) { return std::fmin(std::fmax(x, lo), hi); }
 inline float rbl_max(float a, float b) { return std::fmax(a, b); }
+inline float rbl_fma(float a, float b, float c) { return std::fma(a, b, c); }
 
 #include "rbl_pair_host.hpp"
 
