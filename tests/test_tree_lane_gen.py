@@ -290,6 +290,43 @@ def test_upper_body_split_form_with_tendon_helpers_matches_oracle():
     assert one["n_helpers"] == 1
 
 
+def _sums_of_two_single_use_products(text):
+    """Statements `tA +- tB` of the generated text whose operands are both products used nowhere else: there a compiler that may
+    contract has a choice (which product to fuse), and made it differently in different kernels around the same text."""
+    import collections
+    import re
+    stm = re.findall(r"const (?:float|rbl_f2) (t\d+) = ([^;]+);", text)
+    defs = dict(stm)
+    uses = collections.Counter(u for _, expr in stm for u in re.findall(r"\bt\d+\b", expr))
+    product = lambda x: x in defs and "rbl_" not in defs[x] and re.fullmatch(r"[^+\-]*\*[^+\-]*", defs[x].replace("(-", "(")) is not None
+    n = 0
+    for _, expr in stm:
+        m = re.fullmatch(r"\(?-?(t\d+)\)? [+-] \(?-?(t\d+)\)?", expr.strip())
+        if m and product(m.group(1)) and product(m.group(2)) and uses[m.group(1)] == 1 and uses[m.group(2)] == 1:
+            n += 1
+    return n
+
+
+def test_generated_text_leaves_no_contraction_to_choose():
+    """a*b + c*d is written as rbl_fma(a, b, c*d) everywhere (dot products, cross products, the tendons' activation): the plain step
+    and the fused env step of a robot - separate compilations of this text - then agree bit for bit (GPU:
+    tests/test_random_robots_gpu.py, the hiprtc-built kernels of a random robot)."""
+    import gen_tree_lane_baked as gen
+    from gym_roboy_amd.envs.robots import UpperBodyRobot, RobotDescription
+    from random_robots import random_tree_spec
+    os.makedirs(BUILD, exist_ok=True)
+    descs = [UpperBodyRobot().get_description()] + [RobotDescription(random_tree_spec(s)) for s in (4, 9)]
+    for k, desc in enumerate(descs):
+        one = os.path.join(BUILD, "contract_one_%d.hpp" % k)
+        gen.generate(desc, one)
+        text = open(one).read()
+        assert "rbl_fma(" in text and _sums_of_two_single_use_products(text) == 0
+        split = os.path.join(BUILD, "contract_split_%d.hpp" % k)
+        gen.generate_split(desc, split, 4, 2, 80, 1, 0, 1)
+        assert _sums_of_two_single_use_products(open(split).read()) == 0
+    assert _sums_of_two_single_use_products("const float t1 = a * b;\nconst float t2 = c * d;\nconst float t3 = t1 - t2;") == 1    # (the scan sees one)
+
+
 TWO_SWEEPS, CUT, SHARE_TRUNK = 1 << 16, 1 << 17, 1 << 18          # bits of the generator entry's max_helpers word (csrc/gen_tree_lane.cpp)
 
 
