@@ -16,21 +16,33 @@ streams, pre-generated as a ring of 4 slabs resident in HBM and rescaled by
 Default workload for every --gpus N: 262 144 envs per GPU, RK4 (BASELINE.json
 configs[2] at N = 1; at N = 8 the same shard size as configs[4], 2 097 152 envs
 in all).  The other single-GPU configs (4 096 envs, the Euler shard, a 2 097 152
-env batch, the upper body, the fused env layer) are measured briefly and
-reported under "also"; they are not the headline.
+env batch, the upper body, the fused env layer) are measured briefly at N = 1;
+each contributes ONE compact row to ``roofline.configs``
+([us per step, HBM fraction, vector-fp32 fraction, launches per step]) and its
+long form goes to ``bench_also.json`` beside this file and to stderr.
 
-Timing: W untimed warm-up steps, then the K-step region - bracketed by a
-barrier and a device synchronisation on both sides - is timed R times (R chosen
-so that the repeats cover >= 50 ms of device time, so a small K does not turn
-the number into a measurement of launch latency); ``ms_per_step`` is the mean
-over the repeats of (max over ranks of the region's wall time) / K and ``value``
-the env steps of all ranks in one region divided by that time.
+Output: the LAST thing on stdout is ONE compact JSON line of at most LINE_CAP =
+4 096 bytes with the contract keys (metric, value, unit, n_gpus, steps, warmup,
+repeats, ms_per_step, higher_is_better, scaling, vs_baseline, dtype, data,
+config, roofline, cpu_baseline, collective, sanity); a longer line is a bug and
+the exit code says so (4).  Strict JSON: non-finite numbers are written as null.
+
+Timing (``timing_protocol`` 2): W untimed warm-up steps, then the K-step region -
+bracketed by a barrier and a device synchronisation on both sides - is timed R
+times (R chosen so that the repeats cover >= 50 ms of device time, so a small K
+does not turn the number into a measurement of launch latency); ``ms_per_step``
+is the MEAN over the repeats of (max over ranks of the region's wall time) / K
+(``ms_per_step_median`` beside it; rounds 1-3 = protocol 1 printed the median and
+reduced the statistics in every region) and ``value`` the env steps of all ranks
+in one region divided by that time.
 
 N > 1: launched by torch.distributed.run, one rank per GPU; envs shard
 contiguously (weak scaling: the per-GPU batch is fixed), no data-path
 collective; every STATS_EVERY = 100 steps (counted across the timed regions) the
 rank's episode statistics (8 doubles) are reduced on the device and all-reduced
-over RCCL, and the line carries a ``collective`` object that audits it.  Prints ONE JSON line on rank 0.
+over RCCL, and the line carries a ``collective`` object that audits it.  The
+one-launch-per-step leg (``roofline.one_launch``) runs at N = 1, at N > 1 only
+with --one-launch.  Rank 0 prints the line.
 """
 import argparse
 import json
@@ -147,6 +159,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager per-step launches instead of hipGraph replay")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-launch", action="store_true", help="N > 1: also time the headline with one launch per step over the whole shard (always on at N = 1)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--repeats", type=int, default=None, help="fix the number of timed repeats (default: cover 50 ms)")
     return ap.parse_args()
@@ -513,6 +526,127 @@ def brief(r):
     return {k: r[k] for k in keep if k in r}
 
 
+LINE_CAP = 4096            # bytes: the contract line on stdout never exceeds this (the driver keeps a bounded tail of stdout)
+TIMING_PROTOCOL = 2        # 1 (rounds 1-3): statistics reduction at the end of every region, ms_per_step = median of the region walls
+                           # 2 (round 4 on): reduction every STATS_EVERY steps counted across regions, ms_per_step = mean; the median rides along
+# the secondary workloads whose compact rows ride in roofline.configs (everything else: bench_also.json / stderr)
+CONFIG_ROWS = ("msj-4096-euler", "upper-body-8192-euler", "upper-body-8192-rk4", "msj-262144-euler", "msj-2097152-euler",
+               "fused-env-2097152", "upper-body-65536-euler", "fused-env-UpperBodyRobot-65536")
+TRAFFIC_ROWS = ("msj-262144-euler", "msj-2097152-euler")    # rows that also carry PMC traffic / algorithmic bytes
+
+
+def sig(x, digits=5):
+    """Floats to `digits` significant digits (the line is capped; 1e-5 relative is far below run-to-run spread); non-finite -> None."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if not math.isfinite(x):
+            return None
+        if x == 0.0 or x == int(x) and abs(x) < 1e15:
+            return int(x) if x == int(x) else x
+        return float("%.*g" % (digits, x))
+    return x
+
+
+def sanitize(obj, digits=None):
+    """JSON-safe copy: non-finite floats become null (strict parsers reject NaN / Infinity); digits: also round the floats."""
+    if isinstance(obj, dict):
+        return {str(k): sanitize(v, digits) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [sanitize(v, digits) for v in obj]
+    if isinstance(obj, (np.floating,)):
+        obj = float(obj)
+    if isinstance(obj, (np.integer,)):
+        return int(obj)
+    if isinstance(obj, (np.bool_,)):
+        return bool(obj)
+    if isinstance(obj, float):
+        if not math.isfinite(obj):
+            return None
+        return sig(obj, digits) if digits else obj
+    return obj
+
+
+def config_row(r):
+    """[us per step (HIP events), fraction of HBM peak, fraction of the fp32 vector peak, launches per step] of a secondary workload."""
+    rf = r.get("roofline") or {}
+    return [r.get("launch_us_events", r.get("us_per_step_events")), (rf.get("hbm") or {}).get("frac"),
+            (rf.get("valu") or {}).get("frac"), rf.get("launches_per_step")]
+
+
+def build_line(head, also, one_launch, cpu, world, robot_name, use_graph):
+    """The contract line as a dict: the driver's keys, `roofline` (scalars + both fractions + the one-launch figure + one
+    compact row per secondary workload), `cpu_baseline`, `collective`, `sanity` - and nothing verbose (format_line caps it)."""
+    rf = head["roofline"]
+    chains = rf.get("launches_per_step", 1)
+    by_name = {a.get("workload"): a for a in also if "value" in a}
+    configs = {w: config_row(by_name[w]) for w in CONFIG_ROWS if w in by_name}
+    toa = {}
+    for w in TRAFFIC_ROWS:
+        r = (by_name.get(w) or {}).get("roofline") or {}
+        if r.get("traffic"):
+            toa[w] = r["traffic"] / r["hbm"]["bytes_per_launch"]
+    roof = {"bound": rf["bound"], "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"], "frac": rf["frac"],
+            "traffic": rf["traffic"], "traffic_source": rf.get("traffic_source"), "kernel": head["kernel"],
+            "launch_us_events": rf["launch_us_events"], "launches_per_step": chains, "envs_per_launch": rf["envs_per_launch"],
+            "hbm": {k: rf["hbm"][k] for k in ("achieved", "peak", "frac", "bytes_per_env_step", "bytes_per_launch")},
+            "valu": ({k: rf["valu"][k] for k in ("achieved", "peak", "frac", "flops_per_env_step", "flops_per_launch")}
+                     if rf.get("valu") else None),
+            "one_launch_us": (one_launch or {}).get("us_events"),
+            "one_launch": ({k: one_launch[k] for k in ("us_events", "frac", "hbm_frac")} if one_launch else None),
+            "configs_cols": ["us_events", "hbm_frac", "valu_frac", "launches_per_step"], "configs": configs,
+            "traffic_over_algorithmic": toa,
+            "note": "us_events = HIP events on the launch stream around a region's K steps, median, / K; rocprofv3 in profiles/"}
+    cpu_c = None
+    if cpu is not None:
+        py = cpu.get("python_env_processes") or {}
+        cpu_c = {"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"], "sample": cpu["sample"],
+                 "value_1_core": cpu.get("value_1_core"), "host_cores_available": cpu.get("host_cores_available"),
+                 "by_threads": {th: v["value"] for th, v in (cpu.get("by_threads") or {}).items()},
+                 "python_env_processes": ({"value": py.get("value"), "processes": py.get("processes")} if py else None)}
+    coll = head["collective"]
+    return {
+        "metric": "env-steps/sec, MsjRobot (3-DOF/8-tendon) batched rollout" if robot_name == "MsjRobot"
+                  else "env-steps/sec, %s batched rollout" % robot_name,
+        "value": head["value"], "unit": "env-steps/s",
+        "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"], "repeats": head["repeats"],
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": head["label"], "robot": robot_name, "envs_per_gpu": head["envs_per_gpu"],
+                   "total_envs": head["envs_per_gpu"] * world, "integrator": head["integrator"],
+                   "substeps": head["substeps"], "step_size": 0.1,
+                   "launch": (("hipGraph replay, one kernel per step" + ("; %d concurrent chains over 1/%d of the batch each" % (chains, chains)
+                                                                          if chains > 1 else ""))
+                              if use_graph else "eager per-step launches"),
+                   "parallelism": ("env shards x%d, RCCL all-reduce of episode statistics every %d steps" % (world, STATS_EVERY))
+                                  if world > 1 else "single GPU",
+                   "timing": "mean of the repeats of the K-step region (barrier + synchronize both sides, max over ranks); %.0f ms of device time"
+                             % head["timed_device_ms"]},
+        "timing_protocol": TIMING_PROTOCOL,
+        "ms_per_step_median": head["ms_per_step_median"], "ms_per_step_spread": [head["ms_per_step_min"], head["ms_per_step_max"]],
+        "roofline": roof,
+        "cpu_baseline": cpu_c,
+        "collective": ({k: coll[k] for k in ("backend", "world_size", "allreduce_calls", "payload_bytes", "every_steps",
+                                               "us_per_allreduce", "n_env_steps_allreduced", "expected", "ok")} if coll else None),
+        "sanity": {"finite": head["finite"], "feasible_frac": head["feasible_frac"], "allreduced_stats": head["stats"]},
+    }
+
+
+def format_line(line):
+    """One compact, strictly valid JSON line (no NaN / Infinity tokens, floats to 5 significant digits except the exact counts)."""
+    exact = {"value": line.get("value"), "ms_per_step": line.get("ms_per_step")}      # the driver recomputes one from the other
+    out = sanitize(line, digits=5)
+    for k, v in exact.items():
+        if isinstance(v, float) and math.isfinite(v):
+            out[k] = v
+    if line.get("sanity"):
+        out["sanity"]["allreduced_stats"] = sanitize(line["sanity"].get("allreduced_stats"))   # counts: exact
+    if line.get("collective"):
+        for k in ("n_env_steps_allreduced", "expected"):
+            out["collective"][k] = sanitize(line["collective"].get(k))
+    return json.dumps(out, separators=(",", ":"), allow_nan=False)
+
+
 def main():
     args = parse()
     # stdout carries exactly one JSON line.  Libraries below write there on their own
@@ -584,65 +718,33 @@ def main():
     # the headline workload once more with ONE launch per step over the whole batch (what rb_step_dev / rb_env_step_dev and
     # every per-step caller launch): beside the default form in the same line
     one_launch = None
-    if head["roofline"].get("launches_per_step", 1) > 1 and not os.environ.get("ROBOY_BENCH_NO_ONE_LAUNCH"):
+    if (head["roofline"].get("launches_per_step", 1) > 1 and not os.environ.get("ROBOY_BENCH_NO_ONE_LAUNCH")
+            and (world == 1 or args.one_launch)):      # N > 1: on request only (the leg repeats the whole protocol with its barriers on every rank)
         with torch.cuda.stream(torch.cuda.Stream()):
             one = run_workload(torch, robot, args.workload, args.steps, args.warmup, args.envs, use_graph, rank, world, dist,
                                args.substeps, args.kernel, max(3, (head["repeats"] + 3) // 4), force_chains=1)
         one_launch = {"us_events": one["launch_us_events"], "ms_per_step": one["ms_per_step"], "value": one["value"],
                       "frac": one["roofline"]["frac"], "hbm_frac": one["roofline"]["hbm"]["frac"], "repeats": one["repeats"]}
 
-    def compact(r):
-        """One row of roofline.configs: a secondary workload's numbers in a dozen scalars (the driver's record keeps `roofline`)."""
-        rf = r.get("roofline") or {}
-        return {"us_events": r.get("launch_us_events", r.get("us_per_step_events")), "env_steps_per_s": r["value"],
-                "hbm_frac": (rf.get("hbm") or {}).get("frac"), "valu_frac": (rf.get("valu") or {}).get("frac"),
-                "bound": rf.get("bound"), "launches_per_step": rf.get("launches_per_step"), "kernel": r.get("kernel"),
-                "traffic_over_algorithmic": (rf["traffic"] / rf["hbm"]["bytes_per_launch"]) if rf.get("traffic") else None,
-                "finite": r.get("finite"), "feasible_frac": r.get("feasible_frac")}
-    configs = {a["workload"]: compact(a) for a in also
-               if a.get("workload", "").startswith(("msj-", "upper-body-", "fused-env")) and "value" in a}
-    for a in also:
-        if a.get("workload", "").startswith("ppo-") and "value" in a:
-            configs[a["workload"]] = {"timesteps_per_s": a["value"], "rollout_ms": a.get("rollout_ms"), "update_ms": a.get("update_ms"),
-                                      "rollout_us_per_step": (a["rollout_ms"] * 1e3 / (a["steps"] / 2)) if a.get("rollout_ms") else None}
-
     rc = 0
     if rank == 0:
-        line = {
-            "metric": "env-steps/sec, MsjRobot (3-DOF/8-tendon) batched rollout" if type(robot).__name__ == "MsjRobot"
-                      else "env-steps/sec, %s batched rollout" % type(robot).__name__,
-            "value": head["value"], "unit": "env-steps/s",
-            "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"], "repeats": head["repeats"],
-            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": head["label"], "robot": type(robot).__name__, "envs_per_gpu": head["envs_per_gpu"],
-                       "total_envs": head["envs_per_gpu"] * world, "integrator": head["integrator"],
-                       "substeps": head["substeps"], "step_size": 0.1,
-                       "launch": (("hipGraph replay of per-step kernels" + ("; %d independent chains of launches over 1/%d of the batch each "
-                                                                               "(rb_rollout_chains: concurrent, same results bit for bit)"
-                                                                               % (head["roofline"]["launches_per_step"], head["roofline"]["launches_per_step"])
-                                                                               if head["roofline"].get("launches_per_step", 1) > 1 else ""))
-                                  if use_graph else "eager per-step launches"),
-                       "parallelism": ("env shards x%d, RCCL all-reduce of episode statistics every %d steps"
-                                       % (world, STATS_EVERY)) if world > 1 else "single GPU",
-                       "timing": "mean of %d repeats of the %d-step region (barrier + synchronize on both sides, "
-                                 "max over ranks; the statistics reduction every 100 steps falls into some of them); %.1f ms of device time in all"
-                                 % (head["repeats"], head["steps"], head["timed_device_ms"])},
-            "ms_per_step_spread": [head["ms_per_step_min"], head["ms_per_step_max"]], "ms_per_step_median": head["ms_per_step_median"],
-            "roofline": dict(head["roofline"], kernel=head["kernel"], one_launch_us=(one_launch or {}).get("us_events"),
-                             one_launch=one_launch, configs=configs,
-                             note="launch_us_events = HIP events on the launch stream around the K per-step launches "
-                                  "of a region, median over the repeats, / K = time per STEP over all envs (kernel + kernel boundary); "
-                                  "with launches_per_step > 1 a step is that many concurrent launches and rocprofv3 lists each "
-                                  "with its own, overlapping duration; rocprofv3 kernel-only averages are in profiles/"),
-            "cpu_baseline": cpu,
-            "collective": head["collective"],
-            "also": also,
-            "sanity": {"finite": head["finite"], "feasible_frac": head["feasible_frac"],
-                       "allreduced_stats": head["stats"]},
-        }
+        line = build_line(head, also, one_launch, cpu, world, type(robot).__name__, use_graph)
+        verbose = dict(line, roofline_full=head["roofline"], one_launch=one_launch, cpu_baseline_full=cpu, also=also)
+        text = format_line(line)
+        # the long form (every secondary workload with both rooflines spelled out) goes beside bench.py and to stderr,
+        # never to stdout: the driver keeps a bounded tail of stdout and must find the whole contract line in it
+        try:
+            with open(os.path.join(ROOT, "bench_also.json"), "w") as fh:
+                json.dump(sanitize(verbose), fh, indent=1)
+        except OSError as exc:
+            sys.stderr.write("bench.py: bench_also.json not written (%s)\n" % exc)
+        sys.stderr.write("bench.py: long form follows on stderr\n" + json.dumps(sanitize(verbose)) + "\n")
+        sys.stderr.flush()
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        os.write(json_fd, (text + "\n").encode())
+        if len(text) > LINE_CAP:
+            sys.stderr.write("bench.py: the contract line is %d bytes, over the %d-byte cap\n" % (len(text), LINE_CAP))
+            rc = 4
         if head["collective"] is not None and not head["collective"]["ok"]:
             sys.stderr.write("bench.py: the all-reduced env-step count %r does not match world x envs x steps = %r\n"
                              % (head["collective"]["n_env_steps_allreduced"], head["collective"]["expected"]))

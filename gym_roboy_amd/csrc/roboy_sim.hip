@@ -452,6 +452,15 @@ struct rb_sim {
     int chains_choice = 0;                                 // rb_set_rollout_chains: 0 = the library's choice, 1..MAX_CHAINS = that many
     hipStream_t chain_stream[MAX_CHAINS] = {};             // the further chains of rb_rollout_dev ([0] unused: the handle's stream; created on first use)
     hipEvent_t chain_fork = nullptr, chain_join[MAX_CHAINS] = {};
+    // caller streams handed to rb_step_range_dev / rb_env_step_range_dev: the handle remembers each distinct one with an event
+    // recorded behind its last range launch, so that drain() (rb_destroy, rb_select_kernel, rb_set_stream, graph eviction) waits
+    // for that work too.  A small set (a closed-loop caller uses one stream per chain); beyond it the oldest entry is waited
+    // for and reused.
+    static constexpr int MAX_CALLER_STREAMS = 8;
+    struct CallerStream { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool pending = false; uint64_t tick = 0; };
+    CallerStream caller[MAX_CALLER_STREAMS];
+    uint64_t caller_tick = 0;
+    hipStream_t call_stream = nullptr;                     // the stream of the range call in progress (capturing() looks at it too)
     float *d_q = nullptr, *d_qd = nullptr;
     uint32_t *d_feas = nullptr, *d_goal_count = nullptr;
     // fused env layer (rb_env_*)
@@ -488,10 +497,17 @@ namespace {
 // is not capturable): called by the entry points before they launch or capture.
 // A stream that is being captured must not see the build: the attempt is left for a later call (the state stays
 // "not tried") and this call launches the instances it already has.
-bool capturing(rb_sim *s) {
+bool stream_capturing(hipStream_t stream) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    return s->stream && hipStreamIsCapturing(s->stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+    return stream && hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
 }
+// the handle's stream, or the caller's stream of the range call in progress (rb_*_range_dev set call_stream around their work)
+bool capturing(rb_sim *s) { return stream_capturing(s->stream) || (s->call_stream && stream_capturing(s->call_stream)); }
+struct CallStreamScope {          // the stream a range entry point launches on, visible to the build guards for the call's duration
+    rb_sim *s;
+    CallStreamScope(rb_sim *sim, hipStream_t st) : s(sim) { s->call_stream = st; }
+    ~CallStreamScope() { s->call_stream = nullptr; }
+};
 
 int jit_level() {      // ROBOY_SIM_JIT: 0 = never, 1 (default) = from the batch thresholds on, 2 = at any batch size
     const char *e = std::getenv("ROBOY_SIM_JIT");
@@ -598,7 +614,11 @@ void maybe_jit(rb_sim *s) {
 bool tree_use_lane(rb_sim *s, int which);
 // kernel forms that step a sub-range of the batch (shifted pointers, own env count): what chains and the rb_*_range_dev entry points need
 bool range_capable(const rb_sim *s) {
-    if (s->tree) return s->kernel == RB_KERNEL_ENV_PER_LANE && tree_use_lane(const_cast<rb_sim *>(s), 0);   // one wave per 64 envs, env-major rows
+    if (s->tree) {      // the one-wave-per-64-envs form (env-major rows), not the split form and not the octets
+        if (tree_wants_split(s) && (s->split_baked || s->split_step_k.state == 1)) return false;
+        // (asks again on every call: a lane kernel whose build a stream capture deferred becomes available afterwards)
+        return tree_use_lane(const_cast<rb_sim *>(s), 0);
+    }
     return !s->ntx && s->kernel != RB_KERNEL_TENDON_PER_LANE;
 }
 bool chainable(const rb_sim *s) { return range_capable(s) && (s->tree || s->n > RB_SMALL_BATCH); }
@@ -814,6 +834,35 @@ int drain(rb_sim *s) {
     if (s->own_stream && s->own_stream != s->stream) RB_HIP(hipStreamSynchronize(s->own_stream));
     for (int c = 1; c < rb_sim::MAX_CHAINS; ++c)
         if (s->chain_stream[c]) RB_HIP(hipStreamSynchronize(s->chain_stream[c]));
+    // range launches on caller streams: the event behind the last one on each (the stream itself may be gone by now - an
+    // event outlives its stream - so the EVENT is waited for, never the stream)
+    for (rb_sim::CallerStream &c : s->caller)
+        if (c.pending) { RB_HIP(hipEventSynchronize(c.done)); c.pending = false; }
+    return RB_OK;
+}
+// Remember that a range launch has just been enqueued on `st`, a stream that is not one of the handle's own: record the
+// entry's event behind it.  Not while `st` is being captured (the launch is a graph node then, not work in flight: whoever
+// replays that graph keeps the handle alive meanwhile - roboy_sim.h).
+int note_caller_stream(rb_sim *s, hipStream_t st) {
+    if (st == s->stream || st == s->own_stream) return RB_OK;
+    for (int c = 1; c < rb_sim::MAX_CHAINS; ++c) if (st == s->chain_stream[c] && st) return RB_OK;
+    if (stream_capturing(st)) return RB_OK;
+    rb_sim::CallerStream *slot = nullptr;
+    for (rb_sim::CallerStream &c : s->caller) if (c.done && c.stream == st) { slot = &c; break; }
+    if (!slot) {
+        for (rb_sim::CallerStream &c : s->caller) if (!c.done) { slot = &c; break; }
+        if (!slot) {                                   // every entry taken: the least recently used one is waited for and reused
+            slot = &s->caller[0];
+            for (rb_sim::CallerStream &c : s->caller) if (c.tick < slot->tick) slot = &c;
+            if (slot->pending) { RB_HIP(hipEventSynchronize(slot->done)); slot->pending = false; }
+        } else {
+            RB_HIP(hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
+        }
+        slot->stream = st;
+    }
+    RB_HIP(hipEventRecord(slot->done, st));
+    slot->pending = true;
+    slot->tick = ++s->caller_tick;
     return RB_OK;
 }
 int drop_graphs(rb_sim *s) {
@@ -996,6 +1045,7 @@ void rb_destroy(rb_sim *s) {
     (void)hipFree(s->d_state_rows); (void)hipHostFree(s->h_state_rows);
     (void)hipFree(s->d_goal); (void)hipFree(s->d_ep_ret); (void)hipFree(s->d_ep_sum); (void)hipFree(s->d_ep_cnt);
     (void)hipFree(s->d_step_num); (void)hipFree(s->d_infeas_n); (void)hipFree(s->d_stats);
+    for (rb_sim::CallerStream &c : s->caller) if (c.done) (void)hipEventDestroy(c.done);
     if (s->chain_fork) (void)hipEventDestroy(s->chain_fork);
     for (int c = 1; c < rb_sim::MAX_CHAINS; ++c) {
         if (s->chain_join[c]) (void)hipEventDestroy(s->chain_join[c]);
@@ -1614,8 +1664,10 @@ int rb_env_step_range_dev(rb_sim *s, int64_t first_env, int64_t n_envs, void *hi
     if (!s->env_ready) return fail(RB_EINVAL, "rb_env_configure has not been called");
     if (!s->tree && reinterpret_cast<uintptr_t>(d_act) % 16) return fail(RB_EINVAL, "action slab must be 16-byte aligned");
     if (range_ok(s, first_env, n_envs)) return RB_EINVAL;
-    int rc = env_step_launch(s, long(first_env), long(n_envs), hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream, d_act, d_obs, d_reward, d_done);
-    if (rc == RB_OK) s->env_steps += double(n_envs);
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
+    CallStreamScope scope(s, st);          // a first call captured on the caller's stream defers the run-time builds (capturing())
+    int rc = env_step_launch(s, long(first_env), long(n_envs), st, d_act, d_obs, d_reward, d_done);
+    if (rc == RB_OK) { s->env_steps += double(n_envs); rc = note_caller_stream(s, st); }
     return rc;
 }
 int rb_step_range_dev(rb_sim *s, int64_t first_env, int64_t n_envs, void *hip_stream, const float *d_act, float act_scale) {
@@ -1623,12 +1675,13 @@ int rb_step_range_dev(rb_sim *s, int64_t first_env, int64_t n_envs, void *hip_st
     RB_HIP(hipSetDevice(s->device));
     if (reinterpret_cast<uintptr_t>(d_act) % 16) return fail(RB_EINVAL, "action slab must be 16-byte aligned");
     if (range_ok(s, first_env, n_envs)) return RB_EINVAL;
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
+    CallStreamScope scope(s, st);          // a first call captured on the caller's stream defers the run-time builds (capturing())
     maybe_jit(s);
     const bool whole = first_env == 0 && n_envs == s->n;
     if (!whole && !range_capable(s)) return fail(RB_EUNSUPPORTED, "this kernel form steps whole batches only (rb_range_capable)");
-    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
     int rc = whole && st == s->stream ? launch_step(s, d_act, act_scale) : launch_step(s, d_act, act_scale, long(first_env), long(first_env + n_envs), st);
-    if (rc == RB_OK) s->env_steps += double(n_envs);
+    if (rc == RB_OK) { s->env_steps += double(n_envs); rc = note_caller_stream(s, st); }
     return rc;
 }
 int rb_range_capable(rb_sim *s) {

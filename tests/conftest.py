@@ -8,6 +8,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from build_dir import build_dir  # noqa: E402  (scratch builds live outside the repository)
 
 
 def pytest_configure(config):
@@ -51,8 +53,7 @@ def msj_oracle(msj_robot):
 def hostmath_lib():
     """g++ build of the product's kernel arithmetic for the host (test harness)."""
     import ctypes
-    build = os.path.join(ROOT, "tests", "_build")
-    os.makedirs(build, exist_ok=True)
+    build = build_dir()
     so = os.path.join(build, "libhostmath.so")
     src = os.path.join(ROOT, "tests", "hostmath", "host_math.cpp")
     deps = [src] + [os.path.join(ROOT, "gym_roboy_amd", "csrc", f) for f in ("msj_math.hpp", "msj_build.hpp")]

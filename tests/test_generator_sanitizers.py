@@ -8,7 +8,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BUILD = os.path.join(ROOT, "tests", "_build")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from build_dir import build_dir  # noqa: E402
+BUILD = build_dir()
 
 DRIVER = r'''
 import ctypes, sys

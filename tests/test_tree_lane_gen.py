@@ -16,7 +16,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-BUILD = os.path.join(ROOT, "tests", "_build")
+from build_dir import build_dir  # noqa: E402
+BUILD = build_dir()
 
 
 def host_accel(desc, tag, lds_c=True, pack=True):

@@ -7,6 +7,7 @@ the oracle's tendon lengths at random poses; the LDS layout has no overlap and f
 import ctypes
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -26,8 +27,9 @@ class TreeDev(ctypes.Structure):
 
 @pytest.fixture(scope="module")
 def lib():
-    build = os.path.join(ROOT, "tests", "_build")
-    os.makedirs(build, exist_ok=True)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from build_dir import build_dir
+    build = build_dir()
     so = os.path.join(build, "libtreetables.so")
     src = os.path.join(ROOT, "tests", "hostmath", "tree_tables.cpp")
     dep = os.path.join(ROOT, "gym_roboy_amd", "csrc", "tree_build.hpp")

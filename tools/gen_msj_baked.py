@@ -11,12 +11,13 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def generate(path):
     from gym_roboy_amd.envs.robots import MsjRobot
-    build = os.path.join(ROOT, "tests", "_build")
-    os.makedirs(build, exist_ok=True)
+    from build_dir import build_dir          # tools/build_dir.py: outside the repository
+    build = build_dir()
     so = os.path.join(build, "libgen_msj_baked.so")
     src = os.path.join(ROOT, "gym_roboy_amd", "csrc", "gen_msj_baked.cpp")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, src])

@@ -12,11 +12,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def load_generator():
-    build = os.path.join(ROOT, "tests", "_build")
-    os.makedirs(build, exist_ok=True)
+    from build_dir import build_dir          # tools/build_dir.py: outside the repository
+    build = build_dir()
     so = os.path.join(build, "libgen_tree_lane.so")
     csrc = os.path.join(ROOT, "gym_roboy_amd", "csrc")
     deps = [os.path.join(csrc, f) for f in ("gen_tree_lane.cpp", "tree_lane_gen.hpp")]
