@@ -320,12 +320,15 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
     }
 
 
-def run_fused_env(torch, robot, n_envs, steps=300, warmup=30, spread=False):
+def run_fused_env(torch, robot, n_envs, steps=300, warmup=30, spread=False, chains=1):
     """Secondary line: the fused env layer (rb_env_step_dev: rescale + physics +
     obs/reward/done/goal, 84 + 72 algorithmic bytes per env step), eager launches.
     spread: the envs' episode counters start uniformly spread over an episode (as in training once goals have been reached
     here and there), so every step ends one episode in 400 - and a launch waits for the waves that handle one; default: all
-    episodes in lock-step, none ends inside the timed steps."""
+    episodes in lock-step, none ends inside the timed steps.
+    chains = 2: the batch as two halves on two streams (rb_env_step_range_dev), forked once before the timed steps and joined once
+    behind them - how a closed-loop caller runs its rollout (gym_roboy_amd/ppo.py): one half's row traffic lies under the other
+    half's arithmetic.  Same results (envs are independent)."""
     from gym_roboy_amd.envs.vec_env import RoboyVecEnv
     env = RoboyVecEnv(robot, n_envs)
     if spread:
@@ -339,14 +342,45 @@ def run_fused_env(torch, robot, n_envs, steps=300, warmup=30, spread=False):
     obs = torch.empty((n_envs, 3 * env.n_q), device="cuda")
     rew = torch.empty(n_envs, device="cuda")
     done = torch.empty(n_envs, dtype=torch.int32, device="cuda")
-    for t in range(warmup):
-        env.step_dev(acts[t % RING].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
+    if chains == 2 and not env.range_capable():
+        chains = 1
+    if chains == 2:
+        # each chain's steps as replays of a captured graph of GSTEPS range launches (two eager launches per step from Python
+        # take longer than the kernels): what gym_roboy_amd/ppo.py does with its (policy step, env step) pairs
+        half = ((n_envs // 2 + 255) // 256) * 256
+        st2 = torch.cuda.Stream()
+        GSTEPS = 12 * RING
+        steps = max(GSTEPS, (steps // GSTEPS) * GSTEPS)
+        warmup = GSTEPS
+        ptrs = (obs.data_ptr(), rew.data_ptr(), done.data_ptr())
+        env.step_range_dev(0, half, st.cuda_stream, acts[0].data_ptr(), *ptrs)       # (first call outside any capture)
+        torch.cuda.synchronize()
+        graphs = []
+        for first, count, stream in ((0, half, st), (half, n_envs - half, st2)):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                for t in range(GSTEPS):
+                    env.step_range_dev(first, count, stream.cuda_stream, acts[t % RING].data_ptr(), *ptrs)
+            graphs.append((g, stream))
+
+        def advance(k):
+            st2.wait_stream(st)                                  # fork once ...
+            for _ in range(k // GSTEPS):
+                with torch.cuda.stream(st2):
+                    graphs[1][0].replay()
+                with torch.cuda.stream(st):
+                    graphs[0][0].replay()
+            st.wait_stream(st2)                                  # ... join once
+    else:
+        def advance(k):
+            for t in range(k):
+                env.step_dev(acts[t % RING].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
+    advance(warmup)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record(st)
-    for t in range(steps):
-        env.step_dev(acts[t % RING].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
+    advance(steps)
     e1.record(st)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -359,10 +393,12 @@ def run_fused_env(torch, robot, n_envs, steps=300, warmup=30, spread=False):
     name = "fused-env-%d" % n_envs if type(robot).__name__ == "MsjRobot" else "fused-env-%s-%d" % (type(robot).__name__, n_envs)
     if spread:
         name += "-spread"
+    if chains == 2:
+        name += "-chains"
     return {"workload": name, "label": "fused env layer (RoboyVecEnv.step), %s, %d envs, Euler fp32%s" % (type(robot).__name__, n_envs, ", episodes spread out" if spread else ""),
             "value": n_envs * steps / wall, "ms_per_step": wall * 1e3 / steps, "launch_us_events": us, "steps": steps,
             "roofline": roofline(type(robot).__name__, "euler", 1, n_envs, bytes_per, us * 1e-6, name,
-                                 "tree_lane_step" if env.sim_kernel == 1 and type(robot).__name__ != "MsjRobot" else None),
+                                 "tree_lane_step" if env.sim_kernel == 1 and type(robot).__name__ != "MsjRobot" else None, chains),
             "finite": finite and bool(np.isfinite(q).all() and np.isfinite(qd).all()), "feasible_frac": float(feas.mean())}
 
 
@@ -531,7 +567,7 @@ TIMING_PROTOCOL = 2        # 1 (rounds 1-3): statistics reduction at the end of 
                            # 2 (round 4 on): reduction every STATS_EVERY steps counted across regions, ms_per_step = mean; the median rides along
 # the secondary workloads whose compact rows ride in roofline.configs (everything else: bench_also.json / stderr)
 CONFIG_ROWS = ("msj-4096-euler", "upper-body-8192-euler", "upper-body-8192-rk4", "msj-262144-euler", "msj-2097152-euler",
-               "fused-env-2097152", "upper-body-65536-euler", "fused-env-UpperBodyRobot-65536")
+               "fused-env-2097152", "upper-body-65536-euler", "fused-env-UpperBodyRobot-65536", "fused-env-UpperBodyRobot-65536-chains")
 TRAFFIC_ROWS = ("msj-262144-euler", "msj-2097152-euler")    # rows that also carry PMC traffic / algorithmic bytes
 
 
@@ -706,6 +742,7 @@ def main():
             also.append(brief(run_fused_env(torch, UpperBodyRobot(), 8192)))
             also.append(brief(run_fused_env(torch, UpperBodyRobot(), 8192, spread=True)))
             also.append(brief(run_fused_env(torch, UpperBodyRobot(), 65536)))
+            also.append(brief(run_fused_env(torch, UpperBodyRobot(), 65536, chains=2)))
             for n_fused in (4096, 2097152):
                 also.append(brief(run_fused_rollout(torch, MsjRobot(), n_fused)))
             for fused in (True, False):                      # the consumer, end to end (timesteps/s, not env-steps/s)

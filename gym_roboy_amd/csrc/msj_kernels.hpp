@@ -281,55 +281,15 @@ __device__ __forceinline__ void draw_goal3(const GoalBox &box, uint64_t seed, ui
     for (int j = 0; j < 3; ++j) g[j] = goal_value(box.lo[j], box.hi[j], r.v[j]);
 }
 
-// UNROLL = 0: run-time tendon count (ConstX, c.nt tendons, action rows of c.nt floats)
-template <int INTEG, int BLOCK, int UNROLL, typename CONST = Const8, bool BK = false>
-__global__ void __launch_bounds__(BLOCK)
-msj_env_step_kernel(const CONST c_arg, const EnvParams e, const GoalBox box,
-                    float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
-                    float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
-                    uint32_t *__restrict__ goal_count, const float *__restrict__ act,
-                    float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
-                    double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt, uint32_t *__restrict__ infeas_n,
-                    long n, long cnt, uint64_t seed, uint64_t env0) {
-    // n: the handle's envs = the stride of the state / goal / statistics planes; cnt: the envs of THIS launch - all of them, or a
-    // sub-range (rb_env_step_range_dev: every pointer then points at the range's first env, env0 is its global id)
-    const CONST &c = robot_consts<BK>(c_arg);
-    const long i = long(blockIdx.x) * BLOCK + threadIdx.x;
-    if (i >= cnt) return;
-    float qq[3], vv[3], gg[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { qq[j] = q[j * n + i]; vv[j] = qd[j * n + i]; gg[j] = goal[j * n + i]; }
-    // the reference asserts the action lies in [-1,1] (roboy_env.py:52); a batched kernel
-    // cannot raise, so it clamps.  Then slope * (x - in_high) + out_high, each op rounded
-    // (roboy_env.py:157-158)
-    auto rescale = [&](float a) { return mul_then_add(e.slope, fminf(fmaxf(a, -1.0f), 1.0f) - 1.0f, e.act_hi); };
-    bool ok;
-    if constexpr (UNROLL == 0) {
-        __shared__ float lds_sp[NTX][BLOCK];
-        const int nt = c.nt;
-        const float *row = act + i * nt;
-        for (int k = 0; k < nt; ++k) lds_sp[k][threadIdx.x] = rescale(row[k]) * c.ten[k].ksg;
-        ok = rb::MsjModel<float, NTX>::template step_sp<INTEG, 0>(c, qq, vv, SpLds{&lds_sp[0][threadIdx.x], BLOCK});
-    } else {
-    float sp[NT8];
-    const float4 a0 = reinterpret_cast<const float4 *>(act)[2 * i];
-    const float4 a1 = reinterpret_cast<const float4 *>(act)[2 * i + 1];
-    const float a[NT8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-    for (int k = 0; k < NT8; ++k) sp[k] = rescale(a[k]) * c.ten[k].ksg;   // set-point -> activation offset
-    if (UNROLL == RS) {
-        ok = rb::MsjModel<float, NT8>::template step_rs<INTEG>(c, qq, vv, sp);
-    } else if (UNROLL >= NT8) {
-        ok = rb::MsjModel<float, NT8>::template step_sp<INTEG, UNROLL>(c, qq, vv, rb::SpArray<float, NT8>{sp});
-    } else {
-        // rolled tendon loop: the set-points are indexed at run time, keep them as an LDS column
-        // (as msj_step_env_per_lane does); each lane reads back only what it wrote
-        __shared__ float lds_sp[NT8][BLOCK];
-#pragma unroll
-        for (int k = 0; k < NT8; ++k) lds_sp[k][threadIdx.x] = sp[k];
-        ok = rb::MsjModel<float, NT8>::template step_sp<INTEG, UNROLL>(c, qq, vv, SpLds{&lds_sp[0][threadIdx.x], BLOCK});
-    }
-    }
+// What RoboyEnv.step does around the simulator's answer for env i of this launch (qq, vv: the new state; gg: the env's goal; ok:
+// feasible): reward, done, episode accounting, goal redraw / reset on done, and every row back.  Shared by the env-per-lane
+// kernel and the two-lanes-per-env kernel (whose even lanes call it).
+__device__ __forceinline__ void env_account(const EnvParams &e, const GoalBox &box, long i, long n, float (&qq)[3], float (&vv)[3], float (&gg)[3], bool ok,
+                                            float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
+                                            float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
+                                            uint32_t *__restrict__ goal_count, float *__restrict__ obs, float *__restrict__ reward,
+                                            uint32_t *__restrict__ done, double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt,
+                                            uint32_t *__restrict__ infeas_n, uint64_t seed, uint64_t env0) {
     uint32_t sn = step_num[i] + 1u;
 
     // reward (roboy_env.py:92-112), fp32.  The normalisation (2v - hi - lo)/(hi - lo)
@@ -385,6 +345,105 @@ msj_env_step_kernel(const CONST c_arg, const EnvParams e, const GoalBox box,
     *reinterpret_cast<f4u *>(orow + 4) = f4u{o[4], o[5], o[6], o[7]};
     orow[8] = o[8];
     reward[i] = r; done[i] = dn ? 1u : 0u;
+}
+
+// UNROLL = 0: run-time tendon count (ConstX, c.nt tendons, action rows of c.nt floats)
+template <int INTEG, int BLOCK, int UNROLL, typename CONST = Const8, bool BK = false>
+__global__ void __launch_bounds__(BLOCK)
+msj_env_step_kernel(const CONST c_arg, const EnvParams e, const GoalBox box,
+                    float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
+                    float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
+                    uint32_t *__restrict__ goal_count, const float *__restrict__ act,
+                    float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
+                    double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt, uint32_t *__restrict__ infeas_n,
+                    long n, long cnt, uint64_t seed, uint64_t env0) {
+    // n: the handle's envs = the stride of the state / goal / statistics planes; cnt: the envs of THIS launch - all of them, or a
+    // sub-range (rb_env_step_range_dev: every pointer then points at the range's first env, env0 is its global id)
+    const CONST &c = robot_consts<BK>(c_arg);
+    const long i = long(blockIdx.x) * BLOCK + threadIdx.x;
+    if (i >= cnt) return;
+    float qq[3], vv[3], gg[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { qq[j] = q[j * n + i]; vv[j] = qd[j * n + i]; gg[j] = goal[j * n + i]; }
+    // the reference asserts the action lies in [-1,1] (roboy_env.py:52); a batched kernel
+    // cannot raise, so it clamps.  Then slope * (x - in_high) + out_high, each op rounded
+    // (roboy_env.py:157-158)
+    auto rescale = [&](float a) { return mul_then_add(e.slope, fminf(fmaxf(a, -1.0f), 1.0f) - 1.0f, e.act_hi); };
+    bool ok;
+    if constexpr (UNROLL == 0) {
+        __shared__ float lds_sp[NTX][BLOCK];
+        const int nt = c.nt;
+        const float *row = act + i * nt;
+        for (int k = 0; k < nt; ++k) lds_sp[k][threadIdx.x] = rescale(row[k]) * c.ten[k].ksg;
+        ok = rb::MsjModel<float, NTX>::template step_sp<INTEG, 0>(c, qq, vv, SpLds{&lds_sp[0][threadIdx.x], BLOCK});
+    } else {
+    float sp[NT8];
+    const float4 a0 = reinterpret_cast<const float4 *>(act)[2 * i];
+    const float4 a1 = reinterpret_cast<const float4 *>(act)[2 * i + 1];
+    const float a[NT8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+    for (int k = 0; k < NT8; ++k) sp[k] = rescale(a[k]) * c.ten[k].ksg;   // set-point -> activation offset
+    if (UNROLL == RS) {
+        ok = rb::MsjModel<float, NT8>::template step_rs<INTEG>(c, qq, vv, sp);
+    } else if (UNROLL >= NT8) {
+        ok = rb::MsjModel<float, NT8>::template step_sp<INTEG, UNROLL>(c, qq, vv, rb::SpArray<float, NT8>{sp});
+    } else {
+        // rolled tendon loop: the set-points are indexed at run time, keep them as an LDS column
+        // (as msj_step_env_per_lane does); each lane reads back only what it wrote
+        __shared__ float lds_sp[NT8][BLOCK];
+#pragma unroll
+        for (int k = 0; k < NT8; ++k) lds_sp[k][threadIdx.x] = sp[k];
+        ok = rb::MsjModel<float, NT8>::template step_sp<INTEG, UNROLL>(c, qq, vv, SpLds{&lds_sp[0][threadIdx.x], BLOCK});
+    }
+    }
+    env_account(e, box, i, n, qq, vv, gg, ok, q, qd, feas, goal, step_num, ep_ret, goal_count, obs, reward, done, ep_sum, ep_cnt, infeas_n, seed, env0);
+}
+
+
+// The fused env layer in the two-lanes-per-env form (round 5; msj_step_mirror_pairs above): both lanes of a pair load the env's
+// state, each rescales and evaluates ITS four tendons (the odd lane steps the mirrored env), and behind the integrator the even
+// lane - which holds the env itself - does the accounting of env_account() while the odd lane is done.  What the mid-size
+// batches of a PPO rollout (12 288 - 32 768 envs, RK4) step with: the plain step's mirror-pair form takes 4.5 us there against
+// 5.2 for one env per lane (profiles/r4_a/mid_sweep.log) and the env layer used to be an env-per-lane kernel whatever the step was.
+template <int INTEG, int BLOCK, int MIRROR, bool BK = false>
+__global__ void __launch_bounds__(BLOCK)
+msj_env_step_mirror_pairs(const Const8 c_arg, const PairMap pm, const EnvParams e, const GoalBox box,
+                          float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
+                          float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
+                          uint32_t *__restrict__ goal_count, const float *__restrict__ act,
+                          float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
+                          double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt, uint32_t *__restrict__ infeas_n,
+                          long n, long cnt, uint64_t seed, uint64_t env0) {
+    const Const8 &c = robot_consts<BK>(c_arg);
+    const long wg0 = long(blockIdx.x) * (BLOCK / 2);
+    const long left = cnt - wg0;
+    const int live = int(left < BLOCK / 2 ? left : BLOCK / 2);
+    const int le = int(threadIdx.x >> 1);      // the pair's env within the workgroup
+    if (le >= live) return;                    // whole pairs leave together
+    const bool odd = (threadIdx.x & 1) != 0;
+    const int off = le * 4, oddi = int(threadIdx.x & 1);
+    const long i = wg0 + le;
+    float qq[3], vv[3], gg[3], u[4];
+    const __amdgpu_buffer_rsrc_t ra = wg_rsrc(act + wg0 * NT8, live * NT8 * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // clamp, slope * (x - in_high) + out_high with two roundings (roboy_env.py:157-158), then set-point -> activation offset
+        const float a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, off * NT8 + pm.a[k] + oddi * pm.d[k], 0, 0));
+        u[k] = mul_then_add(e.slope, fminf(fmaxf(a, -1.0f), 1.0f) - 1.0f, e.act_hi) * c.ten[k].ksg;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        qq[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wg_rsrc(q + j * n + wg0, live * 4), off, 0, 0));
+        vv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wg_rsrc(qd + j * n + wg0, live * 4), off, 0, 0));
+        gg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wg_rsrc(goal + j * n + wg0, live * 4), off, 0, 0));
+    }
+    constexpr int F0 = MIRROR == 0 ? 0 : 1, F1 = 2;
+    const uint32_t flip = odd ? 0x80000000u : 0u;
+    qq[F0] = __uint_as_float(__float_as_uint(qq[F0]) ^ flip); vv[F0] = __uint_as_float(__float_as_uint(vv[F0]) ^ flip);
+    qq[F1] = __uint_as_float(__float_as_uint(qq[F1]) ^ flip); vv[F1] = __uint_as_float(__float_as_uint(vv[F1]) ^ flip);
+    const bool ok = rb::MsjModel<float, NT8>::template integrate_acc<INTEG>(c, qq, vv, AccelMirrorHalf<MIRROR>{c, u});
+    if (odd) return;                           // the even lane holds the env itself
+    env_account(e, box, i, n, qq, vv, gg, ok, q, qd, feas, goal, step_num, ep_ret, goal_count, obs, reward, done, ep_sum, ep_cnt, infeas_n, seed, env0);
 }
 
 

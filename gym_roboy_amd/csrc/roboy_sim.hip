@@ -806,6 +806,25 @@ int auto_kernel(const rb_sim *s) {
     return s->n <= (euler ? RB_TENDON_LANE_BATCH_EULER : RB_TENDON_LANE_BATCH_RK4) ? RB_KERNEL_TENDON_PER_LANE : RB_KERNEL_ENV_PER_LANE;
 }
 
+// The form the fused env layer of an 8-tendon ball-joint robot takes: two lanes per env where the robot has a mirror plane and
+// the batch is small enough that the shorter instruction chain per wave is what counts (measured with a 50-step graph,
+// profiles/r5_a/env_pairs_sweep.log, us per env step, one env per lane -> two lanes per env: RK4 4 096 envs 5.49 -> 4.52,
+// 16 384 envs 5.69 -> 4.71, 32 768 envs 6.05 -> 5.17, 49 152 envs 6.44 -> 7.02; Euler 4 096 envs 2.90 -> 2.81, 16 384 envs
+// 3.07 -> 2.97, 32 768 envs 3.43 -> 3.46).  The env layer has no eight-lanes-per-env form, so - unlike the plain step -
+// there is no lower bound.  An explicit rb_select_kernel decides otherwise: 5 = this form, 1 / 2 = one env per lane.
+#ifndef RB_PAIR_ENV_BATCH_EULER
+#define RB_PAIR_ENV_BATCH_EULER 24576
+#endif
+#ifndef RB_PAIR_ENV_BATCH_RK4
+#define RB_PAIR_ENV_BATCH_RK4 32768
+#endif
+bool env_uses_pairs(const rb_sim *s) {
+    if (s->tree || s->ntx || !s->pair_ok) return false;
+    if (s->kernel_choice == RB_KERNEL_LANE_PAIR) return true;
+    if (s->kernel_choice != RB_KERNEL_AUTO) return false;
+    return s->n <= (s->integrator == RB_EULER ? RB_PAIR_ENV_BATCH_EULER : RB_PAIR_ENV_BATCH_RK4);
+}
+
 int check(const rb_sim *s) {
     if (!s) return fail(RB_EINVAL, "null simulation handle");
     return RB_OK;
@@ -1102,6 +1121,16 @@ int rb_debug_tree_fetch(rb_sim *s, float *out, int n_floats, rbt::TreeDev *dev_o
 extern "C" int rb_debug_stamps(unsigned long long *out) {
     RB_HIP(hipDeviceSynchronize());
     RB_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(rbl_stamp_buf), sizeof(unsigned long long) * 8 * 128));
+    return RB_OK;
+}
+#endif
+
+#ifdef RB_LANE_STAMPS
+// diagnostic builds only: the phase stamps of the one-wave joint-tree kernels (tree_lane.hpp), RBL_STAMP_WAVES waves x 4 x (100 MHz clock, shader clock)
+extern "C" int rb_debug_lane_stamps(unsigned long long *out, int n_words) {
+    RB_HIP(hipDeviceSynchronize());
+    const size_t all = sizeof(unsigned long long) * RBL_STAMP_WAVES * 8, want = sizeof(unsigned long long) * size_t(n_words);
+    RB_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(rbl_baked::rbl_lane_stamp_buf), want < all ? want : all));
     return RB_OK;
 }
 #endif
@@ -1611,6 +1640,24 @@ static int env_step_launch(rb_sim *s, long i0, long cnt, hipStream_t stream, con
     hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, 0, ConstX>), dim3(blocks_for(cnt, B)), dim3(B), 0, stream, s->cx, RB_ENV_ARGS)
 #define RB_ENV_LAUNCH_BK(INTEG, B, U)                                                                    \
     hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, U, Const8, true>), dim3(blocks_for(cnt, B)), dim3(B), 0, stream, s->c8, RB_ENV_ARGS)
+    if (env_uses_pairs(s)) {
+        // two lanes per env (robots with a mirror plane: the library's choice up to mid-size batches, or rb_select_kernel)
+        PairMap pm;
+        for (int k = 0; k < 4; ++k) { pm.a[k] = 4 * s->pair_half[k]; pm.d[k] = 4 * (s->pair_image[k] - s->pair_half[k]); }
+#define RB_PAIR_ENV_LAUNCH(INTEG, B, M, BKF)                                                                          \
+    hipLaunchKernelGGL((msj_env_step_mirror_pairs<INTEG, B, M, BKF>), dim3(blocks_for(2 * cnt, B)), dim3(B), 0, stream, s->c8p, pm, RB_ENV_ARGS)
+#define RB_PAIR_ENV_LAUNCH_B(INTEG, M, BKF)                                                                           \
+    do { if (n <= RB_PAIR_SMALL_BATCH) RB_PAIR_ENV_LAUNCH(INTEG, 64, M, BKF); else RB_PAIR_ENV_LAUNCH(INTEG, 256, M, BKF); } while (0)
+#define RB_PAIR_ENV_LAUNCH_M(INTEG, BKF)                                                                              \
+    do { if (s->pair_mirror == 0) RB_PAIR_ENV_LAUNCH_B(INTEG, 0, BKF); else RB_PAIR_ENV_LAUNCH_B(INTEG, 1, BKF); } while (0)
+        if (s->pair_baked) { if (s->integrator == RB_EULER) RB_PAIR_ENV_LAUNCH_M(0, true); else RB_PAIR_ENV_LAUNCH_M(1, true); }
+        else               { if (s->integrator == RB_EULER) RB_PAIR_ENV_LAUNCH_M(0, false); else RB_PAIR_ENV_LAUNCH_M(1, false); }
+#undef RB_PAIR_ENV_LAUNCH_M
+#undef RB_PAIR_ENV_LAUNCH_B
+#undef RB_PAIR_ENV_LAUNCH
+        RB_HIP(hipGetLastError());
+        return RB_OK;
+    }
     maybe_jit(s);
     if (s->jit_state == 1) {
         // msj_env_step_kernel<INTEG, 256, 8 / RS, Const8, true> of this robot's own module; same parameter list

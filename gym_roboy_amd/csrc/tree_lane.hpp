@@ -212,6 +212,23 @@ __device__ __forceinline__ void store_outputs(float *__restrict__ gq, float *__r
     lane_wave_sync();
 }
 
+#if defined(RB_LANE_STAMPS)
+// diagnostic builds only (tools/lane_stamps.py): per wave (the first RBL_STAMP_WAVES workgroups) the constant 100 MHz clock and the
+// shader clock at the kernel's entry, behind the input rows, behind the step and behind the output rows; rb_debug_lane_stamps
+// fetches the buffer.  No product build defines RB_LANE_STAMPS.
+#define RBL_STAMP_WAVES 4096
+__device__ unsigned long long rbl_lane_stamp_buf[RBL_STAMP_WAVES * 8];
+__device__ __forceinline__ void rbl_lane_stamp(int k) {
+    if (blockIdx.x < RBL_STAMP_WAVES && threadIdx.x == 0) {
+        rbl_lane_stamp_buf[blockIdx.x * 8 + 2 * k] = __builtin_amdgcn_s_memrealtime();
+        rbl_lane_stamp_buf[blockIdx.x * 8 + 2 * k + 1] = __builtin_amdgcn_s_memtime();
+    }
+}
+#define RBL_LANE_STAMP(k) rbl_lane_stamp(k)
+#else
+#define RBL_LANE_STAMP(k)
+#endif
+
 // forward_step_command for a batch: act rows are set-points scaled by act_scale (tree_step_aba's contract)
 template <int INTEG>
 __global__ void __launch_bounds__(64)
@@ -225,15 +242,19 @@ tree_lane_step(float *__restrict__ q, float *__restrict__ qd, uint32_t *__restri
     float *region = lds_lane;
     const LaneLds L{region + lane};
     float qq[RBL_NQ], vv[RBL_NQ], spu[RBL_NT], none[RBL_NQ];
+    RBL_LANE_STAMP(0);
     load_inputs<false>(q, qd, act, nullptr, env0, live, region, lane, qq, vv, spu, none);
+    RBL_LANE_STAMP(1);
 #pragma unroll
     for (int k = 0; k < RBL_NT; ++k) spu[k] = rbe::rounded_here((spu[k] * act_scale) * KSG[k]);
     const bool ok = lane_step<INTEG>(L, spu, h, nsub, qq, vv);
+    RBL_LANE_STAMP(2);
     {
         float no_obs[3 * RBL_NQ];
         store_outputs<false>(q, qd, nullptr, env0, live, region, lane, qq, vv, no_obs);
     }
     if (lane < live) feas[env0 + lane] = ok ? 1u : 0u;
+    RBL_LANE_STAMP(3);
 }
 
 // RoboyEnv.step fused around the step (semantics of tree_env_step_aba / msj_env_step_kernel)
@@ -257,7 +278,9 @@ tree_lane_env_step(const rbe::TreeEnvArgs a) {
     float *region = lds_lane;
     const LaneLds L{region + lane};
     float qq[RBL_NQ], vv[RBL_NQ], spu[RBL_NT], gg[RBL_NQ];
+    RBL_LANE_STAMP(0);
     load_inputs<true>(q, qd, act, goal, env0, live, region, lane, qq, vv, spu, gg);
+    RBL_LANE_STAMP(1);
     // the env's counters, requested now as well (their latency passes behind the acceleration)
     const bool mine = lane < live;
     const long me = env0 + (mine ? lane : live - 1);
@@ -271,6 +294,7 @@ tree_lane_env_step(const rbe::TreeEnvArgs a) {
         spu[k] = rbe::rounded_here(rbe::mul_then_add(slope, x - 1.0f, act_hi) * KSG[k]);
     }
     const bool ok = lane_step<INTEG>(L, spu, h, nsub, qq, vv);
+    RBL_LANE_STAMP(2);
     const rbe::tree_env_kernarg_ptr late = rbe::late_args();
     const rbe::EnvParams ep = rbe::late_env_params(late);
     const uint64_t seed = late->seed, env_id0 = late->env_id0;
@@ -334,6 +358,7 @@ tree_lane_env_step(const rbe::TreeEnvArgs a) {
         // (an atomic that returns nothing: a load-add-store here is a memory latency the wave - alone on its SIMD - sits out)
         if (!ok) __hip_atomic_fetch_add(&late->infeas_n[me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    RBL_LANE_STAMP(3);
 }
 
 }  // namespace RBL_NS

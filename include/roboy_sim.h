@@ -144,6 +144,20 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator,
               int64_t env_id_offset, rb_sim **out);
 void rb_destroy(rb_sim *sim);
 int rb_info(const rb_sim *sim, rb_sim_info *info);
+/* rb_select_kernel: pin the kernel form (RB_KERNEL_*), or hand the choice back to the library (RB_KERNEL_AUTO, the default).
+ * What is bit-equal to what: every form evaluates the same model (each passes the same parity tests against the fp64 oracle,
+ * 2e-5), but the forms order their floating-point sums differently, so results are BIT-identical only within one form -
+ *   - across batch splits (env_id_offset shards, sub-ranges, rollout chains): bit-identical as long as every piece runs the
+ *     same form.  RB_KERNEL_AUTO chooses by the HANDLE's batch size (ball joints with a mirror plane: eight lanes per env up to
+ *     4 096 / 12 288 envs for Euler / RK4, two lanes per env up to 16 384 / 32 768, one env per lane above), so shards on either
+ *     side of a threshold agree to ~1 ulp per step, not bit for bit: pin the form (the same rb_select_kernel on every
+ *     handle) where bit equality across shard sizes is wanted;
+ *   - rb_env_step_dev against rb_step_dev + the reference's env arithmetic: bit-identical states when the handle's form is
+ *     pinned to 1 or 5.  Under RB_KERNEL_AUTO the env layer chooses for itself (it has no eight-lanes form): two lanes per
+ *     env up to 24 576 / 32 768 envs (robots with a mirror plane), one env per lane otherwise;
+ *   - the env-per-lane form itself has two instances by the handle's batch size: up to 65 536 envs (64-thread workgroups,
+ *     tendon loop written out) and above (256-thread workgroups; RK4: the stages as a rolled loop over running sums) - equal to
+ *     ~1 ulp, bit-identical only among handles on the same side of 65 536 envs. */
 int rb_select_kernel(rb_sim *sim, int kernel);
 /* How the env-per-lane kernels of this handle get the robot's constants: RB_SPEC_NONE = through the kernarg
  * (scalar loads); RB_SPEC_TABLE = instances compiled ahead of time on the reference's MsjRobot (the handle's

@@ -11,14 +11,14 @@ from oracle import philox_np as ph
 
 
 class HipStepper:
-    def __init__(self, robot, n, seed, env_id_offset=0, integrator="euler"):
+    def __init__(self, robot, n, seed, env_id_offset=0, integrator="euler", kernel=1):
         from gym_roboy_amd.envs.simulations import HipBatchSimulation
         self.sim = HipBatchSimulation(robot, n, seed=seed, env_id_offset=env_id_offset, integrator=integrator)
-        # the fused env kernel evaluates the env-per-lane arithmetic; use the same
-        # form here so states can be compared bit for bit (the tendon-per-lane
-        # form sums the 8 tendon torques in a different order)
+        # the fused env kernel evaluates the env-per-lane arithmetic (kernel = 1), or - where the handle's plain step takes the
+        # two-lanes-per-env form - that one (kernel = 5); use the same form here so states can be compared bit for bit (the
+        # tendon-per-lane form sums the 8 tendon torques in a different order)
         if robot.get_description().n_q == 3:
-            self.sim.select_kernel(1)
+            self.sim.select_kernel(kernel)
         # (joint trees: the plain step and the fused env kernel take the same form on their own - the batch size decides)
 
     def step(self, sp):

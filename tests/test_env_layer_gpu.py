@@ -19,17 +19,23 @@ pytestmark = pytest.mark.gpu
 from host_env_model import HipStepper, HostEnvModel
 
 
-@pytest.mark.parametrize("n,integrator,auto_reset,vel_penalty", [
-    (777, "euler", True, False), (777, "euler", True, True), (777, "euler", False, False), (777, "euler", False, True),
-    (777, "rk4", True, True),
+@pytest.mark.parametrize("n,integrator,auto_reset,vel_penalty,form", [
+    (777, "euler", True, False, 1), (777, "euler", True, True, 1), (777, "euler", False, False, 1), (777, "euler", False, True, 1),
+    (777, "rk4", True, True, 1),
     # above 65 536 envs the fused kernel switches to its rolled-loop form (256-thread workgroups, LDS set-points)
-    (70001, "euler", True, True), (70001, "rk4", True, False)])
-def test_fused_env_step_matches_host_replay(msj_robot, n, integrator, auto_reset, vel_penalty):
+    (70001, "euler", True, True, 1), (70001, "rk4", True, False, 1),
+    # the two-lanes-per-env form (round 5): chosen explicitly, and by the library (form 0: nothing selected on the env's
+    # handle) for MsjRobot up to 24 576 envs (Euler) / 32 768 envs (RK4) - also where the plain step takes eight lanes per env
+    (777, "rk4", True, True, 5), (777, "euler", False, True, 5), (777, "rk4", True, False, 0), (9001, "euler", True, False, 0),
+    (20001, "rk4", True, True, 0), (32768, "rk4", True, True, 0)])
+def test_fused_env_step_matches_host_replay(msj_robot, n, integrator, auto_reset, vel_penalty, form):
     from gym_roboy_amd.envs.vec_env import RoboyVecEnv
     seed, max_len = 5, 12
     vec = RoboyVecEnv(msj_robot, n, seed=seed, joint_vel_penalty=vel_penalty, auto_reset=auto_reset,
                       max_episode_length=max_len, integrator=integrator)
-    host = HostEnvModel(msj_robot, HipStepper(msj_robot, n, seed, integrator=integrator), n, seed, max_len,
+    if form:
+        vec.sim.select_kernel(form)                   # 1: one env per lane, 5: two lanes per env; 0: the library's choice
+    host = HostEnvModel(msj_robot, HipStepper(msj_robot, n, seed, integrator=integrator, kernel=5 if form != 1 else 1), n, seed, max_len,
                         vel_penalty, True, auto_reset)
     obs0 = vec.reset()
     # vec.__init__ drew goal 0 (configure), reset() drew goal 1: mirror RoboyEnv(...) then reset()
@@ -58,6 +64,40 @@ def test_fused_env_step_matches_host_replay(msj_robot, n, integrator, auto_reset
     got = np.array([st[k] for k in ("sum_return", "sum_return_sq", "n_episodes", "sum_length", "n_goal_reached",
                                     "n_infeasible_steps", "n_env_steps", "sum_reward")])
     np.testing.assert_allclose(got, host.stats, rtol=1e-4, atol=1e-2)
+    vec.close(); host.stepper.close()
+
+
+def test_fused_env_step_in_pair_form_on_kernarg_constants_and_the_other_mirror_plane(msj_robot):
+    """MsjRobot turned by 90 degrees about z (mirror plane y-z, constants not the baked table's): the two-lanes-per-env env
+    kernel's kernarg instance against the host replay over the plain step in the same form - bit for bit."""
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    from test_mirror_pairs import _rotated_msj
+    desc = _rotated_msj()
+
+    class Turned(type(msj_robot)):
+        @classmethod
+        def get_description(cls):
+            return desc
+    robot = Turned()
+    n, seed, max_len = 1500, 8, 10
+    vec = RoboyVecEnv(robot, n, seed=seed, joint_vel_penalty=True, auto_reset=True, max_episode_length=max_len, integrator="rk4")
+    vec.sim.select_kernel(5)
+    host = HostEnvModel(robot, HipStepper(robot, n, seed, integrator="rk4", kernel=5), n, seed, max_len, True, True, True)
+    obs0 = vec.reset()
+    host.goal = host.draw(np.ones(n, bool))
+    assert np.array_equal(obs0[:, 6:], host.goal)
+    rng = np.random.default_rng(1)
+    n_done = 0
+    for t in range(25):
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        obs, rew, done, _ = vec.step(a)
+        h_obs, h_rew, h_done, margin = host.step(a)
+        assert np.array_equal(done, h_done) or (margin[done != h_done] < 1e-5).all()
+        assert np.array_equal(done, h_done)
+        assert np.array_equal(obs, h_obs.astype(np.float32))
+        np.testing.assert_allclose(rew, h_rew, rtol=2e-5, atol=2e-4)
+        n_done += int(done.sum())
+    assert n_done >= 2 * n and vec.stats()["n_episodes"] == n_done
     vec.close(); host.stepper.close()
 
 

@@ -427,6 +427,48 @@ def test_sharding_is_invisible(msj_robot):
         s.close()
 
 
+@pytest.mark.parametrize("integrator", ["rk4", "euler"])
+def test_shards_on_either_side_of_the_auto_thresholds(msj_robot, integrator):
+    """ADVICE (round 4): RB_KERNEL_AUTO picks the kernel form by the HANDLE's batch size, so shards whose sizes straddle
+    the thresholds (RK4 12 288 / 32 768 envs, Euler 4 096 / 16 384) run other forms than the whole batch: equal to a few ulp per
+    step (the forms order their sums differently), and BIT-equal once every handle is pinned to one form - the contract written
+    in include/roboy_sim.h at rb_select_kernel."""
+    # eight lanes / two lanes / one lane per env; 65 536 envs in all: the env-per-lane form has two instances, one up to 65 536 envs
+    # per handle (64-thread workgroups, tendons unrolled) and one above (256 threads, RK4 stages rolled: equal to ~1 ulp) - the
+    # pinned comparison stays inside the first
+    sizes = (8192, 20480, 36864) if integrator == "rk4" else (2048, 10240, 53248)
+    total = sum(sizes)
+    offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+
+    def run(sim, steps=3):
+        d = sim.malloc(4 * sim.n_envs * 8)
+        for t in range(steps):
+            sim.fill_actions_dev(d, t)
+            sim.step_dev(d, 0.3)
+        sim.synchronize()
+        return sim.read_state()
+
+    for pinned in (False, True):
+        whole = _sim(msj_robot, total, seed=3, integrator=integrator)
+        parts = [_sim(msj_robot, n, seed=3, env_id_offset=int(o), integrator=integrator) for n, o in zip(sizes, offsets)]
+        if pinned:
+            for s in [whole] + parts:
+                s.select_kernel(KERNELS["env_per_lane"])
+        else:
+            assert whole.info()["kernel"] == KERNELS["env_per_lane"]
+            assert [p.info()["kernel"] for p in parts] == [KERNELS["tendon_per_lane"], KERNELS["lane_pair"], KERNELS["env_per_lane"]]
+        qw, qdw, fw = run(whole)
+        res = [run(p) for p in parts]
+        qp, qdp = np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res])
+        if pinned:
+            assert np.array_equal(qw, qp) and np.array_equal(qdw, qdp)
+        else:
+            assert np.abs(qw - qp).max() < 3e-6 and np.abs(qdw - qdp).max() < 3e-5       # a few ulp of O(1) angles per step, three steps
+            assert not (np.array_equal(qw, qp) and np.array_equal(qdw, qdp))              # (the forms do differ in the last bits)
+        for s in [whole] + parts:
+            s.close()
+
+
 def test_pushing_into_the_boundary_becomes_and_stays_infeasible(msj_robot):
     """Restates test_simulation_client.py:54-68 for the batched client."""
     sim = _sim(msj_robot, 4)
