@@ -143,6 +143,9 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // RB_SPLIT_HELPER_SHARE is then the distal waves' share of the tendons).  SPLIT_CUT there.  Measured and NOT selected: 22 % fewer
 // vector instructions on the longest path of the upper body, and 10.2 / 30.1 us against 8.84 / 25.1 - all five waves are busy at once
 // there, and the two that share a SIMD run at 7 cycles per instruction instead of 5.5 (profiles/r4_a/cut_form.log).
+#ifndef RB_SPLIT_MAX_PARTS
+#define RB_SPLIT_MAX_PARTS 4      // part waves per env group at most (the upper body has three branches: three parts)
+#endif
 #ifndef RB_SPLIT_CUT
 #define RB_SPLIT_CUT 0
 #endif
@@ -957,11 +960,11 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
             std::string why_gen;
             s->lane_ok = rblg::generate(robot, true, s->lane_gen, why_gen) == RB_OK;
             s->lane_baked = s->lane_ok && s->lane_gen.hash == RBL_TEXT_HASH && rblg::lane_lds_slots(s->lane_gen) == rbl_baked::LDS_SLOTS;
-            s->split_ok = (RB_SPLIT_CUT ? rblg::generate_split_cut(robot, 4, s->split_gen, why_gen, RB_SPLIT_HELPERS, RB_SPLIT_HELPER_SHARE)
-                                        : rblg::generate_split(robot, 4, s->split_gen, why_gen, RB_SPLIT_HELPERS, RB_SPLIT_HELPER_SHARE, RB_SPLIT_TWO_SWEEPS != 0, RB_SPLIT_SHARE_TRUNK != 0)) == RB_OK &&
+            s->split_ok = (RB_SPLIT_CUT ? rblg::generate_split_cut(robot, RB_SPLIT_MAX_PARTS, s->split_gen, why_gen, RB_SPLIT_HELPERS, RB_SPLIT_HELPER_SHARE)
+                                        : rblg::generate_split(robot, RB_SPLIT_MAX_PARTS, s->split_gen, why_gen, RB_SPLIT_HELPERS, RB_SPLIT_HELPER_SHARE, RB_SPLIT_TWO_SWEEPS != 0, RB_SPLIT_SHARE_TRUNK != 0)) == RB_OK &&
                           split_lds_bytes(s->split_gen) <= 160 * 1024;
             if (!s->split_ok && RB_SPLIT_HELPERS > 0)        // (the exchange area of the helper form does not fit: the three-barrier-less form)
-                s->split_ok = rblg::generate_split(robot, 4, s->split_gen, why_gen, 0) == RB_OK;
+                s->split_ok = rblg::generate_split(robot, RB_SPLIT_MAX_PARTS, s->split_gen, why_gen, 0) == RB_OK;
             // (... and the host's LDS formula is the kernels': a launch with less LDS than tree_lane_split.hpp lays out would write past it)
             s->split_baked = s->split_ok && s->split_gen.hash == RBL_SPLIT_TEXT_HASH && s->split_gen.n_parts == RBL_NPARTS &&
                              s->split_gen.n_helpers == RBL_NHELPERS && split_lds_bytes(s->split_gen) == size_t(rbl_split_baked::SP_LDS_BYTES);

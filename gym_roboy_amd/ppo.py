@@ -292,11 +292,15 @@ def adam_state_torch_to_flat(sd, policy, layout, m, v):
     slices = _param_slices(policy, layout)
     if len(order) != len(slices):
         raise ValueError("optimiser state of another module: %d parameters, this policy has %d" % (len(order), len(slices)))
+    # every parameter or none: moments of some parameters under ONE step count would resume the others with zero moments and a
+    # bias correction that assumes they have been stepping all along
+    missing = [idx for idx in order if state.get(idx) is None]
+    if missing:
+        raise ValueError("partial optimiser state: %d of %d parameters carry no moments (a torch.optim.Adam that stepped only some of "
+                         "its parameters cannot be converted to the flat form)" % (len(missing), len(order)))
     t = 0
     for idx, (off, shape) in zip(order, slices):
-        st = state.get(idx)
-        if st is None:
-            continue
+        st = state[idx]
         if tuple(st["exp_avg"].shape) != tuple(shape):
             raise ValueError("optimiser state of another policy layout: %r against %r" % (tuple(st["exp_avg"].shape), tuple(shape)))
         n = int(st["exp_avg"].numel())
@@ -463,10 +467,21 @@ class PPO:
         self._rollout_tail(b)
 
     def _pick_chains(self, N):
-        if self._fused is None or not hasattr(self.env, "step_range_dev") or not self.env.range_capable():
+        asked = self._chains_arg is not None and int(self._chains_arg) >= 2
+        why = None
+        if self._fused is None:
+            why = "the fused policy step is off (fused_policy=False)"
+        elif not hasattr(self.env, "step_range_dev") or not self.env.range_capable():
+            why = "the env's kernel form steps whole batches only"
+        elif asked and N < 512:
+            why = "fewer than 512 envs"
+        if why is not None:
+            if asked:      # an explicit request that cannot be honoured is said, not dropped silently
+                import warnings
+                warnings.warn("rollout_chains=%r not honoured (%s): the rollout runs as one chain" % (self._chains_arg, why), RuntimeWarning, stacklevel=3)
             return 1
         if self._chains_arg is not None:
-            return 2 if int(self._chains_arg) >= 2 and N >= 512 else 1
+            return 2 if asked else 1
         return 2 if N >= self.CHAIN_BATCH and self._fused.obs_dim <= self.CHAIN_MAX_OBS else 1
 
     def _build_rollout_graph(self):

@@ -118,6 +118,40 @@ def test_adam_state_moves_between_the_two_optimiser_forms():
     assert adam_state_torch_to_flat(torch.optim.Adam(policy.parameters()).state_dict(), policy, layout, m, v) is None
     with pytest.raises(ValueError):
         adam_state_torch_to_flat(opt.state_dict(), MlpPolicy(5, 8), pn.grad_layout(5, 8)[0], m, v)
+    # ADVICE (round 4): an optimiser that stepped only SOME of its parameters is refused (its moments under one step count would
+    # resume the others with zero moments and a wrong bias correction)
+    partial = opt.state_dict()
+    del partial["state"][0]
+    with pytest.raises(ValueError, match="partial optimiser state"):
+        adam_state_torch_to_flat(partial, policy, layout, m, v)
+
+
+def test_an_explicit_chain_request_that_cannot_be_honoured_warns():
+    """ADVICE (round 4): PPO(rollout_chains=2) over an env that cannot step sub-ranges (or without the fused policy step) runs one
+    chain - and says so."""
+    from gym_roboy_amd.ppo import PPO
+
+    class Agent:                      # _pick_chains reads these three attributes only
+        _pick_chains = PPO._pick_chains
+        CHAIN_BATCH, CHAIN_MAX_OBS = PPO.CHAIN_BATCH, PPO.CHAIN_MAX_OBS
+    a = Agent()
+    a._fused, a._chains_arg, a.env = None, 2, object()
+    with pytest.warns(RuntimeWarning, match="fused policy step is off"):
+        assert a._pick_chains(65536) == 1
+    a._fused = type("F", (), {"obs_dim": 9})()
+    with pytest.warns(RuntimeWarning, match="whole batches only"):
+        assert a._pick_chains(65536) == 1
+    a.env = type("E", (), {"step_range_dev": None, "range_capable": lambda self: True})()
+    with pytest.warns(RuntimeWarning, match="fewer than 512"):
+        assert a._pick_chains(256) == 1
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert a._pick_chains(65536) == 2
+        a._chains_arg = None
+        assert a._pick_chains(256) == 1 and a._pick_chains(PPO.CHAIN_BATCH) == 2      # the library's own choice: silent
+        a._chains_arg = 1
+        assert a._pick_chains(1 << 20) == 1
 
 
 @pytest.mark.gpu

@@ -22,7 +22,7 @@ tag = sys.argv[1]
 SRC = os.path.join(ROOT, "gpurun_out", tag)
 DST = os.path.join(ROOT, "profiles", sys.argv[2] if len(sys.argv) > 2 else tag)       # (raw run directory, committed directory)
 os.makedirs(DST, exist_ok=True)
-STEP_KERNELS = ("msj_step_env_per_lane", "msj_step_tendon_per_lane", "msj_step_mirror_pairs", "tree_step_aba", "msj_env_step_kernel",
+STEP_KERNELS = ("msj_step_env_per_lane", "msj_step_tendon_per_lane", "msj_step_mirror_pairs", "msj_env_step_mirror_pairs", "tree_step_aba", "msj_env_step_kernel",
                 "tree_lane_step", "tree_lane_env_step", "tree_env_step_aba", "tree_split_step", "tree_split_env_step")
 
 
@@ -41,7 +41,7 @@ def mean_tail(v, skip=10):
     return sum(v) / len(v), len(v)
 
 
-for name in ("bench_unprofiled.json", "bench_under_rocprof.json", "bench_2rank_gloo.json", "train_rollout_world1.json",
+for name in ("bench_unprofiled.json", "bench_under_rocprof.json", "bench_2rank_gloo.json", "bench_also_unprofiled.json", "train_rollout_world1.json",
              "train_rollout_world2.json", "ppo_update_kernel_stats.txt"):
     p = os.path.join(SRC, name)
     if os.path.exists(p):
