@@ -85,7 +85,7 @@ VALU_PEAK = 157.3e12       # flop/s, fp32 vector peak (MI355X_MICROARCH.md "Peak
 # x 1024 SIMDs / 1.20 ns.  The spec peak is the roof `frac` is quoted against; this is what an all-FMA stream reaches.
 VALU_FMA_MEASURED = 64 * 2 * 1024 / 1.20e-9
 KERNEL_NAMES = {1: "msj_step_env_per_lane", 2: "msj_step_tendon_per_lane", 3: "tree_step_aba", 5: "msj_step_mirror_pairs"}
-TREE_KERNEL_NAMES = {1: "tree_lane_step", 3: "tree_step_aba", 4: "tree_split_step"}   # joint trees: env-per-lane (generated) / octets / several waves per env group
+TREE_KERNEL_NAMES = {1: "tree_lane_step", 3: "tree_step_aba", 4: "tree_split_step", 6: "tree_split_step"}   # joint trees: env-per-lane (generated) / octets / several waves per env group
 PROFILE_DIRS = ("r4_a", "r3_a", "r2_a", "r1_b")   # newest first: where the committed rocprofv3 PMC passes live
 
 
@@ -155,7 +155,7 @@ def parse():
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=None, help="override envs per GPU")
     ap.add_argument("--substeps", type=int, default=None, help="override integrator substeps per env step")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 env-per-lane, 2 tendon-per-lane (ball joints), 3 octets (joint trees), 4 env-per-lane split over several waves (joint trees), 5 two lanes per env (ball joints with a mirror plane)")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 env-per-lane, 2 tendon-per-lane (ball joints), 3 octets (joint trees), 4 env-per-lane split over several waves (joint trees), 5 two lanes per env (ball joints with a mirror plane), 6 the lean two-part split (joint trees, two workgroups per CU)")
     ap.add_argument("--no-graph", action="store_true", help="eager per-step launches instead of hipGraph replay")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -38,6 +38,7 @@
 #include "tree_lane_split.hpp"
 #undef RBL_NS
 #include "tree_lane_jit.hpp"
+#include "tree_lane_split2.hpp"      // the lean two-part split instances: a translation unit of their own (roboy_sim_split2.hip)
 
 namespace {
 
@@ -143,6 +144,18 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // RB_SPLIT_HELPER_SHARE is then the distal waves' share of the tendons).  SPLIT_CUT there.  Measured and NOT selected: 22 % fewer
 // vector instructions on the longest path of the upper body, and 10.2 / 30.1 us against 8.84 / 25.1 - all five waves are busy at once
 // there, and the two that share a SIMD run at 7 cycles per instruction instead of 5.5 (profiles/r4_a/cut_form.log).
+// The lean two-part split form (roboy_sim_split2.hip): two part waves per 64 envs and two workgroups per CU - one generation up to
+// 32 768 envs, where one wave per 64 envs leaves half of the SIMDs idle (16.1 us for the upper body's Euler step) and the five-wave
+// form needs two generations (17.5 us).  Measured: profiles/r5_a/split2_sweep.log.
+#ifndef RB_TREE_SPLIT2_BATCH
+#define RB_TREE_SPLIT2_BATCH 32768
+#endif
+#ifndef RB_SPLIT2_PARTS
+#define RB_SPLIT2_PARTS 2            // (tools/gen_tree_lane_baked.py: SPLIT2_PARTS, SPLIT2_SHARE_TRUNK)
+#endif
+#ifndef RB_SPLIT2_SHARE_TRUNK
+#define RB_SPLIT2_SHARE_TRUNK 1
+#endif
 #ifndef RB_SPLIT_MAX_PARTS
 #define RB_SPLIT_MAX_PARTS 4      // part waves per env group at most (the upper body has three branches: three parts)
 #endif
@@ -449,6 +462,9 @@ struct rb_sim {
     rblg::SplitGenerated split_gen;
     bool split_ok = false, split_baked = false;
     rblj::Kernel split_step_k, split_env_k;
+    // ... and its lean two-part form (two workgroups per CU; ahead-of-time instances only: roboy_sim_split2.hip)
+    rblg::SplitGenerated split2_gen;
+    bool split2_baked = false;
     GoalBox box;
     hipStream_t own_stream = nullptr, stream = nullptr;
     static constexpr int MAX_CHAINS = 4;
@@ -532,6 +548,20 @@ bool tree_wants_split(const rb_sim *s) {
     if (!s->tree || !s->split_ok) return false;
     if (s->kernel_choice == RB_KERNEL_ENV_PER_LANE_SPLIT) return true;
     return s->kernel_choice == RB_KERNEL_AUTO && s->split_baked && s->n <= RB_TREE_SPLIT_BATCH;
+}
+// the lean layout's formula (tree_lane_split.hpp, RBL_LEAN): q | qd | goal, the exchange area over the action / observation image, flags
+size_t split_lean_lds_bytes(const rblg::SplitGenerated &g) {
+    const int img = 3 * g.n_q + (3 * g.n_q > g.n_t ? 3 * g.n_q : g.n_t);
+    int shared = g.x_buffers * g.x_slots > img - 3 * g.n_q ? g.x_buffers * g.x_slots : img - 3 * g.n_q;
+    if (shared < 4 * g.n_q) shared = 4 * g.n_q;
+    return size_t(3 * g.n_q + shared + 3 * g.n_parts + 1) * 64 * 4;
+}
+// does this handle run the lean two-part split form?  An explicit choice, or AUTO between the five-wave form's batch and a wave on
+// every SIMD; ahead-of-time instances only
+bool tree_wants_split2(const rb_sim *s) {
+    if (!s->tree || !s->split2_baked) return false;
+    if (s->kernel_choice == RB_KERNEL_ENV_PER_LANE_SPLIT2) return true;
+    return s->kernel_choice == RB_KERNEL_AUTO && s->n > RB_TREE_SPLIT_BATCH && s->n <= RB_TREE_SPLIT2_BATCH;
 }
 size_t split_lds_bytes(const rblg::SplitGenerated &g) {      // the formula of tree_lane_split.hpp: SP_LDS_BYTES
     const int img = 3 * g.n_q + (3 * g.n_q > g.n_t ? 3 * g.n_q : g.n_t);
@@ -618,6 +648,7 @@ bool tree_use_lane(rb_sim *s, int which);
 // kernel forms that step a sub-range of the batch (shifted pointers, own env count): what chains and the rb_*_range_dev entry points need
 bool range_capable(const rb_sim *s) {
     if (s->tree) {      // the one-wave-per-64-envs form (env-major rows), not the split form and not the octets
+        if (tree_wants_split2(s)) return false;
         if (tree_wants_split(s) && (s->split_baked || s->split_step_k.state == 1)) return false;
         // (asks again on every call: a lane kernel whose build a stream capture deferred becomes available afterwards)
         return tree_use_lane(const_cast<rb_sim *>(s), 0);
@@ -677,7 +708,12 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale, long i0 = 0, lon
 #define RB_STEP_LAUNCH_BK(INTEG, B, U)                                                                \
     launch_baked_step<INTEG, B, U>(blocks_for(cnt, B), stream, s->c8, rq, rqd, rfeas, ract, us, n, cnt)
 
-    if (s->tree && tree_wants_split(s) && (s->split_baked || s->split_step_k.state == 1)) {
+    if (s->tree && tree_wants_split2(s)) {
+        // two part waves per 64 envs, two workgroups per CU (whole batches only)
+        s->kernel = RB_KERNEL_ENV_PER_LANE_SPLIT2;
+        rbs2::launch_step(s->integrator == RB_EULER ? 0 : 1, blocks_for(n, 64), s->stream, s->d_q, s->d_qd, s->d_feas, d_act, act_scale,
+                          s->tree_host.dev.h, s->tree_host.dev.nsub, n);
+    } else if (s->tree && tree_wants_split(s) && (s->split_baked || s->split_step_k.state == 1)) {
         // one workgroup of n_parts (+ helper) waves per 64 envs
         const unsigned groups = blocks_for(n, 64);
         const size_t lds = split_lds_bytes(s->split_gen);
@@ -968,6 +1004,14 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
             // (... and the host's LDS formula is the kernels': a launch with less LDS than tree_lane_split.hpp lays out would write past it)
             s->split_baked = s->split_ok && s->split_gen.hash == RBL_SPLIT_TEXT_HASH && s->split_gen.n_parts == RBL_NPARTS &&
                              s->split_gen.n_helpers == RBL_NHELPERS && split_lds_bytes(s->split_gen) == size_t(rbl_split_baked::SP_LDS_BYTES);
+            // the lean two-part form: only if the text generated for THIS robot is the text the second translation unit was compiled from
+            if (robot->n_q == rbs2::n_q() && robot->n_t == rbs2::n_t()) {
+                std::string why2;
+                s->split2_baked = rblg::generate_split(robot, RB_SPLIT2_PARTS, s->split2_gen, why2, 0, 45, false, RB_SPLIT2_SHARE_TRUNK != 0) == RB_OK &&
+                                  s->split2_gen.hash == rbs2::text_hash() && s->split2_gen.n_parts == rbs2::n_parts() &&
+                                  split_lean_lds_bytes(s->split2_gen) == rbs2::lds_bytes();
+                if (!s->split2_baked) s->split2_gen = rblg::SplitGenerated();      // (the text is not kept for nothing)
+            }
         }
         else why = "not a ball-joint robot (" + why + ") and not a supported joint tree (" + why_tree + ")";
     }
@@ -1148,6 +1192,7 @@ void rb_jit_cache_stats(int64_t *hits, int64_t *compiles, int64_t *stores) {
 int rb_specialization(rb_sim *s) {
     if (check(s)) return -1;
     if (s->tree) {
+        if (tree_wants_split2(s)) return RB_SPEC_TABLE;
         if (tree_wants_split(s)) return s->split_baked ? RB_SPEC_TABLE : (s->split_step_k.state == 1 ? RB_SPEC_JIT : RB_SPEC_NONE);
         if (!tree_wants_lane(s)) { g_err = s->lane_ok ? "the octet kernels are selected (batch below the build threshold, or by choice)" : "no generator for this robot"; return RB_SPEC_NONE; }
         if (s->lane_baked) return RB_SPEC_TABLE;
@@ -1165,7 +1210,9 @@ int rb_specialization(rb_sim *s) {
 int rb_select_kernel(rb_sim *s, int kernel) {
     if (check(s)) return RB_EINVAL;
     // validate first: a refused request leaves the handle as it was (kernel_choice, rb_info, the graph cache)
-    if (kernel < RB_KERNEL_AUTO || kernel > RB_KERNEL_LANE_PAIR) return fail(RB_EINVAL, "unknown kernel variant");
+    if (kernel < RB_KERNEL_AUTO || kernel > RB_KERNEL_ENV_PER_LANE_SPLIT2) return fail(RB_EINVAL, "unknown kernel variant");
+    if (kernel == RB_KERNEL_ENV_PER_LANE_SPLIT2 && !(s->tree && s->split2_baked))
+        return fail(RB_EUNSUPPORTED, "the lean two-part split form exists for the robot the library was built for only (the committed upper body)");
     if (kernel == RB_KERNEL_LANE_PAIR && !(s->pair_ok && !s->tree && !s->ntx))
         return fail(RB_EUNSUPPORTED, "the two-lanes-per-env form needs an 8-tendon ball-joint robot with a mirror plane (tendons in mirror-image pairs, "
                                      "principal-axis inertia, symmetric joint limits)");
@@ -1193,7 +1240,8 @@ int rb_select_kernel(rb_sim *s, int kernel) {
         }
         int rc = drop_graphs(s);             // graphs captured with another variant must not be replayed
         if (rc) { s->kernel_choice = before; return rc; }
-        s->kernel = tree_wants_split(s) ? RB_KERNEL_ENV_PER_LANE_SPLIT : (tree_wants_lane(s) ? RB_KERNEL_ENV_PER_LANE : RB_KERNEL_ENV_PER_WAVE);
+        s->kernel = tree_wants_split2(s) ? RB_KERNEL_ENV_PER_LANE_SPLIT2
+                  : tree_wants_split(s) ? RB_KERNEL_ENV_PER_LANE_SPLIT : (tree_wants_lane(s) ? RB_KERNEL_ENV_PER_LANE : RB_KERNEL_ENV_PER_WAVE);
         return RB_OK;
     }
     if (kernel == RB_KERNEL_ENV_PER_WAVE) return fail(RB_EUNSUPPORTED, "ball-joint robots have no env-per-wave kernel");
@@ -1567,6 +1615,16 @@ int rb_env_set_goal(rb_sim *s, const float *goal_q, const uint32_t *step_num) {
 static int env_step_launch(rb_sim *s, long i0, long cnt, hipStream_t stream, const float *d_act, float *d_obs, float *d_reward, uint32_t *d_done) {
     const long n = s->n;
     const bool whole = i0 == 0 && cnt == n;
+    if (s->tree && tree_wants_split2(s)) {
+        if (!whole) return fail(RB_EUNSUPPORTED, "the split forms of the joint-tree kernels step whole batches only");
+        rbe::TreeEnvArgs ka{s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, s->d_ep_ret, s->d_goal_count, d_act,
+                            d_obs, d_reward, d_done, s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, s->tree_host.dev.h, s->tree_host.dev.nsub, n,
+                            s->seed, uint64_t(s->env0), n};
+        s->kernel = RB_KERNEL_ENV_PER_LANE_SPLIT2;
+        rbs2::launch_env_step(s->integrator == RB_EULER ? 0 : 1, blocks_for(n, 64), stream, ka);
+        RB_HIP(hipGetLastError());
+        return RB_OK;
+    }
     if (s->tree && tree_wants_split(s) && (s->split_baked || build_split_kernel(s, 1))) {
         if (!whole) return fail(RB_EUNSUPPORTED, "the split form of the joint-tree kernels steps whole batches only");
         const unsigned groups = blocks_for(n, 64);
@@ -1738,7 +1796,7 @@ int rb_range_capable(rb_sim *s) {
     if (check(s)) return -1;
     // the fused env layer of the ball-joint class is always an env-per-lane kernel (whatever form the plain step takes);
     // joint trees: the one-wave-per-64-envs form, not the split form and not the octets
-    const bool env = s->tree ? (!tree_wants_split(s) && tree_use_lane(s, 1)) : true;
+    const bool env = s->tree ? (!tree_wants_split2(s) && !tree_wants_split(s) && tree_use_lane(s, 1)) : true;
     return (range_capable(s) ? 1 : 0) | (env ? 2 : 0);
 }
 

@@ -29,6 +29,18 @@
 // (proximal links, tendons) and a distal one, which is a part like any other here (it owns and integrates its joints, and the trunk's
 // like everybody); five barriers per acceleration, all in the generated text; single-buffered exchange area; the RK4 accumulators
 // take a slot per joint a part integrates instead of one per joint of the robot.
+//
+// The LEAN layout (round 5, RBL_LEAN = 1; no helpers): for batches between "one workgroup per CU" and "a wave on every SIMD" - the upper
+// body at 16 384 < n <= 32 768 envs, where the one-wave form leaves half of the SIMDs idle and the five-wave form needs two
+// generations.  Two part waves per env group and TWO workgroups per CU: the workgroup must fit 80 KB of LDS.  A part wave is alone on
+// its SIMD with the whole 512-register file and uses ~300 of it, so what the other layouts keep in LDS moves to registers - the
+// parking slots of the generated code (a local array behind the same accessor: every slot index is a literal, the array becomes
+// registers) and the RK4 accumulators - and the exchange area lies OVER the action / observation image (dead while the step runs;
+// a barrier behind the waves' input reads and one in front of their output writes keep the two uses apart):
+//   image   q | qd | goal          3 n_q slots, readable to the end of the step
+//   shared  max(action / observation image, 2 x RBL_X_SLOTS exchange buffers, 4 n_q)   the goal rows a finished episode writes go behind the observation image
+//   flags   3 per part + 1
+// Upper body: 222 slots = 55.5 KB against 481 = 120 KB in the plain layout of the same two parts.
 #pragma once
 #include "env_common.hpp"
 #include "philox.hpp"
@@ -39,12 +51,23 @@
 #ifndef RBL_NHELPERS
 #define RBL_NHELPERS 0
 #endif
+#ifndef RBL_LEAN
+#define RBL_LEAN 0
+#endif
+#if RBL_LEAN && RBL_NHELPERS > 0
+#error "the lean layout has no helper waves"
+#endif
 
 namespace RBL_NS {
 
 struct SplitLds {
     float *p;   // the wave's private region + lane
     __device__ __forceinline__ float &operator()(int slot) const { return p[slot * 64]; }
+};
+// the lean layout's parking "slots": a local array of the wave (slot indices are literals in the generated text: registers)
+struct SplitRegs {
+    float *p;
+    __device__ __forceinline__ float &operator()(int slot) const { return p[slot]; }
 };
 
 // row images: q | qd | goal | action, the observation image [q | qd | goal as observed] over the action image (dead after a wave's
@@ -59,12 +82,17 @@ constexpr int SP_OV = RBL_NQ * 64, SP_OG = 2 * RBL_NQ * 64, SP_OA = 3 * RBL_NQ *
 #define RBL_X_SINGLE (RBL_NHELPERS > 0)
 #endif
 constexpr int SP_ACC_JOINTS = RBL_ACC_JOINTS;
-constexpr int SP_WAVE_SLOTS = RBL_PART_LDS + 2 * SP_ACC_JOINTS;
+constexpr bool SP_LEAN = RBL_LEAN != 0;
+constexpr int SP_WAVE_SLOTS = SP_LEAN ? 0 : RBL_PART_LDS + 2 * SP_ACC_JOINTS;
 constexpr int SP_ACC_SLOT = RBL_PART_LDS;
 constexpr int SP_NWAVES = RBL_NPARTS + RBL_NHELPERS;
 constexpr int SP_X_BUFFERS = RBL_X_SINGLE ? 1 : 2;
-constexpr int SP_X_OFF = SP_IMG_SLOTS;
-constexpr int SP_WAVE_OFF = SP_X_OFF + SP_X_BUFFERS * RBL_X_SLOTS;
+// lean: the exchange area over the action / observation image, behind q | qd | goal; the goal rows of finished episodes behind the observation image
+constexpr int SP_X_OFF = SP_LEAN ? 3 * RBL_NQ : SP_IMG_SLOTS;
+constexpr int SP_SHARED_SLOTS = (SP_X_BUFFERS * RBL_X_SLOTS > SP_IMG_SLOTS - 3 * RBL_NQ ? SP_X_BUFFERS * RBL_X_SLOTS : SP_IMG_SLOTS - 3 * RBL_NQ) > 4 * RBL_NQ
+                                    ? (SP_X_BUFFERS * RBL_X_SLOTS > SP_IMG_SLOTS - 3 * RBL_NQ ? SP_X_BUFFERS * RBL_X_SLOTS : SP_IMG_SLOTS - 3 * RBL_NQ) : 4 * RBL_NQ;
+constexpr int SP_WAVE_OFF = SP_LEAN ? 3 * RBL_NQ + SP_SHARED_SLOTS : SP_X_OFF + SP_X_BUFFERS * RBL_X_SLOTS;
+constexpr int SP_GOAL_OUT_OFF = SP_LEAN ? 6 * RBL_NQ : SP_WAVE_OFF;     // where the accountant leaves the new goal rows (plain layout: its own parking region, free by then)
 constexpr int SP_FLAG_OFF = SP_WAVE_OFF + RBL_NPARTS * SP_WAVE_SLOTS;
 constexpr int SP_DRAW_OFF = SP_FLAG_OFF + 3 * RBL_NPARTS + 1;     // per part: limit flag, and (env layer) its joints' shares of |dq|^2, |qd|^2; then the "a goal changed" word
 // ... then (helper form, env layer) the goals the helpers draw ahead for every env of the group, one slot per joint: a helper is idle
@@ -175,8 +203,8 @@ __device__ __forceinline__ constexpr int sp_acc(int j) {
 }
 
 // One env step of the joints part PART integrates (the trunk's and its own); the other entries of q / v are not touched.
-template <int INTEG, int PART>
-__device__ __forceinline__ bool split_step(const SplitLds &L, float *xbase, int lane, const float (&spu)[RBL_NT], float h, int nsub,
+template <int INTEG, int PART, class PARK>
+__device__ __forceinline__ bool split_step(const PARK &L, float *xbase, int lane, const float (&spu)[RBL_NT], float h, int nsub,
                                            float (&q)[RBL_NQ], float (&v)[RBL_NQ]) {
     bool ok = true;
     int n_acc = 0;                                   // accelerations so far: selects the exchange buffer
@@ -197,6 +225,30 @@ __device__ __forceinline__ bool split_step(const SplitLds &L, float *xbase, int 
         } else {
             const float h6 = h * (1.0f / 6.0f);
             float kq[RBL_NQ], kv[RBL_NQ];
+            if constexpr (SP_LEAN) {
+                // the weighted sums in registers (the wave has ~200 to spare), same order of accumulation as the LDS form: k1 + 2 k2 + 2 k3 + k4
+                float qa[RBL_NQ], va[RBL_NQ];
+#pragma unroll
+                for (int j = 0; j < RBL_NQ; ++j) { kq[j] = 0.0f; kv[j] = 0.0f; qa[j] = 0.0f; va[j] = 0.0f; }
+#pragma unroll 1
+                for (int st = 0; st < 4; ++st) {
+                    const float wgt = (st == 0 || st == 3) ? 1.0f : 2.0f, cst = st == 0 ? 0.0f : (st == 3 ? h : 0.5f * h);
+                    float qs[RBL_NQ];
+#pragma unroll
+                    for (int j = 0; j < RBL_NQ; ++j) {
+                        qs[j] = 0.0f;
+                        if (sp_mine<PART>(j)) { qs[j] = q[j] + cst * kq[j]; kq[j] = sp_sat(v[j] + cst * kv[j], j); }
+                    }
+#pragma unroll
+                    for (int j = 0; j < RBL_NQ; ++j) if (sp_mine<PART>(j)) qa[j] += wgt * kq[j];
+                    accel(qs, kq, kv);
+#pragma unroll
+                    for (int j = 0; j < RBL_NQ; ++j) if (sp_mine<PART>(j)) va[j] += wgt * kv[j];
+                }
+#pragma unroll
+                for (int j = 0; j < RBL_NQ; ++j)
+                    if (sp_mine<PART>(j)) { q[j] = q[j] + h6 * qa[j]; v[j] = v[j] + h6 * va[j]; }
+            } else {
 #pragma unroll
             for (int j = 0; j < RBL_NQ; ++j) {
                 kq[j] = 0.0f; kv[j] = 0.0f;
@@ -220,6 +272,7 @@ __device__ __forceinline__ bool split_step(const SplitLds &L, float *xbase, int 
 #pragma unroll
             for (int j = 0; j < RBL_NQ; ++j)
                 if (sp_mine<PART>(j)) { q[j] = q[j] + h6 * L(SP_ACC_SLOT + sp_acc<PART>(j)); v[j] = v[j] + h6 * L(SP_ACC_SLOT + SP_ACC_JOINTS + sp_acc<PART>(j)); }
+            }
         }
 #pragma unroll
         for (int j = 0; j < RBL_NQ; ++j) {
@@ -256,8 +309,18 @@ __device__ __forceinline__ void split_wave(float *lds, int lane, int live, float
             spu[k] = rbe::rounded_here((a * act_scale) * KSG[k]);
         }
     }
-    const SplitLds L{lds + (SP_WAVE_OFF + PART * SP_WAVE_SLOTS) * 64 + lane};
-    const bool ok = split_step<INTEG, PART>(L, lds + SP_X_OFF * 64, lane, spu, h, nsub, q, v);
+    bool ok;
+    if constexpr (SP_LEAN) {
+        // the exchange area lies over the action image: nobody writes it before everybody has read its actions ...
+        RBL_PART_BARRIER;
+        float park[RBL_PART_LDS > 0 ? RBL_PART_LDS : 1];
+        ok = split_step<INTEG, PART>(SplitRegs{park}, lds + SP_X_OFF * 64, lane, spu, h, nsub, q, v);
+        // ... and over the observation image: nobody writes that before everybody has read the last acceleration's exchange
+        RBL_PART_BARRIER;
+    } else {
+        const SplitLds L{lds + (SP_WAVE_OFF + PART * SP_WAVE_SLOTS) * 64 + lane};
+        ok = split_step<INTEG, PART>(L, lds + SP_X_OFF * 64, lane, spu, h, nsub, q, v);
+    }
     // (the accelerations' barriers lie between every wave's reads of the input image above and these writes)
     const int wl = sp_opaque(lane);
 #pragma unroll
@@ -524,8 +587,9 @@ tree_split_env_step(const rbe::TreeEnvArgs a) {
         const bool any = __builtin_amdgcn_ballot_w64(dn && mine) != 0ull;
         if (lane == 0) lds[(SP_FLAG_OFF + 3 * RBL_NPARTS) * 64] = any ? 1.0f : 0.0f;
         if (any) {
-            // the new goal rows go out from the accountant's registers through its own parking region (free now)
-            float *gimg = lds + (SP_WAVE_OFF) * 64;
+            // the new goal rows go out from the accountant's registers through its own parking region (free now; lean layout: behind the
+            // observation image, inside the exchange area nobody uses any more)
+            float *gimg = lds + (SP_GOAL_OUT_OFF) * 64;
 #pragma unroll
             for (int j = 0; j < RBL_NQ; ++j) gimg[wl * RBL_NQ + j] = gn[j];
         }
@@ -549,7 +613,7 @@ tree_split_env_step(const rbe::TreeEnvArgs a) {
         sq.read(lds, wave, lane); sv.read(lds + OV, wave, lane); so.read(lds + OO, wave, lane);
         const bool new_goals = lds[(SP_FLAG_OFF + 3 * RBL_NPARTS) * 64] != 0.0f;
         sq.store(late->q, env0, live, wave, lane); sv.store(late->qd, env0, live, wave, lane); so.store(late->obs, env0, live, wave, lane);
-        if (new_goals) sp_store_image<RBL_NQ>(late->goal, env0, live, lds + SP_WAVE_OFF * 64, wave, lane);
+        if (new_goals) sp_store_image<RBL_NQ>(late->goal, env0, live, lds + SP_GOAL_OUT_OFF * 64, wave, lane);
     }
 #if defined(RB_SPLIT_STAMPS)
     rbl_stamp_mark();                                  // stores issued

@@ -141,7 +141,7 @@ def upper_body():
 
 
 @pytest.mark.parametrize("integrator", ["euler", "rk4"])
-@pytest.mark.parametrize("kernel", [1, 3, 4])      # env-per-lane / octets / several waves per env group (the library's choice at 8 192 envs)
+@pytest.mark.parametrize("kernel", [1, 3, 4, 6])      # env-per-lane / octets / several waves per env group (the library's choice at 8 192 envs) / its lean two-part form
 def test_upper_body_full_batch_sample_determinism_permutation(upper_body, integrator, kernel):
     from gym_roboy_amd.envs.simulations import HipBatchSimulation
     from oracle.c_oracle import COracle
@@ -173,6 +173,55 @@ def test_upper_body_full_batch_sample_determinism_permutation(upper_body, integr
     q3, qd3, f3 = sim.forward_step_command(sp[perm])
     assert np.array_equal(q3, q1[perm]) and np.array_equal(qd3, qd1[perm]) and np.array_equal(f3, f1[perm])
     sim.close()
+
+
+@pytest.mark.parametrize("integrator", ["euler", "rk4"])
+def test_upper_body_between_the_split_form_and_a_wave_per_simd(upper_body, integrator):
+    """16 384 < n <= 32 768 envs: the library's choice is the lean two-part split form (rb_kernel 6: two workgroups per CU share
+    its LDS) - a ragged 32 731-env batch against the fp64 oracle (every 509th env), deterministic, and the fused env layer's
+    states bit-identical to the plain step's in the same form."""
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    from oracle.c_oracle import COracle
+    desc = upper_body.get_description()
+    n = 32768 - 37
+    q, qd, sp = _states(desc, n, 11)
+    sim = HipBatchSimulation(upper_body, n, integrator=integrator)
+    assert sim.info()["kernel"] == 6
+    sim.set_state(q, qd)
+    q1, qd1, f1 = sim.forward_step_command(sp)
+    assert sim.info()["kernel"] == 6 and np.isfinite(q1).all() and np.isfinite(qd1).all()
+    idx = np.concatenate([np.arange(0, n, 509), np.arange(n - 40, n)])          # ... and the ragged last group
+    qo, qdo, fo = COracle(desc, "f64").step(q[idx], qd[idx], sp[idx], integrator=0 if integrator == "euler" else 1, threads=8)
+    assert np.abs(q1[idx] - qo).max() < 2e-5 and np.abs(qd1[idx] - qdo).max() < 2e-5
+    near = np.minimum(np.abs(qo - desc.q_lo), np.abs(qo - desc.q_hi)).min(axis=1) < 1e-5
+    assert not np.any((f1[idx] != fo) & ~near)
+    sim.set_state(q, qd)
+    q2, qd2, f2 = sim.forward_step_command(sp)
+    assert np.array_equal(q1, q2) and np.array_equal(qd1, qd2) and np.array_equal(f1, f2)
+    # the same envs in the five-wave form (two generations) and as one wave per 64 envs: rounding apart
+    for other in (4, 1):
+        sim.select_kernel(other)
+        sim.set_state(q, qd)
+        q3, qd3, _ = sim.forward_step_command(sp)
+        assert np.abs(q3 - q1).max() < 1e-5 and np.abs(qd3 - qd1).max() < 1e-5
+    sim.close()
+    # fused env layer in the same form: one step from the same state with actions = set-points / 0.3
+    vec = RoboyVecEnv(upper_body, n, seed=1, auto_reset=False, integrator=integrator)
+    assert vec.sim.info()["kernel"] == 6
+    vec.reset()
+    vec.sim.set_state(q, qd)
+    act = np.clip(sp / np.float32(0.3), -1, 1).astype(np.float32)
+    obs, rew, done, _ = vec.step(act)
+    ref = HipBatchSimulation(upper_body, n, integrator=integrator)
+    ref.set_state(q, qd)
+    from gym_roboy_amd.envs import reward as rw
+    one = np.ones(desc.n_t, np.float32)
+    box = upper_body.get_action_space()
+    qr, qdr, fr = ref.forward_step_command(rw.rescale_between_boxes(act, -one, one, box.low, box.high).astype(np.float32))
+    assert np.array_equal(obs[:, :desc.n_q], qr) and np.array_equal(obs[:, desc.n_q:2 * desc.n_q], qdr)
+    assert np.isfinite(rew).all()
+    vec.close(); ref.close()
 
 
 def test_upper_body_full_batch_shards_and_rest_equilibrium(upper_body):

@@ -25,7 +25,7 @@ def upper_oracle(upper_body):
     return COracle(upper_body.get_description(), "f64")
 
 
-LANE, OCTET, SPLIT = 1, 3, 4      # rb_kernel: RB_KERNEL_ENV_PER_LANE, RB_KERNEL_ENV_PER_WAVE, RB_KERNEL_ENV_PER_LANE_SPLIT
+LANE, OCTET, SPLIT, SPLIT2 = 1, 3, 4, 6      # rb_kernel: RB_KERNEL_ENV_PER_LANE, _ENV_PER_WAVE, _ENV_PER_LANE_SPLIT, _ENV_PER_LANE_SPLIT2 (lean two-part form, round 5)
 
 
 def _check(robot, oracle, n, integrator, nsub, seed, kernel=None, expect=OCTET):
@@ -51,7 +51,7 @@ def _check(robot, oracle, n, integrator, nsub, seed, kernel=None, expect=OCTET):
 @pytest.mark.parametrize("integrator", ["euler", "rk4"])
 @pytest.mark.parametrize("nsub", [1, 2])
 @pytest.mark.parametrize("n", [1, 257])
-@pytest.mark.parametrize("kernel", [None, LANE, OCTET])
+@pytest.mark.parametrize("kernel", [None, LANE, OCTET, SPLIT2])
 def test_upper_body_step_matches_oracle(upper_body, upper_oracle, integrator, nsub, n, kernel):
     # the library's choice for the committed upper body at these batch sizes is the split form compiled ahead of time
     _check(upper_body, upper_oracle, n, integrator, nsub, seed=n + nsub, kernel=kernel, expect=SPLIT)
@@ -65,7 +65,7 @@ def test_kernel_forms_of_the_upper_body_agree_with_each_other(upper_body):
     n = 300
     q, qd, sp = random_states(desc, n, 21)
     out = {}
-    for kernel in (LANE, SPLIT, OCTET):
+    for kernel in (LANE, SPLIT, OCTET, SPLIT2):
         for integ in ("euler", "rk4"):
             sim = HipBatchSimulation(upper_body, n, integrator=integ)
             sim.select_kernel(kernel)
@@ -73,7 +73,7 @@ def test_kernel_forms_of_the_upper_body_agree_with_each_other(upper_body):
             out[kernel, integ] = sim.forward_step_command(sp)
             sim.close()
     for integ in ("euler", "rk4"):
-        for kernel in (SPLIT, OCTET):
+        for kernel in (SPLIT, OCTET, SPLIT2):
             # (three instruction streams with three summation orders - the lane form writes the two arms as one stream of
             # pair values: half the tolerance against the oracle)
             assert np.abs(out[kernel, integ][0] - out[LANE, integ][0]).max() < 1e-5
@@ -91,8 +91,11 @@ def test_upper_body_specialization_is_the_ahead_of_time_table(upper_body):
     sim.select_kernel(0)
     assert sim.info()["kernel"] == SPLIT
     sim.close()
-    big = HipBatchSimulation(upper_body, 16384 + 64)          # beyond the split form's batch range: one wave per 64 envs
-    assert big.info()["kernel"] == LANE and big.specialization() == "table"
+    mid = HipBatchSimulation(upper_body, 16384 + 64)          # beyond one five-wave workgroup per CU: two part waves per env group, two workgroups per CU
+    assert mid.info()["kernel"] == SPLIT2 and mid.specialization() == "table" and not mid.range_capable()
+    mid.close()
+    big = HipBatchSimulation(upper_body, 32768 + 64)          # beyond that: one wave per 64 envs (a wave on every SIMD from 65 536 envs on)
+    assert big.info()["kernel"] == LANE and big.specialization() == "table" and big.range_capable()
     big.close()
 
 
@@ -185,7 +188,7 @@ def test_tree_kernel_on_the_msj_robot_equals_the_closed_form(msj_robot, msj_orac
     _check(Msj4(), COracle(desc, "f64"), 65, "euler", 1, seed=8)
 
 
-@pytest.mark.parametrize("kernel", [None, LANE, OCTET])      # None: the library's choice for 130 envs, the split form
+@pytest.mark.parametrize("kernel", [None, LANE, OCTET, SPLIT2])      # None: the library's choice for 130 envs, the split form
 @pytest.mark.parametrize("auto_reset,integrator", [(True, "euler"), (False, "euler"), (True, "rk4")])
 def test_fused_env_layer_on_the_upper_body_matches_host_replay(upper_body, auto_reset, integrator, kernel):
     """RoboyVecEnv over the joint-tree kernel: same replay check as for MsjRobot

@@ -53,6 +53,8 @@ SPLIT_HELPER_SHARE = 80    # percent of a helped part's tendons its helper takes
 SPLIT_TWO_SWEEPS = 1       # the parts' backward pass in two sweeps around barrier T (RB_SPLIT_TWO_SWEEPS)
 SPLIT_SHARE_TRUNK = 1      # one part evaluates the trunk links' inertias / bias forces for all (RB_SPLIT_SHARE_TRUNK)
 SPLIT_CUT = 0              # the cut form instead: SPLIT_HELPERS parts as a proximal and a distal wave each (RB_SPLIT_CUT)
+SPLIT2_PARTS = 2           # the lean two-part form (RB_SPLIT2_PARTS): no helpers, the trunk shared (RB_SPLIT2_SHARE_TRUNK)
+SPLIT2_SHARE_TRUNK = 1
 
 
 def generate_split(desc, path, max_parts=4, max_helpers=0, helper_share=0, two_sweeps=0, cut=0, share_trunk=0):
@@ -79,3 +81,6 @@ if __name__ == "__main__":
     print("wrote", out, generate(UpperBodyRobot().get_description(), out))
     out = os.path.join(os.path.dirname(out), "tree_lane_split_baked.hpp")
     print("wrote", out, generate_split(UpperBodyRobot().get_description(), out, max_helpers=SPLIT_HELPERS, helper_share=SPLIT_HELPER_SHARE, two_sweeps=SPLIT_TWO_SWEEPS, cut=SPLIT_CUT, share_trunk=SPLIT_SHARE_TRUNK))
+    # the two-part form for the lean layout of tree_lane_split.hpp (two workgroups per CU; csrc/roboy_sim_split2.hip)
+    out = os.path.join(os.path.dirname(out), "tree_lane_split2_baked.hpp")
+    print("wrote", out, generate_split(UpperBodyRobot().get_description(), out, max_parts=SPLIT2_PARTS, max_helpers=0, share_trunk=SPLIT2_SHARE_TRUNK))
