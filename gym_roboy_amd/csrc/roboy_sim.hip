@@ -462,9 +462,11 @@ struct rb_sim {
     rblg::SplitGenerated split_gen;
     bool split_ok = false, split_baked = false;
     rblj::Kernel split_step_k, split_env_k;
-    // ... and its lean two-part form (two workgroups per CU; ahead-of-time instances only: roboy_sim_split2.hip)
+    // ... and its lean two-part form (two workgroups per CU): the ahead-of-time instances of roboy_sim_split2.hip for the committed
+    // upper body, hiprtc-built ones for any other robot that has a split plan (on request: rb_select_kernel(6))
     rblg::SplitGenerated split2_gen;
-    bool split2_baked = false;
+    bool split2_ok = false, split2_baked = false;
+    rblj::Kernel split2_step_k, split2_env_k;
     GoalBox box;
     hipStream_t own_stream = nullptr, stream = nullptr;
     static constexpr int MAX_CHAINS = 4;
@@ -559,9 +561,9 @@ size_t split_lean_lds_bytes(const rblg::SplitGenerated &g) {
 // does this handle run the lean two-part split form?  An explicit choice, or AUTO between the five-wave form's batch and a wave on
 // every SIMD; ahead-of-time instances only
 bool tree_wants_split2(const rb_sim *s) {
-    if (!s->tree || !s->split2_baked) return false;
-    if (s->kernel_choice == RB_KERNEL_ENV_PER_LANE_SPLIT2) return true;
-    return s->kernel_choice == RB_KERNEL_AUTO && s->n > RB_TREE_SPLIT_BATCH && s->n <= RB_TREE_SPLIT2_BATCH;
+    if (!s->tree || !s->split2_ok) return false;
+    if (s->kernel_choice == RB_KERNEL_ENV_PER_LANE_SPLIT2) return true;      // (rb_select_kernel has built the kernels of a robot without instances)
+    return s->kernel_choice == RB_KERNEL_AUTO && s->split2_baked && s->n > RB_TREE_SPLIT_BATCH && s->n <= RB_TREE_SPLIT2_BATCH;
 }
 size_t split_lds_bytes(const rblg::SplitGenerated &g) {      // the formula of tree_lane_split.hpp: SP_LDS_BYTES
     const int img = 3 * g.n_q + (3 * g.n_q > g.n_t ? 3 * g.n_q : g.n_t);
@@ -584,6 +586,26 @@ bool build_split_kernel(rb_sim *s, int kind = 0) {
     if (k.state == 1 && split_lds_bytes(s->split_gen) > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(k.fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(split_lds_bytes(s->split_gen))) != hipSuccess) {
         k.state = -1; k.why = "LDS of the split kernel not granted";
+    }
+    return k.state == 1;
+}
+
+// the hiprtc-built lean two-part kernels of a robot without ahead-of-time instances (explicit choice only); kind: 0 = step, 1 = env step
+bool build_split2_kernel(rb_sim *s, int kind = 0) {
+    rblj::Kernel &k = kind == 0 ? s->split2_step_k : s->split2_env_k;
+    if (k.state != 0) return k.state == 1;
+    if (capturing(s)) return false;                      // try again outside the capture
+    if (hipSetDevice(s->device) != hipSuccess) { k.state = -1; k.why = "hipSetDevice failed"; return false; }
+    const size_t lds = split_lean_lds_bytes(s->split2_gen);
+    const std::string src = "#include \"tree_lane_defs.hpp\"\n#define RBL_NS rbl_jit_split2\n#define RBL_LEAN 1\n" + s->split2_gen.text + "#include \"tree_lane_split.hpp\"\n" +
+                            "static_assert(rbl_jit_split2::SP_LDS_BYTES == " + std::to_string(lds) + ", \"host and kernel LDS layouts differ\");\n";
+    const std::string name = std::string(kind == 0 ? "rbl_jit_split2::tree_split_step<" : "rbl_jit_split2::tree_split_env_step<") + (s->integrator == RB_EULER ? "0>" : "1>");
+    const char *names[1] = {name.c_str()};
+    hipFunction_t *slots[1] = {&k.fn};
+    k.state = rbj::compile_and_load(src, "roboy_tree_split2_jit.hip", names, 1, k.mod, slots, k.why) ? 1 : -1;
+    if (k.state == 1 && lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k.fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) {
+        k.state = -1; k.why = "LDS of the lean split kernel not granted";
     }
     return k.state == 1;
 }
@@ -711,8 +733,20 @@ int launch_step(rb_sim *s, const float *d_act, float act_scale, long i0 = 0, lon
     if (s->tree && tree_wants_split2(s)) {
         // two part waves per 64 envs, two workgroups per CU (whole batches only)
         s->kernel = RB_KERNEL_ENV_PER_LANE_SPLIT2;
-        rbs2::launch_step(s->integrator == RB_EULER ? 0 : 1, blocks_for(n, 64), s->stream, s->d_q, s->d_qd, s->d_feas, d_act, act_scale,
-                          s->tree_host.dev.h, s->tree_host.dev.nsub, n);
+        if (s->split2_baked) {
+            rbs2::launch_step(s->integrator == RB_EULER ? 0 : 1, blocks_for(n, 64), s->stream, s->d_q, s->d_qd, s->d_feas, d_act, act_scale,
+                              s->tree_host.dev.h, s->tree_host.dev.nsub, n);
+        } else {
+            if (!build_split2_kernel(s, 0)) return fail(RB_EUNSUPPORTED, "lean split kernel not available: " + s->split2_step_k.why);
+            float *q = s->d_q, *qd = s->d_qd;
+            uint32_t *feas = s->d_feas;
+            float hh = s->tree_host.dev.h;
+            int ns = s->tree_host.dev.nsub;
+            long nn = n;
+            void *args[] = {&q, &qd, &feas, &d_act, &act_scale, &hh, &ns, &nn};
+            RB_HIP(hipModuleLaunchKernel(s->split2_step_k.fn, blocks_for(n, 64), 1, 1, 64u * unsigned(s->split2_gen.n_parts), 1, 1,
+                                         unsigned(split_lean_lds_bytes(s->split2_gen)), s->stream, args, nullptr));
+        }
     } else if (s->tree && tree_wants_split(s) && (s->split_baked || s->split_step_k.state == 1)) {
         // one workgroup of n_parts (+ helper) waves per 64 envs
         const unsigned groups = blocks_for(n, 64);
@@ -1005,12 +1039,13 @@ int rb_create(const rb_robot_desc *robot, int64_t n_envs, int integrator, double
             s->split_baked = s->split_ok && s->split_gen.hash == RBL_SPLIT_TEXT_HASH && s->split_gen.n_parts == RBL_NPARTS &&
                              s->split_gen.n_helpers == RBL_NHELPERS && split_lds_bytes(s->split_gen) == size_t(rbl_split_baked::SP_LDS_BYTES);
             // the lean two-part form: only if the text generated for THIS robot is the text the second translation unit was compiled from
-            if (robot->n_q == rbs2::n_q() && robot->n_t == rbs2::n_t()) {
+            if (s->split_ok) {
                 std::string why2;
-                s->split2_baked = rblg::generate_split(robot, RB_SPLIT2_PARTS, s->split2_gen, why2, 0, 45, false, RB_SPLIT2_SHARE_TRUNK != 0) == RB_OK &&
-                                  s->split2_gen.hash == rbs2::text_hash() && s->split2_gen.n_parts == rbs2::n_parts() &&
-                                  split_lean_lds_bytes(s->split2_gen) == rbs2::lds_bytes();
-                if (!s->split2_baked) s->split2_gen = rblg::SplitGenerated();      // (the text is not kept for nothing)
+                s->split2_ok = rblg::generate_split(robot, RB_SPLIT2_PARTS, s->split2_gen, why2, 0, 45, false, RB_SPLIT2_SHARE_TRUNK != 0) == RB_OK &&
+                               split_lean_lds_bytes(s->split2_gen) <= 160 * 1024;
+                s->split2_baked = s->split2_ok && robot->n_q == rbs2::n_q() && robot->n_t == rbs2::n_t() && s->split2_gen.hash == rbs2::text_hash() &&
+                                  s->split2_gen.n_parts == rbs2::n_parts() && split_lean_lds_bytes(s->split2_gen) == rbs2::lds_bytes();
+                if (!s->split2_ok) s->split2_gen = rblg::SplitGenerated();
             }
         }
         else why = "not a ball-joint robot (" + why + ") and not a supported joint tree (" + why_tree + ")";
@@ -1105,6 +1140,7 @@ void rb_destroy(rb_sim *s) {
     for (auto &kv : s->graphs) kv.second.destroy();
     rbj::unload(s->jit);
     rblj::unload(s->lane_step_k); rblj::unload(s->lane_env_k); rblj::unload(s->split_step_k); rblj::unload(s->split_env_k);
+    rblj::unload(s->split2_step_k); rblj::unload(s->split2_env_k);
     (void)hipFree(s->d_q); (void)hipFree(s->d_qd); (void)hipFree(s->d_feas);
     (void)hipFree(s->d_goal_count); (void)hipFree(s->d_rows); (void)hipFree(s->d_u8); (void)hipFree(s->d_ten);
     (void)hipFree(s->d_tree_words);
@@ -1192,7 +1228,7 @@ void rb_jit_cache_stats(int64_t *hits, int64_t *compiles, int64_t *stores) {
 int rb_specialization(rb_sim *s) {
     if (check(s)) return -1;
     if (s->tree) {
-        if (tree_wants_split2(s)) return RB_SPEC_TABLE;
+        if (tree_wants_split2(s)) return s->split2_baked ? RB_SPEC_TABLE : (s->split2_step_k.state == 1 ? RB_SPEC_JIT : RB_SPEC_NONE);
         if (tree_wants_split(s)) return s->split_baked ? RB_SPEC_TABLE : (s->split_step_k.state == 1 ? RB_SPEC_JIT : RB_SPEC_NONE);
         if (!tree_wants_lane(s)) { g_err = s->lane_ok ? "the octet kernels are selected (batch below the build threshold, or by choice)" : "no generator for this robot"; return RB_SPEC_NONE; }
         if (s->lane_baked) return RB_SPEC_TABLE;
@@ -1211,8 +1247,8 @@ int rb_select_kernel(rb_sim *s, int kernel) {
     if (check(s)) return RB_EINVAL;
     // validate first: a refused request leaves the handle as it was (kernel_choice, rb_info, the graph cache)
     if (kernel < RB_KERNEL_AUTO || kernel > RB_KERNEL_ENV_PER_LANE_SPLIT2) return fail(RB_EINVAL, "unknown kernel variant");
-    if (kernel == RB_KERNEL_ENV_PER_LANE_SPLIT2 && !(s->tree && s->split2_baked))
-        return fail(RB_EUNSUPPORTED, "the lean two-part split form exists for the robot the library was built for only (the committed upper body)");
+    if (kernel == RB_KERNEL_ENV_PER_LANE_SPLIT2 && !(s->tree && s->split2_ok))
+        return fail(RB_EUNSUPPORTED, "no split form for this robot (a ball-joint robot, a serial chain, or branches tied together by tendons)");
     if (kernel == RB_KERNEL_LANE_PAIR && !(s->pair_ok && !s->tree && !s->ntx))
         return fail(RB_EUNSUPPORTED, "the two-lanes-per-env form needs an 8-tendon ball-joint robot with a mirror plane (tendons in mirror-image pairs, "
                                      "principal-axis inertia, symmetric joint limits)");
@@ -1229,6 +1265,13 @@ int rb_select_kernel(rb_sim *s, int kernel) {
             if (lane_kernel(s, 0)->state != 1) {
                 s->kernel_choice = before;
                 return fail(RB_EUNSUPPORTED, "env-per-lane kernel not available: " + s->lane_step_k.why);
+            }
+        }
+        if (kernel == RB_KERNEL_ENV_PER_LANE_SPLIT2 && !s->split2_baked) {
+            if (capturing(s)) { s->kernel_choice = before; return fail(RB_EINVAL, "the lean split-form kernel cannot be built during a stream capture"); }
+            if (!build_split2_kernel(s)) {
+                s->kernel_choice = before;
+                return fail(RB_EUNSUPPORTED, "lean split-form kernel not available: " + s->split2_step_k.why);
             }
         }
         if (kernel == RB_KERNEL_ENV_PER_LANE_SPLIT && !s->split_baked) {
@@ -1621,7 +1664,14 @@ static int env_step_launch(rb_sim *s, long i0, long cnt, hipStream_t stream, con
                             d_obs, d_reward, d_done, s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, s->tree_host.dev.h, s->tree_host.dev.nsub, n,
                             s->seed, uint64_t(s->env0), n};
         s->kernel = RB_KERNEL_ENV_PER_LANE_SPLIT2;
-        rbs2::launch_env_step(s->integrator == RB_EULER ? 0 : 1, blocks_for(n, 64), stream, ka);
+        if (s->split2_baked) {
+            rbs2::launch_env_step(s->integrator == RB_EULER ? 0 : 1, blocks_for(n, 64), stream, ka);
+        } else {
+            if (!build_split2_kernel(s, 1)) return fail(RB_EUNSUPPORTED, "lean split env kernel not available: " + s->split2_env_k.why);
+            void *args[] = {&ka};
+            RB_HIP(hipModuleLaunchKernel(s->split2_env_k.fn, blocks_for(n, 64), 1, 1, 64u * unsigned(s->split2_gen.n_parts), 1, 1,
+                                         unsigned(split_lean_lds_bytes(s->split2_gen)), stream, args, nullptr));
+        }
         RB_HIP(hipGetLastError());
         return RB_OK;
     }

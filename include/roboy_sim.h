@@ -61,7 +61,8 @@ enum rb_kernel {
                                       the instruction stream only */
     RB_KERNEL_ENV_PER_LANE_SPLIT2 = 6,/* joint trees, batches between "one workgroup of form 4 per CU" and "a wave on every SIMD"
                                       (the upper body: 16 384 < n <= 32 768 envs): the same code in TWO part waves per 64 envs
-                                      with a workgroup lean enough in LDS for two per CU; ahead-of-time instances only */
+                                      with a workgroup lean enough in LDS for two per CU; the library's own choice in that
+                                      range for the committed upper body, built by hiprtc on request for other robots */
     RB_KERNEL_LANE_PAIR = 5          /* ball-joint robots with a mirror plane (MsjRobot): two lanes per env - the odd lane
                                       steps the env's mirror image with the same code and constants, four tendons each,
                                       torque sums swapped by DPP: twice the waves of the env-per-lane form for the same

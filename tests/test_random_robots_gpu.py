@@ -114,9 +114,10 @@ def test_robot_with_two_identical_branches_runs_them_as_pair_values(seed):
     sim.close()
 
 
-@pytest.mark.parametrize("seed", [5, 9])        # 11 joints in 2 parts, 18 joints in 4 parts (several roots: no trunk)
-def test_random_tree_robot_split_form_matches_oracle(seed):
-    """The split form (several waves per group of 64 envs) of a random robot, built by hiprtc on request."""
+@pytest.mark.parametrize("kernel", [4, 6])      # the split form, and its lean two-part layout (round 5: parking in registers, exchange area over the row image)
+@pytest.mark.parametrize("seed", [5, 9])        # 11 joints in 2 parts, 18 joints in 4 parts (several roots: no trunk; lean form: packed into 2)
+def test_random_tree_robot_split_form_matches_oracle(seed, kernel):
+    """The split forms (several waves per group of 64 envs) of a random robot, built by hiprtc on request."""
     from gym_roboy_amd.envs.simulations import HipBatchSimulation
     from oracle.c_oracle import COracle
     robot, desc = random_tree_robot(seed)
@@ -124,8 +125,8 @@ def test_random_tree_robot_split_form_matches_oracle(seed):
     n = 130
     q, qd, sp = random_states(desc, n, seed)
     sim = HipBatchSimulation(robot, n, integrator=integrator, n_substeps=2 if seed == 5 else 1)
-    sim.select_kernel(4)
-    assert sim.info()["kernel"] == 4 and sim.specialization() == "jit"
+    sim.select_kernel(kernel)
+    assert sim.info()["kernel"] == kernel and sim.specialization() == "jit"
     sim.set_state(q, qd)
     q1, qd1, f1 = sim.forward_step_command(sp)
     qo, qdo, fo = COracle(desc, "f64").step(q, qd, sp, integrator=0 if integrator == "euler" else 1, n_substeps=2 if seed == 5 else 1)
@@ -189,8 +190,9 @@ def test_split_form_is_refused_where_the_tree_has_no_parts():
     from gym_roboy_amd.envs.simulations import HipBatchSimulation
     robot, _ = random_tree_robot(41, n_q=6, n_t=3, shape="chain")
     sim = HipBatchSimulation(robot, 10)
-    with pytest.raises(Exception, match="no split form"):
-        sim.select_kernel(4)
+    for k in (4, 6):
+        with pytest.raises(Exception, match="no split form"):
+            sim.select_kernel(k)
     sim.close()
 
 
@@ -386,7 +388,7 @@ def test_fused_env_layer_on_random_robots_matches_host_replay(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", [1, 4])          # RB_KERNEL_ENV_PER_LANE, RB_KERNEL_ENV_PER_LANE_SPLIT: both built by hiprtc for this robot
+@pytest.mark.parametrize("kernel", [1, 4, 6])       # RB_KERNEL_ENV_PER_LANE, _SPLIT, _SPLIT2 (the lean two-part layout): all built by hiprtc for this robot
 def test_fused_env_layer_of_the_hiprtc_built_lane_and_split_kernels_matches_host_replay(kernel):
     """The env-step kernels of the env-per-lane forms take ONE struct argument (env_common.hpp: TreeEnvArgs) and read most of it
     behind the step; for a robot without ahead-of-time instances they are compiled by hiprtc and launched through

@@ -225,6 +225,25 @@ def test_hiprtc_builds_the_kernels_of_a_random_robot():
         assert size > 10000
 
 
+def test_hiprtc_builds_the_lean_split_kernels_of_a_random_robot():
+    """What build_split2_kernel (csrc/roboy_sim.hip) hands to hiprtc for rb_select_kernel(6) on a robot without ahead-of-time
+    instances: the two-part split text behind `#define RBL_LEAN 1` - parking slots in registers, exchange area over the row
+    image (tree_lane_split.hpp) - compiled here for gfx950."""
+    import gen_tree_lane_baked as gen
+    from gym_roboy_amd.envs.robots import RobotDescription
+    from random_robots import random_tree_spec
+    hdr = os.path.join(BUILD, "lane_split2_rtc.hpp")
+    info = gen.generate_split(RobotDescription(random_tree_spec(5)), hdr, max_parts=2, share_trunk=1)
+    assert info["n_parts"] == 2 and info["n_helpers"] == 0
+    text = open(hdr).read()
+    text = text[:text.rindex("#define RBL_SPLIT_TEXT_HASH")]
+    src = '#include "tree_lane_defs.hpp"\n#define RBL_NS rbl_jit_split2\n#define RBL_LEAN 1\n' + text + '#include "tree_lane_split.hpp"\n'
+    for kern in ("rbl_jit_split2::tree_split_step<1>", "rbl_jit_split2::tree_split_env_step<0>"):
+        rc, log, size = _hiprtc_compile(src, "roboy_tree_split2_jit.hip", [kern])
+        assert rc == 0, log[:2000]
+        assert size > 10000
+
+
 def host_split_accel(desc, tag, max_parts=4, max_helpers=0):
     """generate_split -> g++ -> ctypes; returns (accel(q, qd, sp) -> (qdd, trunk mismatches), info).  Every part - and every
     helper wave - runs in a thread of its own; the barriers of the text are pthread barriers."""
