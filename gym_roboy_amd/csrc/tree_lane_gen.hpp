@@ -247,6 +247,20 @@ class Gen {
         for (const auto &t : terms) acc = fma(t.first, t.second, acc);
         return acc;
     }
+    // Several sums of products at once, their chains interleaved term by term: every sum is the same sequence of operations as
+    // dot() would write - the same value bit for bit - but consecutive statements belong to DIFFERENT chains.  A packed operation
+    // whose operand was written by the instruction right in front of it costs a wait state (hipcc puts an `s_nop` between two
+    // dependent v_pk_* instructions: 184 of them in the upper body's one-wave kernel, issue slots a SIMD's only wave pays for),
+    // and the rows of a 6 x 6 product are six independent chains.
+    std::vector<Val> dots(const std::vector<std::vector<std::pair<Val, Val>>> &rows) {
+        std::vector<Val> acc(rows.size(), K(0.0));
+        size_t longest = 0;
+        for (const auto &r : rows) longest = r.size() > longest ? r.size() : longest;
+        for (size_t k = 0; k < longest; ++k)
+            for (size_t r = 0; r < rows.size(); ++r)
+                if (k < rows[r].size()) acc[r] = fma(rows[r][k].first, rows[r][k].second, acc[r]);
+        return acc;
+    }
     // (a pair's functions are those of its two floats; rbl_f2 overloads take plain floats for the other arguments)
     Val call1(const char *fn, const Val &a) { return emit(std::string(fn) + "(" + S(a) + ")", a.pair); }
     Val call2(const char *fn, const Val &a, const Val &b) { return emit(std::string(fn) + "(" + S(a) + ", " + S(b) + ")", a.pair || b.pair); }
@@ -637,10 +651,11 @@ class Aba {
         Sym6 &I = IA[i];
         for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) I.m[r][c] = g.add(I.m[r][c], Iown[i].m[r][c]);
         const std::array<Val, 6> s = {z[i][0], z[i][1], z[i][2], sl[i][0], sl[i][1], sl[i][2]};
-        for (int r = 0; r < 6; ++r) {
-            std::vector<std::pair<Val, Val>> terms;
-            for (int c = 0; c < 6; ++c) terms.push_back({I.at(r, c), s[c]});
-            U[i][r] = g.dot(terms);
+        {
+            std::vector<std::vector<std::pair<Val, Val>>> rows(6);
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) rows[r].push_back({I.at(r, c), s[c]});
+            const std::vector<Val> u = g.dots(rows);           // (the six rows' chains interleaved)
+            for (int r = 0; r < 6; ++r) U[i][r] = u[r];
         }
         std::vector<std::pair<Val, Val>> sU, sP;
         for (int r = 0; r < 6; ++r) { sU.push_back({s[r], U[i][r]}); sP.push_back({s[r], pA[i][r]}); }
@@ -657,12 +672,18 @@ class Aba {
             Sym6 Ia;
             for (int r = 0; r < 6; ++r) for (int cc = r; cc < 6; ++cc) Ia.m[r][cc] = g.sub(I.m[r][cc], g.mul(Kk[r], U[i][cc]));
             const Val ud = g.mul(uu[i], invD[i]);
-            for (int r = 0; r < 6; ++r) {
-                std::vector<std::pair<Val, Val>> terms;
-                for (int cc = 0; cc < 6; ++cc) terms.push_back({Ia.at(r, cc), c[cc]});
-                const Val pu = g.fma(U[i][r], ud, pA[i][r]);
-                const Val pa = g.add(pu, g.dot(terms));
-                (*par_p)[r] = g.add((*par_p)[r], arrive(pa, i, rob.parent[i]));
+            {
+                std::vector<std::vector<std::pair<Val, Val>>> rows(6);
+                std::array<Val, 6> pu;
+                for (int r = 0; r < 6; ++r) {
+                    for (int cc = 0; cc < 6; ++cc) rows[r].push_back({Ia.at(r, cc), c[cc]});
+                    pu[r] = g.fma(U[i][r], ud, pA[i][r]);
+                }
+                const std::vector<Val> iac = g.dots(rows);
+                for (int r = 0; r < 6; ++r) {
+                    const Val pa = g.add(pu[r], iac[r]);
+                    (*par_p)[r] = g.add((*par_p)[r], arrive(pa, i, rob.parent[i]));
+                }
             }
             for (int r = 0; r < 6; ++r)
                 for (int cc = r; cc < 6; ++cc) par_I->m[r][cc] = g.add(par_I->m[r][cc], arrive(Ia.m[r][cc], i, rob.parent[i]));
@@ -691,10 +712,11 @@ class Aba {
         Sym6 &I = IA[i];
         for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) I.m[r][c] = g.add(I.m[r][c], Iown[i].m[r][c]);
         const std::array<Val, 6> s = {z[i][0], z[i][1], z[i][2], sl[i][0], sl[i][1], sl[i][2]};
-        for (int r = 0; r < 6; ++r) {
-            std::vector<std::pair<Val, Val>> terms;
-            for (int c = 0; c < 6; ++c) terms.push_back({I.at(r, c), s[c]});
-            U[i][r] = g.dot(terms);
+        {
+            std::vector<std::vector<std::pair<Val, Val>>> rows(6);
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) rows[r].push_back({I.at(r, c), s[c]});
+            const std::vector<Val> u = g.dots(rows);           // (the six rows' chains interleaved)
+            for (int r = 0; r < 6; ++r) U[i][r] = u[r];
         }
         std::vector<std::pair<Val, Val>> sU, sP;
         for (int r = 0; r < 6; ++r) { sU.push_back({s[r], U[i][r]}); sP.push_back({s[r], pA[i][r]}); }
@@ -710,12 +732,18 @@ class Aba {
             Sym6 Ia;
             for (int r = 0; r < 6; ++r) for (int cc = r; cc < 6; ++cc) Ia.m[r][cc] = g.sub(I.m[r][cc], g.mul(Kk[r], U[i][cc]));
             const Val ud = g.mul(uu0[i], invD[i]);
-            for (int r = 0; r < 6; ++r) {
-                std::vector<std::pair<Val, Val>> terms;
-                for (int cc = 0; cc < 6; ++cc) terms.push_back({Ia.at(r, cc), c[cc]});
-                const Val pu = g.fma(U[i][r], ud, pA[i][r]);
-                const Val pa = g.add(pu, g.dot(terms));
-                (*par_p)[r] = g.add((*par_p)[r], arrive(pa, i, rob.parent[i]));
+            {
+                std::vector<std::vector<std::pair<Val, Val>>> rows(6);
+                std::array<Val, 6> pu;
+                for (int r = 0; r < 6; ++r) {
+                    for (int cc = 0; cc < 6; ++cc) rows[r].push_back({Ia.at(r, cc), c[cc]});
+                    pu[r] = g.fma(U[i][r], ud, pA[i][r]);
+                }
+                const std::vector<Val> iac = g.dots(rows);
+                for (int r = 0; r < 6; ++r) {
+                    const Val pa = g.add(pu[r], iac[r]);
+                    (*par_p)[r] = g.add((*par_p)[r], arrive(pa, i, rob.parent[i]));
+                }
             }
             for (int r = 0; r < 6; ++r)
                 for (int cc = r; cc < 6; ++cc) par_I->m[r][cc] = g.add(par_I->m[r][cc], arrive(Ia.m[r][cc], i, rob.parent[i]));
