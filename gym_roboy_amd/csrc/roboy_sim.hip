@@ -558,8 +558,8 @@ size_t split_lean_lds_bytes(const rblg::SplitGenerated &g) {
     if (shared < 4 * g.n_q) shared = 4 * g.n_q;
     return size_t(3 * g.n_q + shared + 3 * g.n_parts + 1) * 64 * 4;
 }
-// does this handle run the lean two-part split form?  An explicit choice, or AUTO between the five-wave form's batch and a wave on
-// every SIMD; ahead-of-time instances only
+// does this handle run the lean two-part split form?  An explicit choice (any robot with a split plan: hiprtc), or AUTO between the
+// five-wave form's batch and a wave on every SIMD where ahead-of-time instances exist
 bool tree_wants_split2(const rb_sim *s) {
     if (!s->tree || !s->split2_ok) return false;
     if (s->kernel_choice == RB_KERNEL_ENV_PER_LANE_SPLIT2) return true;      // (rb_select_kernel has built the kernels of a robot without instances)
