@@ -80,6 +80,48 @@ def test_kernel_forms_of_the_upper_body_agree_with_each_other(upper_body):
             assert np.abs(out[kernel, integ][1] - out[LANE, integ][1]).max() < 1e-5
 
 
+def test_ragged_last_wave_and_unaligned_rows_in_the_one_wave_kernels(upper_body):
+    """Edge cases of the row movement of the one-wave kernels (a wave's rows are one contiguous run behind a range-checked buffer
+    resource): a ragged last wave (61 live envs) gives what the same envs give inside full waves, bit for bit; so do action /
+    observation arrays at a 4-byte offset in the fused env layer (legal there for joint trees).  (Written for a 16-bytes-per-lane
+    form of the row movement - LDS-DMA loads, dwordx4 stores - that was measured and not kept: profiles/r5_a/x4_ab.log.)"""
+    import torch
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    desc = upper_body.get_description()
+    full, ragged = 64 * 5, 64 * 5 - 3
+    q, qd, sp = random_states(desc, full, 17)
+    out = {}
+    for n in (full, ragged):
+        sim = HipBatchSimulation(upper_body, n)
+        sim.select_kernel(LANE)
+        sim.set_state(q[:n], qd[:n])
+        out[n] = sim.forward_step_command(sp[:n])
+        sim.close()
+    for a, b in zip(out[full], out[ragged]):
+        assert np.array_equal(a[:ragged], b)
+    obs = []
+    for n, shift in ((full, 0), (full, 1), (ragged, 0), (ragged, 1)):
+        vec = RoboyVecEnv(upper_body, n, seed=2)
+        vec.sim.select_kernel(LANE)
+        vec.reset()
+        vec.sim.set_state(q[:n], qd[:n])
+        abuf = torch.zeros(n * desc.n_t + 4, dtype=torch.float32, device="cuda")
+        act = abuf[shift:shift + n * desc.n_t]
+        act.copy_(torch.from_numpy(np.clip(sp[:n] / np.float32(0.3), -1, 1).reshape(-1)))
+        assert (act.data_ptr() % 16 == 0) == (shift == 0)
+        obuf = torch.zeros(n * 3 * desc.n_q + 4, dtype=torch.float32, device="cuda")
+        o = obuf[shift:shift + n * 3 * desc.n_q]
+        rew = torch.zeros(n, device="cuda"); done = torch.zeros(n, dtype=torch.int32, device="cuda")
+        vec.step_dev(act.data_ptr(), o.data_ptr(), rew.data_ptr(), done.data_ptr())
+        torch.cuda.synchronize()
+        obs.append((o.cpu().numpy().reshape(n, -1)[:ragged, :2 * desc.n_q].copy(), rew.cpu().numpy()[:ragged].copy()))
+        vec.close()
+    for other in obs[1:]:
+        assert np.array_equal(obs[0][0], other[0]) and np.array_equal(obs[0][1], other[1])
+    assert np.abs(obs[0][0][:, :desc.n_q] - out[full][0][:ragged]).max() < 1e-6
+
+
 def test_upper_body_specialization_is_the_ahead_of_time_table(upper_body):
     from gym_roboy_amd.envs.simulations import HipBatchSimulation
     sim = HipBatchSimulation(upper_body, 64)
