@@ -251,3 +251,40 @@ def test_upper_body_full_batch_shards_and_rest_equilibrium(upper_body):
     assert np.abs(q).max() < 1e-6 and np.abs(qd).max() < 1e-5 and f.all()
     assert np.array_equal(q[0], q[-1]) and np.array_equal(q[0], q[4097])
     whole.close()
+
+
+@pytest.mark.parametrize("robot_name,n,integrator,steps", [("msj", 4096, "euler", 100000), ("msj", 262144, "rk4", 4000),
+                                                           ("upper", 8192, "euler", 20000), ("upper", 20480, "rk4", 2000)])
+def test_long_random_action_rollouts_stay_finite_and_inside_the_limits(msj_robot, upper_body, robot_name, n, integrator, steps):
+    """Soak: tens of thousands of env steps under i.i.d. random set-points (a ring of 64 Philox slabs, hipGraph replay, the library's
+    own kernel form and chains at each size) - every state stays finite, inside the joint limits and the speed limits, the
+    feasible fraction stays high (limits are touched and left again, nothing sticks), and the statistics counter saw every step."""
+    import torch
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    robot = msj_robot if robot_name == "msj" else upper_body
+    desc = robot.get_description()
+    sim = HipBatchSimulation(robot, n, integrator=integrator, seed=7)
+    st = torch.cuda.Stream()
+    sim.set_stream(st.cuda_stream)
+    ring_n = 64
+    ring = torch.empty(ring_n * n * desc.n_t, dtype=torch.float32, device="cuda")
+    for r in range(ring_n):
+        sim.fill_actions_dev(ring.data_ptr() + 4 * r * n * desc.n_t, r)
+    done = 0
+    while done < steps:
+        k = min(1024, steps - done)
+        sim.rollout_dev(ring.data_ptr(), ring_n, k, 0.3, use_graph=True)
+        done += k
+    sim.synchronize()
+    q, qd, feas = sim.read_state()
+    assert np.isfinite(q).all() and np.isfinite(qd).all()
+    assert np.all(q >= desc.q_lo.astype(np.float32) - 1e-6) and np.all(q <= desc.q_hi.astype(np.float32) + 1e-6)
+    assert np.all(np.abs(qd) <= desc.qd_max.astype(np.float32) * (1 + 1e-6))
+    assert feas.mean() > 0.9, feas.mean()
+    assert np.abs(q).max() > 0.05                                  # (and the robots did move)
+    import ctypes
+    from gym_roboy_amd import _native as nat
+    out = (ctypes.c_double * 8)()
+    nat.check(sim._lib.rb_env_stats(sim.handle, out, 0))
+    assert out[6] == float(n) * steps                             # slot 6: env steps issued since the handle was created
+    sim.close()

@@ -817,6 +817,52 @@ def test_a_range_call_captured_on_a_callers_stream_defers_the_runtime_build():
     assert np.isfinite(_sim(robot, 64).read_state()[0]).all()
 
 
+def test_handles_give_their_device_memory_streams_and_graphs_back(msj_robot):
+    """Production hygiene: create / use / destroy many handles - every robot class and kernel form, graph rollouts in two chains,
+    the fused env layer, range launches on caller streams (events), statistics - and the free device memory returns to where it
+    was (hipMemGetInfo through torch; torch's own caching allocator is kept out of it by allocating nothing in between)."""
+    import torch
+    from gym_roboy_amd.envs.robots import UpperBodyRobot
+    from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+    upper = UpperBodyRobot()
+    act_m = torch.zeros((131072, 8), device="cuda")
+    act_u = torch.zeros((32768, 38), device="cuda")
+    ring = torch.zeros((4, 131072, 8), device="cuda")
+    obs_m = torch.zeros((131072, 9), device="cuda"); obs_u = torch.zeros((32768, 60), device="cuda")
+    rew = torch.zeros(131072, device="cuda"); done = torch.zeros(131072, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+
+    def cycle():
+        for n, kernel in ((512, 0), (20000, 0), (131072, 0), (131072, 5)):
+            sim = _sim(msj_robot, n, integrator="rk4")
+            if kernel:
+                sim.select_kernel(kernel)
+            sim.rollout_dev(ring.data_ptr(), 4, 24, 0.3, use_graph=True)
+            if sim.range_capable():
+                sim.step_range_dev(0, n // 2 // 256 * 256 or n, side.cuda_stream, act_m.data_ptr(), 0.3)
+            sim.close()
+        for n, kernel in ((300, 0), (300, 3), (20000, 0), (32768, 1)):
+            sim = _sim(upper, n)
+            if kernel:
+                sim.select_kernel(kernel)
+            sim.step_dev(act_u.data_ptr(), 0.3)
+            sim.close()
+        for robot, n, a, o in ((msj_robot, 20000, act_m, obs_m), (upper, 20000, act_u, obs_u)):
+            env = RoboyVecEnv(robot, n)
+            for _ in range(3):
+                env.step_dev(a.data_ptr(), o.data_ptr(), rew.data_ptr(), done.data_ptr())
+            env.stats()
+            env.close()
+        torch.cuda.synchronize()
+
+    cycle()                                               # first use: code objects, the runtime's own pools
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(5):
+        cycle()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, "device memory lost over 5 create / destroy cycles: %.1f MB" % ((free0 - free1) / 2 ** 20)
+
+
 def test_a_refused_kernel_selection_changes_nothing():
     """ADVICE (round 3): rb_select_kernel validates before it writes - a refused request leaves rb_info, rb_specialization and the
     dispatch of the next step as they were (joint trees: the split form stays the library's choice)."""
