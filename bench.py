@@ -86,7 +86,7 @@ VALU_PEAK = 157.3e12       # flop/s, fp32 vector peak (MI355X_MICROARCH.md "Peak
 VALU_FMA_MEASURED = 64 * 2 * 1024 / 1.20e-9
 KERNEL_NAMES = {1: "msj_step_env_per_lane", 2: "msj_step_tendon_per_lane", 3: "tree_step_aba", 5: "msj_step_mirror_pairs"}
 TREE_KERNEL_NAMES = {1: "tree_lane_step", 3: "tree_step_aba", 4: "tree_split_step", 6: "tree_split_step"}   # joint trees: env-per-lane (generated) / octets / several waves per env group
-PROFILE_DIRS = ("r4_a", "r3_a", "r2_a", "r1_b")   # newest first: where the committed rocprofv3 PMC passes live
+PROFILE_DIRS = ("r5_a", "r4_a", "r3_a", "r2_a", "r1_b")   # newest first: where the committed rocprofv3 PMC passes live
 
 
 def pmc_traffic(workload):
