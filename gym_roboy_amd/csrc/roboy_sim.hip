@@ -271,6 +271,39 @@ msj_step_tendon_per_lane(const Const8 c, const rb::MsjTendon<float> *__restrict_
 }
 
 
+// The fused env layer in the eight-lanes-per-env form (round 5): the step as above - lane k rescales and evaluates tendon k - and
+// behind the integrator lane 0 of each group does RoboyEnv.step's accounting (rbk::env_account, shared with the other two forms).
+// For small batches, where a launch is one wave's dependent chain: the chain of this form is a third of the env-per-lane kernel's.
+// n: the handle's envs (plane stride); cnt: the envs of this launch (a sub-range arrives on shifted pointers, env0 = its global id).
+template <int INTEG>
+__global__ void __launch_bounds__(64)
+msj_env_step_tendon_per_lane(const Const8 c, const rb::MsjTendon<float> *__restrict__ ten, const EnvParams ep, const GoalBox box,
+                             float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
+                             float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
+                             uint32_t *__restrict__ goal_count, const float *__restrict__ act,
+                             float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
+                             double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt, uint32_t *__restrict__ infeas_n,
+                             long n, long cnt, uint64_t seed, uint64_t env0) {
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7u, qn = nb >> 3, rn = nb & 7u;      // XCD-aware block -> env-group map (above)
+    const unsigned blk = (xcd < rn ? xcd * (qn + 1u) : rn * (qn + 1u) + (xcd - rn) * qn) + (blockIdx.x >> 3);
+    const long t = long(blk) * 64 + threadIdx.x;
+    const int k = threadIdx.x & 7;
+    long e = t >> 3;
+    const bool live = e < cnt;
+    if (!live) e = cnt - 1;           // dead groups shadow the last env so every DPP partner is active
+    const rb::MsjTendon<float> rec = ten[k];
+    // clamp, slope * (x - in_high) + out_high with two roundings (roboy_env.py:157-158), then set-point -> activation offset
+    const float a = act[e * NT8 + k];
+    const float spk = rbk::mul_then_add(ep.slope, fminf(fmaxf(a, -1.0f), 1.0f) - 1.0f, ep.act_hi) * rec.ksg;
+    float qq[3], vv[3], gg[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { qq[j] = q[j * n + e]; vv[j] = qd[j * n + e]; gg[j] = goal[j * n + e]; }
+    const bool ok = rb::MsjModel<float, NT8>::template integrate<INTEG>(c, qq, vv, AccelOneTendon{c, rec, spk});
+    if (live && k == 0)
+        rbk::env_account(ep, box, e, n, qq, vv, gg, ok, q, qd, feas, goal, step_num, ep_ret, goal_count, obs, reward, done, ep_sum, ep_cnt, infeas_n, seed, env0);
+}
+
+
 // State layout: SoA planes [n_q][n] for the env-per-lane / tendon-per-lane kernels, env-major rows
 // [n][n_q] for the joint-tree kernels (rows != 0), tree_aba.hpp.
 __device__ __forceinline__ long state_index(long i, int j, int n_q, long n, int rows) { return rows ? i * n_q + j : long(j) * n + i; }
@@ -884,15 +917,32 @@ int auto_kernel(const rb_sim *s) {
 // profiles/r5_a/env_pairs_sweep.log, us per env step, one env per lane -> two lanes per env: RK4 4 096 envs 5.49 -> 4.52,
 // 16 384 envs 5.69 -> 4.71, 32 768 envs 6.05 -> 5.17, 49 152 envs 6.44 -> 7.02; Euler 4 096 envs 2.90 -> 2.81, 16 384 envs
 // 3.07 -> 2.97, 32 768 envs 3.43 -> 3.46).  The env layer has no eight-lanes-per-env form, so - unlike the plain step -
-// there is no lower bound.  An explicit rb_select_kernel decides otherwise: 5 = this form, 1 / 2 = one env per lane.
+// the lower bound is the eight-lanes form's own (below).  An explicit rb_select_kernel decides otherwise: 5 = this form, 2 = eight
+// lanes per env, 1 = one env per lane.
 #ifndef RB_PAIR_ENV_BATCH_EULER
 #define RB_PAIR_ENV_BATCH_EULER 24576
 #endif
 #ifndef RB_PAIR_ENV_BATCH_RK4
 #define RB_PAIR_ENV_BATCH_RK4 32768
 #endif
+// ... and eight lanes per env below that (any 8-tendon ball-joint robot; rb_select_kernel(2) pins it).  Same kind of sweep
+// (profiles/r5_a/env_octets_sweep.log; eight lanes / two lanes / one lane per env): RK4 256 envs 3.38 / 4.39 / 5.36, 4 096 envs
+// 3.61 / 4.49 / 5.46, 8 192 envs 3.81 / 4.59 / 5.55, 12 288 envs 4.97 / 4.65 / 5.63; Euler 256 envs 2.35 / 2.70 / 2.80, 4 096 envs
+// 2.53 / 2.84 / 2.92, 8 192 envs 2.74 / 2.88 / 2.96, 12 288 envs 3.09 / 2.92 / 3.01
+#ifndef RB_OCTET_ENV_BATCH_EULER
+#define RB_OCTET_ENV_BATCH_EULER 8192
+#endif
+#ifndef RB_OCTET_ENV_BATCH_RK4
+#define RB_OCTET_ENV_BATCH_RK4 8192
+#endif
+bool env_uses_octets(const rb_sim *s) {
+    if (s->tree || s->ntx || !s->d_ten) return false;
+    if (s->kernel_choice == RB_KERNEL_TENDON_PER_LANE) return true;
+    if (s->kernel_choice != RB_KERNEL_AUTO) return false;
+    return s->n <= (s->integrator == RB_EULER ? RB_OCTET_ENV_BATCH_EULER : RB_OCTET_ENV_BATCH_RK4);
+}
 bool env_uses_pairs(const rb_sim *s) {
-    if (s->tree || s->ntx || !s->pair_ok) return false;
+    if (s->tree || s->ntx || !s->pair_ok || env_uses_octets(s)) return false;
     if (s->kernel_choice == RB_KERNEL_LANE_PAIR) return true;
     if (s->kernel_choice != RB_KERNEL_AUTO) return false;
     return s->n <= (s->integrator == RB_EULER ? RB_PAIR_ENV_BATCH_EULER : RB_PAIR_ENV_BATCH_RK4);
@@ -1751,6 +1801,14 @@ static int env_step_launch(rb_sim *s, long i0, long cnt, hipStream_t stream, con
     hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, 0, ConstX>), dim3(blocks_for(cnt, B)), dim3(B), 0, stream, s->cx, RB_ENV_ARGS)
 #define RB_ENV_LAUNCH_BK(INTEG, B, U)                                                                    \
     hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, U, Const8, true>), dim3(blocks_for(cnt, B)), dim3(B), 0, stream, s->c8, RB_ENV_ARGS)
+    if (env_uses_octets(s)) {
+        // eight lanes per env (small batches, or rb_select_kernel(2))
+        const unsigned g = blocks_for(cnt * NT8, 64);
+        if (s->integrator == RB_EULER) hipLaunchKernelGGL((msj_env_step_tendon_per_lane<0>), dim3(g), dim3(64), 0, stream, s->c8, s->d_ten, RB_ENV_ARGS);
+        else hipLaunchKernelGGL((msj_env_step_tendon_per_lane<1>), dim3(g), dim3(64), 0, stream, s->c8, s->d_ten, RB_ENV_ARGS);
+        RB_HIP(hipGetLastError());
+        return RB_OK;
+    }
     if (env_uses_pairs(s)) {
         // two lanes per env (robots with a mirror plane: the library's choice up to mid-size batches, or rb_select_kernel)
         PairMap pm;

@@ -157,8 +157,8 @@ int rb_info(const rb_sim *sim, rb_sim_info *info);
  *     side of a threshold agree to ~1 ulp per step, not bit for bit: pin the form (the same rb_select_kernel on every
  *     handle) where bit equality across shard sizes is wanted;
  *   - rb_env_step_dev against rb_step_dev + the reference's env arithmetic: bit-identical states when the handle's form is
- *     pinned to 1 or 5.  Under RB_KERNEL_AUTO the env layer chooses for itself (it has no eight-lanes form): two lanes per
- *     env up to 24 576 / 32 768 envs (robots with a mirror plane), one env per lane otherwise;
+ *     pinned to 1, 2 or 5.  Under RB_KERNEL_AUTO the env layer chooses by its own thresholds: eight lanes per env up to 8 192 envs,
+ *     two lanes per env up to 24 576 / 32 768 envs (robots with a mirror plane), one env per lane otherwise;
  *   - the env-per-lane form itself has two instances by the handle's batch size: up to 65 536 envs (64-thread workgroups,
  *     tendon loop written out) and above (256-thread workgroups; RK4: the stages as a rolled loop over running sums) - equal to
  *     ~1 ulp, bit-identical only among handles on the same side of 65 536 envs. */

@@ -25,17 +25,19 @@ from host_env_model import HipStepper, HostEnvModel
     # above 65 536 envs the fused kernel switches to its rolled-loop form (256-thread workgroups, LDS set-points)
     (70001, "euler", True, True, 1), (70001, "rk4", True, False, 1),
     # the two-lanes-per-env form (round 5): chosen explicitly, and by the library (form 0: nothing selected on the env's
-    # handle) for MsjRobot up to 24 576 envs (Euler) / 32 768 envs (RK4) - also where the plain step takes eight lanes per env
+    # handle) for MsjRobot above 8 192 and up to 24 576 envs (Euler) / 32 768 envs (RK4); up to 8 192 envs its choice is eight lanes per env
     (777, "rk4", True, True, 5), (777, "euler", False, True, 5), (777, "rk4", True, False, 0), (9001, "euler", True, False, 0),
-    (20001, "rk4", True, True, 0), (32768, "rk4", True, True, 0)])
+    (20001, "rk4", True, True, 0), (32768, "rk4", True, True, 0),
+    # eight lanes per env (round 5): lane k rescales and evaluates tendon k, lane 0 of the group accounts; ragged batch, both integrators
+    (777, "rk4", True, True, 2), (777, "euler", False, False, 2), (3001, "rk4", True, False, 2)])
 def test_fused_env_step_matches_host_replay(msj_robot, n, integrator, auto_reset, vel_penalty, form):
     from gym_roboy_amd.envs.vec_env import RoboyVecEnv
     seed, max_len = 5, 12
     vec = RoboyVecEnv(msj_robot, n, seed=seed, joint_vel_penalty=vel_penalty, auto_reset=auto_reset,
                       max_episode_length=max_len, integrator=integrator)
     if form:
-        vec.sim.select_kernel(form)                   # 1: one env per lane, 5: two lanes per env; 0: the library's choice
-    host = HostEnvModel(msj_robot, HipStepper(msj_robot, n, seed, integrator=integrator, kernel=5 if form != 1 else 1), n, seed, max_len,
+        vec.sim.select_kernel(form)                   # 1: one env per lane, 2: eight lanes per env, 5: two lanes per env; 0: the library's choice
+    host = HostEnvModel(msj_robot, HipStepper(msj_robot, n, seed, integrator=integrator, kernel={0: 2 if n <= 8192 else 5, 1: 1, 2: 2, 5: 5}[form]), n, seed, max_len,
                         vel_penalty, True, auto_reset)
     obs0 = vec.reset()
     # vec.__init__ drew goal 0 (configure), reset() drew goal 1: mirror RoboyEnv(...) then reset()
