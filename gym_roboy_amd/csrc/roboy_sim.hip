@@ -687,6 +687,12 @@ void maybe_jit(rb_sim *s) {
 // 70.3 -> 56.9; RK4 65 536 envs 55.6 -> 53.7, 131 072 envs 109.3 -> 102.1.  Three and four chains are no better anywhere
 // (chain_count.log).  Envs are independent, so the results are those of one launch per step, bit for bit.
 // ROBOY_SIM_CHAINS = 1 switches it off (2-4 force a count).
+// flags of the events that fork and join the chains (same device on both sides).  hipEventDisableSystemFence would buy 0.3 us per step of
+// a 20-step rollout (profiles/r5_a/event_flags_ab.log) and is NOT used: the consumer kernels behind the join read the other chain's
+// half of the state and rely on the event's release
+#ifndef RB_CHAIN_EVENT_FLAGS
+#define RB_CHAIN_EVENT_FLAGS hipEventDisableTiming
+#endif
 #ifndef RB_CHAIN_BATCH_RK4
 #define RB_CHAIN_BATCH_RK4 98304
 #endif
@@ -1465,11 +1471,11 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
     bool forked = false;
     auto fork = [&]() -> int {       // the further chains start behind everything the handle's stream holds so far
         if (chains == 1 || forked) return RB_OK;
-        if (!s->chain_fork) RB_HIP(hipEventCreateWithFlags(&s->chain_fork, hipEventDisableTiming));
+        if (!s->chain_fork) RB_HIP(hipEventCreateWithFlags(&s->chain_fork, RB_CHAIN_EVENT_FLAGS));
         for (int c = 1; c < chains; ++c)
             if (!s->chain_stream[c]) {
                 RB_HIP(hipStreamCreateWithFlags(&s->chain_stream[c], hipStreamNonBlocking));
-                RB_HIP(hipEventCreateWithFlags(&s->chain_join[c], hipEventDisableTiming));
+                RB_HIP(hipEventCreateWithFlags(&s->chain_join[c], RB_CHAIN_EVENT_FLAGS));
             }
         // (a stream that reports everything done has nothing for the chains to wait for: saves the two calls' ~5 us of host time in
         // front of the first launch of a short rollout)
