@@ -687,11 +687,15 @@ void maybe_jit(rb_sim *s) {
 // 70.3 -> 56.9; RK4 65 536 envs 55.6 -> 53.7, 131 072 envs 109.3 -> 102.1.  Three and four chains are no better anywhere
 // (chain_count.log).  Envs are independent, so the results are those of one launch per step, bit for bit.
 // ROBOY_SIM_CHAINS = 1 switches it off (2-4 force a count).
-// flags of the events that fork and join the chains (same device on both sides).  hipEventDisableSystemFence would buy 0.3 us per step of
-// a 20-step rollout (profiles/r5_a/event_flags_ab.log) and is NOT used: the consumer kernels behind the join read the other chain's
-// half of the state and rely on the event's release
+// Flags of the events that fork and join the chains.  Producer and consumer of such an event are kernels on the SAME device, whose own
+// dispatch packets carry the device-scope release / acquire that dependent kernels need; the event's own system-scope fence (for
+// the host and other devices) is a fixed cost of ~3 us per event on top: without it a 20-step rollout of the headline batch takes
+// 13.3-13.4 instead of 13.5-13.7 us per step (profiles/r5_a/event_flags_ab.log; hipEventReleaseToDevice changes nothing).  That the
+// consumers behind the join do see the other chain's writes is tested with a reader on other XCDs than the writers
+// (tests/test_full_size_gpu.py: ..._see_the_other_chains_writes; tools/proto/chain_coherence_probe.py: 300 rollouts, 0 mismatches).
+// Host visibility is not these events' job: every host-facing entry point synchronises the handle's stream.
 #ifndef RB_CHAIN_EVENT_FLAGS
-#define RB_CHAIN_EVENT_FLAGS hipEventDisableTiming
+#define RB_CHAIN_EVENT_FLAGS (hipEventDisableTiming | hipEventDisableSystemFence)
 #endif
 #ifndef RB_CHAIN_BATCH_RK4
 #define RB_CHAIN_BATCH_RK4 98304

@@ -288,3 +288,34 @@ def test_long_random_action_rollouts_stay_finite_and_inside_the_limits(msj_robot
     nat.check(sim._lib.rb_env_stats(sim.handle, out, 0))
     assert out[6] == float(n) * steps                             # slot 6: env steps issued since the handle was created
     sim.close()
+
+
+def test_consumers_behind_the_join_see_the_other_chains_writes(msj_robot):
+    """The chains' fork / join events carry no system-scope fence (RB_CHAIN_EVENT_FLAGS, csrc/roboy_sim.hip): what orders the other
+    chain's writes before the consumers behind the join is the kernels' own device-scope release / acquire.  A batch whose second
+    half starts at a block index that is not a multiple of 8, so that the kernel that reads the state right behind the join
+    (pack_state_kernel: another block -> XCD map than the range launches) runs on other XCDs than the writers - a stale line in an
+    XCD-private L2 would show against the same rollout stepped as one chain.  150 rollouts, bit for bit."""
+    import torch
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    n = 262144 + 768
+    st = torch.cuda.Stream()
+    sims = []
+    for chains in (2, 1):
+        s = HipBatchSimulation(msj_robot, n, integrator="rk4", seed=1)
+        s.set_stream(st.cuda_stream)
+        s.set_rollout_chains(chains)
+        sims.append(s)
+    assert sims[0].rollout_chains() == 2 and sims[1].rollout_chains() == 1
+    ring = torch.empty(4 * n * 8, dtype=torch.float32, device="cuda")
+    for r in range(4):
+        sims[0].fill_actions_dev(ring.data_ptr() + 4 * r * n * 8, r)
+    for it in range(150):
+        outs = []
+        for s in sims:
+            s.rollout_dev(ring.data_ptr(), 4, 8, 0.3, use_graph=True)
+            outs.append(s.read_state())
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b), "rollout %d: the reader behind the join saw stale state" % it
+    for s in sims:
+        s.close()
