@@ -36,7 +36,9 @@ is the MEAN over the repeats of (max over ranks of the region's wall time) / K
 reduced the statistics in every region) and ``value`` the env steps of all ranks
 in one region divided by that time.
 
-N > 1: launched by torch.distributed.run, one rank per GPU; envs shard
+N > 1: one rank per GPU under torch.distributed.run - started by the caller (WORLD_SIZE set: behave as a rank) or, when
+`python bench.py --gpus N` is run bare, by bench.py itself as a fresh child process tree before any GPU call
+(``self_launch``: rank 0's line is relayed, the exit code is the launcher's); envs shard
 contiguously (weak scaling: the per-GPU batch is fixed), no data-path
 collective; every STATS_EVERY = 100 steps (counted across the timed regions) the
 rank's episode statistics (8 doubles) are reduced on the device and all-reduced
@@ -86,22 +88,50 @@ VALU_PEAK = 157.3e12       # flop/s, fp32 vector peak (MI355X_MICROARCH.md "Peak
 VALU_FMA_MEASURED = 64 * 2 * 1024 / 1.20e-9
 KERNEL_NAMES = {1: "msj_step_env_per_lane", 2: "msj_step_tendon_per_lane", 3: "tree_step_aba", 5: "msj_step_mirror_pairs"}
 TREE_KERNEL_NAMES = {1: "tree_lane_step", 3: "tree_step_aba", 4: "tree_split_step", 6: "tree_split_step"}   # joint trees: env-per-lane (generated) / octets / several waves per env group
-PROFILE_DIRS = ("r5_a", "r4_a", "r3_a", "r2_a", "r1_b")   # newest first: where the committed rocprofv3 PMC passes live
+PROFILE_DIRS = ("r6_a", "r5_a", "r4_a", "r3_a", "r2_a", "r1_b")   # newest first: where the committed rocprofv3 PMC passes live
+GENERATED_HEADERS = ("tree_lane_baked.hpp", "tree_lane_split_baked.hpp", "tree_lane_split2_baked.hpp")   # `make` output, git-ignored
+
+
+def csrc_hash():
+    """16 hex digits over everything the kernels are built from: the tracked sources under gym_roboy_amd/csrc (the generated
+    headers are functions of them), the robot descriptions and the two generator scripts.  Profile summaries are stamped with it
+    at collection (tools/summarize_profile.py); a stamp that differs from the tree's hash marks a counter row as stale."""
+    import glob
+    import hashlib
+    files = []
+    for pat in ("gym_roboy_amd/csrc/*.hip", "gym_roboy_amd/csrc/*.hpp", "gym_roboy_amd/csrc/*.cpp", "gym_roboy_amd/csrc/Makefile",
+                "gym_roboy_amd/envs/robots/data/*.json", "tools/gen_tree_lane_baked.py", "tools/gen_msj_baked.py"):
+        files += glob.glob(os.path.join(ROOT, pat))
+    h = hashlib.sha256()
+    for f in sorted(set(files)):
+        if os.path.basename(f) in GENERATED_HEADERS:
+            continue
+        h.update(os.path.relpath(f, ROOT).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+_PMC_CACHE = {}
 
 
 def pmc_traffic(workload):
-    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC
-    passes (profiles/<round>/hbm_traffic_pmc.json: separate --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE runs of this workload, FETCH_SIZE doubled as the gfx950
-    guide prescribes).  PMC collection cannot run inside the timed bench, so the
-    number is the profiled one, not a live one; None if the workload was not profiled."""
+    """(HBM bytes per launch, source file, stale) of the step kernel from the committed rocprofv3 PMC passes
+    (profiles/<round>/hbm_traffic_pmc.json: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this workload, FETCH_SIZE
+    doubled as the gfx950 guide prescribes).  PMC collection cannot run inside the timed bench, so the number is the profiled
+    one, not a live one.  The NEWEST profile directory that holds the workload answers; `stale` is True unless that entry was
+    stamped, at collection, with the hash of the kernel sources this tree has (csrc_hash) - an older round's row is never passed
+    off as this library's.  (None, None, None) if the workload was never profiled."""
+    if "hash" not in _PMC_CACHE:
+        _PMC_CACHE["hash"] = csrc_hash()
     for d in PROFILE_DIRS:
         try:
             with open(os.path.join(ROOT, "profiles", d, "hbm_traffic_pmc.json")) as fh:
-                return json.load(fh)[workload]["hbm_bytes_per_launch"], "profiles/%s/hbm_traffic_pmc.json" % d
+                entry = json.load(fh)[workload]
+            return entry["hbm_bytes_per_launch"], "profiles/%s/hbm_traffic_pmc.json" % d, entry.get("csrc_hash") != _PMC_CACHE["hash"]
         except Exception:
             continue
-    return None, None
+    return None, None, None
 
 
 def flops_per_env_step(robot_name, integrator, substeps, kernel=None):
@@ -140,9 +170,9 @@ def roofline(robot_name, integrator, substeps, n_envs, bytes_per_env_step, launc
                 "flops_per_env_step": flops, "flops_per_launch": flops * n_envs,
                 "source": "profiles/flops_per_env_step.json (instrumented restatement, oracle/flop_count.cpp)"}
     top = valu if (valu is not None and valu["frac"] > hbm["frac"]) else hbm
-    traffic, src = pmc_traffic(workload) if workload else (None, None)
+    traffic, src, stale = pmc_traffic(workload) if workload else (None, None, None)
     return {"bound": "valu" if top is valu else "hbm", "achieved": top["achieved"], "peak": top["peak"],
-            "unit": top["unit"], "frac": top["frac"], "traffic": traffic, "traffic_source": src,
+            "unit": top["unit"], "frac": top["frac"], "traffic": traffic, "traffic_source": src, "traffic_stale": stale,
             "launch_us_events": launch_s * 1e6, "launches_per_step": chains, "envs_per_launch": n_envs // chains if chains > 1 else n_envs,
             "hbm": hbm, "valu": valu}
 
@@ -622,7 +652,25 @@ def build_line(head, also, one_launch, cpu, world, robot_name, use_graph):
         r = (by_name.get(w) or {}).get("roofline") or {}
         if r.get("traffic"):
             toa[w] = r["traffic"] / r["hbm"]["bytes_per_launch"]
+    # scalars first: the driver's record keeps the scalar fields of `roofline`, so north_star's claims must be readable off them alone.
+    # `frac` follows the contract (HIP events on the launch stream around a region's K launches, median over the repeats);
+    # `frac_wall` is the same ratio from `ms_per_step`, the wall-clock mean that `value` is built on (barrier, synchronisation and
+    # the amortised statistics reduction included) - always the smaller of the two.
+    step_wall_s = head["ms_per_step"] * 1e-3
+    hbm_wall = rf["hbm"]["bytes_per_launch"] / step_wall_s / HBM_PEAK
+    valu_wall = (rf["valu"]["flops_per_launch"] / step_wall_s / VALU_PEAK) if rf.get("valu") else None
+
+    def row_frac(w, col):
+        return configs[w][col] if w in configs else None
     roof = {"bound": rf["bound"], "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"], "frac": rf["frac"],
+            "frac_wall": valu_wall if rf["bound"] == "valu" else hbm_wall,
+            "hbm_frac": rf["hbm"]["frac"], "valu_frac": (rf.get("valu") or {}).get("frac"),
+            "hbm_frac_wall": hbm_wall, "valu_frac_wall": valu_wall,
+            "one_launch_frac": (one_launch or {}).get("frac"), "one_launch_hbm_frac": (one_launch or {}).get("hbm_frac"),
+            "euler_262144_hbm_frac": row_frac("msj-262144-euler", 1), "euler_2097152_hbm_frac": row_frac("msj-2097152-euler", 1),
+            "fused_env_2097152_hbm_frac": row_frac("fused-env-2097152", 1),
+            "traffic_over_algorithmic": (rf["traffic"] / rf["hbm"]["bytes_per_launch"]) if rf.get("traffic") else None,
+            "traffic_stale": rf.get("traffic_stale"),
             "traffic": rf["traffic"], "traffic_source": rf.get("traffic_source"), "kernel": head["kernel"],
             "launch_us_events": rf["launch_us_events"], "launches_per_step": chains, "envs_per_launch": rf["envs_per_launch"],
             "hbm": {k: rf["hbm"][k] for k in ("achieved", "peak", "frac", "bytes_per_env_step", "bytes_per_launch")},
@@ -631,7 +679,7 @@ def build_line(head, also, one_launch, cpu, world, robot_name, use_graph):
             "one_launch_us": (one_launch or {}).get("us_events"),
             "one_launch": ({k: one_launch[k] for k in ("us_events", "frac", "hbm_frac")} if one_launch else None),
             "configs_cols": ["us_events", "hbm_frac", "valu_frac", "launches_per_step"], "configs": configs,
-            "traffic_over_algorithmic": toa,
+            "traffic_over_algorithmic_rows": toa,
             "note": "us_events = HIP events on the launch stream around a region's K steps, median, / K; rocprofv3 in profiles/"}
     cpu_c = None
     if cpu is not None:
@@ -683,8 +731,81 @@ def format_line(line):
     return json.dumps(out, separators=(",", ":"), allow_nan=False)
 
 
+LAUNCH_TIMEOUT_S = float(os.environ.get("ROBOY_BENCH_LAUNCH_TIMEOUT", "1500"))   # the parent of a self-started N-rank run gives up after this
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_argv(n, port, argv):
+    """The command the driver's contract names for N > 1 (one rank per GPU, rendezvous on 127.0.0.1), around this file."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n, argv, timeout=None):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks as a fresh CHILD process tree (never an exec of
+    this process, and before this process has made any GPU call - it never makes one), relay rank 0's one JSON line to stdout,
+    let the children's stderr through, return the launcher's exit code; on this process's own timeout or SIGTERM / SIGINT the
+    whole child process group is killed.  The reference's axis: `SubprocVecEnv` of `num_cpu` workers, train_parallel.py:19-29."""
+    import signal
+    timeout = LAUNCH_TIMEOUT_S if timeout is None else timeout
+    cmd = launcher_argv(n, free_port(), argv)
+    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %s\n" % (n, " ".join(cmd)))
+    sys.stderr.flush()
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, cwd=ROOT, start_new_session=True)
+
+    def kill_group(sig=signal.SIGKILL):
+        try:
+            os.killpg(proc.pid, sig)          # start_new_session: the launcher leads its own process group (pgid = its pid)
+        except (ProcessLookupError, PermissionError):
+            pass
+
+    def on_signal(signum, _frame):
+        kill_group(signal.SIGTERM)
+        time.sleep(2.0)
+        kill_group()
+        sys.exit(128 + signum)
+
+    previous = {s: signal.signal(s, on_signal) for s in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+        rc = proc.returncode
+    except subprocess.TimeoutExpired:
+        kill_group(signal.SIGTERM)
+        try:
+            out, _ = proc.communicate(timeout=10)
+        except subprocess.TimeoutExpired:
+            kill_group()
+            out, _ = proc.communicate()
+        sys.stderr.write("bench.py: the %d-rank run did not finish within %.0f s: killed\n" % (n, timeout))
+        rc = 124
+    finally:
+        for s, h in previous.items():
+            signal.signal(s, h)
+        kill_group()                           # nothing of the child tree outlives this call
+    lines = [l for l in (out or "").splitlines() if l.strip()]
+    contract = [l for l in lines if l.lstrip().startswith("{")]
+    for l in lines:                            # anything else a library wrote to the ranks' stdout: not on ours
+        if l not in contract:
+            sys.stderr.write(l + "\n")
+    if contract:
+        sys.stdout.write(contract[-1].strip() + "\n")
+        sys.stdout.flush()
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks printed no contract line\n")
+        rc = 5
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     # stdout carries exactly one JSON line.  Libraries below write there on their own
     # (RCCL prints a version banner on stdout when its first communicator comes up), so
     # file descriptor 1 points at stderr until the line is ready.
@@ -697,8 +818,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit("--gpus %d under a launcher that set WORLD_SIZE=1: start bench.py without one (it starts its own ranks) "
+                         "or with --nproc-per-node %d" % (args.gpus, args.gpus))
     from gym_roboy_amd.envs.robots import MsjRobot, UpperBodyRobot
     robot = UpperBodyRobot() if args.workload.startswith("upper-body") else MsjRobot()
     # CPU baseline first: its Python env workers are separate processes, started while this

@@ -687,16 +687,29 @@ void maybe_jit(rb_sim *s) {
 // 70.3 -> 56.9; RK4 65 536 envs 55.6 -> 53.7, 131 072 envs 109.3 -> 102.1.  Three and four chains are no better anywhere
 // (chain_count.log).  Envs are independent, so the results are those of one launch per step, bit for bit.
 // ROBOY_SIM_CHAINS = 1 switches it off (2-4 force a count).
-// Flags of the events that fork and join the chains.  Producer and consumer of such an event are kernels on the SAME device, whose own
-// dispatch packets carry the device-scope release / acquire that dependent kernels need; the event's own system-scope fence (for
-// the host and other devices) is a fixed cost of ~3 us per event on top: without it a 20-step rollout of the headline batch takes
-// 13.3-13.4 instead of 13.5-13.7 us per step (profiles/r5_a/event_flags_ab.log; hipEventReleaseToDevice changes nothing).  That the
-// consumers behind the join do see the other chain's writes is tested with a reader on other XCDs than the writers
-// (tests/test_full_size_gpu.py: ..._see_the_other_chains_writes; tools/proto/chain_coherence_probe.py: 300 rollouts, 0 mismatches).
-// Host visibility is not these events' job: every host-facing entry point synchronises the handle's stream.
+// Flags of the events that fork and join the chains.  Producer and consumer of such an event are kernels on the SAME device; the
+// event's own system-scope release (for the host and other devices) is a fixed cost of ~3 us per event: without it a 20-step rollout
+// of the headline batch takes 13.3-13.4 instead of 13.5-13.7 us per step (profiles/r5_a/event_flags_ab.log).  What the fence-free form
+// rests on is read off the packets, not inferred (profiles/r6_a/chain_fence_scopes.log, ROCm 7.2.0 / HIP 7.2, AMD_LOG_LEVEL=4): every
+// kernel dispatch packet of a chain - eager or replayed from a graph - is written with acquire and release fence scope >= agent, the
+// event's marker is a barrier packet whose own release scope drops from system to agent with the flag, and the waiting stream's
+// barrier packet acquires at agent scope: the XCD-private L2s are written back / invalidated at agent scope on both sides of the
+// join, which is all a same-device consumer needs.  Host visibility is not these events' job: every host-facing entry point
+// synchronises the handle's stream.  Guard tests with readers on other XCDs than the writers: tests/test_full_size_gpu.py
+// (..._see_the_other_chains_writes: graph chains, eager head + trailing partial turn, the upper body's chains).
+// ROBOY_SIM_EVENT_SYSTEM_FENCE=1 restores the system-scope events at run time (another ROCm, a doubt, an A/B); a HIP without the
+// flag builds the fenced form.
 #ifndef RB_CHAIN_EVENT_FLAGS
+#ifdef hipEventDisableSystemFence
 #define RB_CHAIN_EVENT_FLAGS (hipEventDisableTiming | hipEventDisableSystemFence)
+#else
+#define RB_CHAIN_EVENT_FLAGS hipEventDisableTiming
 #endif
+#endif
+inline unsigned chain_event_flags() {
+    static const bool fenced = [] { const char *e = std::getenv("ROBOY_SIM_EVENT_SYSTEM_FENCE"); return e && e[0] == '1'; }();
+    return fenced ? unsigned(hipEventDisableTiming) : unsigned(RB_CHAIN_EVENT_FLAGS);
+}
 #ifndef RB_CHAIN_BATCH_RK4
 #define RB_CHAIN_BATCH_RK4 98304
 #endif
@@ -1010,7 +1023,7 @@ int note_caller_stream(rb_sim *s, hipStream_t st) {
         } else {
             // (completion is all drain() needs from it - not host visibility of the launch's writes: no system-scope fence on the
             // caller's stream behind every range launch, ~3 us each)
-            RB_HIP(hipEventCreateWithFlags(&slot->done, hipEventDisableTiming | hipEventDisableSystemFence));
+            RB_HIP(hipEventCreateWithFlags(&slot->done, chain_event_flags()));
         }
         slot->stream = st;
     }
@@ -1477,11 +1490,11 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
     bool forked = false;
     auto fork = [&]() -> int {       // the further chains start behind everything the handle's stream holds so far
         if (chains == 1 || forked) return RB_OK;
-        if (!s->chain_fork) RB_HIP(hipEventCreateWithFlags(&s->chain_fork, RB_CHAIN_EVENT_FLAGS));
+        if (!s->chain_fork) RB_HIP(hipEventCreateWithFlags(&s->chain_fork, chain_event_flags()));
         for (int c = 1; c < chains; ++c)
             if (!s->chain_stream[c]) {
                 RB_HIP(hipStreamCreateWithFlags(&s->chain_stream[c], hipStreamNonBlocking));
-                RB_HIP(hipEventCreateWithFlags(&s->chain_join[c], RB_CHAIN_EVENT_FLAGS));
+                RB_HIP(hipEventCreateWithFlags(&s->chain_join[c], chain_event_flags()));
             }
         // (a stream that reports everything done has nothing for the chains to wait for: saves the two calls' ~5 us of host time in
         // front of the first launch of a short rollout)

@@ -82,8 +82,19 @@ def test_the_drivers_exact_command_prints_one_capped_line():
         assert us > 0 and hbm > 0 and launches >= 1, w
     # north_star's HBM evidence readable off the line alone: the Euler shard and the 2 M Euler batch
     assert r["configs"]["msj-262144-euler"][1] > 0.4 and r["configs"]["msj-2097152-euler"][1] > 0.4
-    assert set(r["traffic_over_algorithmic"]) == {"msj-262144-euler", "msj-2097152-euler"}
-    assert all(0.9 < x < 1.5 for x in r["traffic_over_algorithmic"].values())
+    assert set(r["traffic_over_algorithmic_rows"]) == {"msj-262144-euler", "msj-2097152-euler"}
+    assert all(0.9 < x < 1.5 for x in r["traffic_over_algorithmic_rows"].values())
+    # ... and as SCALARS of `roofline` (the driver's record keeps the scalar fields): both fractions from the events and from the
+    # wall clock `value` is built on, the one-launch figure, the three HBM-bound rows, traffic over algorithmic bytes of the headline
+    assert r["hbm_frac"] == r["hbm"]["frac"] and r["valu_frac"] == r["valu"]["frac"] == r["frac"]
+    assert 0.8 * r["frac"] < r["frac_wall"] < r["frac"] and r["frac_wall"] == r["valu_frac_wall"]
+    assert abs(r["frac_wall"] - 3036 * 262144 / (d["ms_per_step"] * 1e-3) / 157.3e12) < 2e-4 * r["frac_wall"]
+    assert abs(r["hbm_frac_wall"] - 84 * 262144 / (d["ms_per_step"] * 1e-3) / 8e12) < 2e-4 * r["hbm_frac_wall"]
+    assert r["one_launch_frac"] == r["one_launch"]["frac"] < r["frac"]
+    assert r["euler_262144_hbm_frac"] == r["configs"]["msj-262144-euler"][1] > 0.4
+    assert r["euler_2097152_hbm_frac"] == r["configs"]["msj-2097152-euler"][1] > 0.4
+    assert r["fused_env_2097152_hbm_frac"] == r["configs"]["fused-env-2097152"][1] > 0.4
+    assert 0.9 < r["traffic_over_algorithmic"] < 1.5 and r["traffic_stale"] in (False, True)
     # wall time per step (barrier + sync around 20 launches + the amortised statistics reduction) close to the device-event time per
     # step: 6-9 % apart on the boxes of rounds 4-5 (HSA_ENABLE_INTERRUPT=0 changes nothing: the waits poll already); 20 % = a bug
     assert d["ms_per_step"] * 1e3 < 1.20 * r["launch_us_events"]
@@ -166,3 +177,20 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert c["n_env_steps_allreduced"] == 2 * 262144.0 * (16 + 5 + 20 * 4)
     assert d["cpu_baseline"] is None and d["roofline"]["configs"] == {}
     assert d["roofline"]["one_launch"] is None          # N > 1: the one-launch leg runs with --one-launch only
+
+
+def test_bare_gpus_2_starts_its_own_ranks_over_gloo():
+    """`python3 bench.py --gpus 2 --steps 20 --warmup 5` WITHOUT a launcher (the driver's N = 1 command with another N): the
+    parent starts torch.distributed.run itself as a child before any GPU call, relays rank 0's one line, exits 0.  Two ranks
+    share the box's one GPU, collectives over gloo (throughput means nothing here)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ROBOY_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _check_line(out.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["config"]["total_envs"] == 2 * 262144
+    c = d["collective"]
+    assert c["ok"] and c["world_size"] == 2 and c["backend"] == "gloo"
+    assert c["n_env_steps_allreduced"] == c["expected"] == 2 * 262144.0 * (16 + 5 + 20 * (d["repeats"] + 2))
+    assert d["cpu_baseline"] is None and "starting" in out.stderr

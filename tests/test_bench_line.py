@@ -78,7 +78,15 @@ def test_worst_case_line_stays_under_the_cap_and_parses_strictly(nan):
     assert "also" not in d
     r = d["roofline"]
     assert set(r["configs"]) == set(bench.CONFIG_ROWS) and all(len(row) == len(r["configs_cols"]) == 4 for row in r["configs"].values())
-    assert set(r["traffic_over_algorithmic"]) == set(bench.TRAFFIC_ROWS)
+    assert set(r["traffic_over_algorithmic_rows"]) == set(bench.TRAFFIC_ROWS)
+    # the scalars the driver's record keeps: north_star's claims readable without the nested objects
+    for key in ("frac", "frac_wall", "hbm_frac", "valu_frac", "hbm_frac_wall", "valu_frac_wall", "one_launch_frac", "one_launch_hbm_frac",
+                "euler_262144_hbm_frac", "euler_2097152_hbm_frac", "fused_env_2097152_hbm_frac", "traffic_over_algorithmic", "traffic_stale"):
+        assert key in r and not isinstance(r[key], (dict, list)), key
+    assert r["euler_262144_hbm_frac"] == r["configs"]["msj-262144-euler"][1] and r["fused_env_2097152_hbm_frac"] == r["configs"]["fused-env-2097152"][1]
+    assert abs(r["frac_wall"] - 3036 * 262144 / (head["ms_per_step"] * 1e-3) / 157.3e12) < 1e-4 * r["frac_wall"]
+    if not nan:
+        assert abs(r["traffic_over_algorithmic"] - LONG / (84 * 262144)) < 1e-4 * r["traffic_over_algorithmic"]
     assert r["hbm"]["frac"] > 0 and r["valu"]["frac"] > 0 and r["one_launch_us"] > 0 and len(r["note"]) <= 120
     # value and ms_per_step survive unrounded (the driver recomputes one from the other); counts survive exactly
     assert d["value"] == head["value"] and d["ms_per_step"] == head["ms_per_step"]
@@ -102,3 +110,83 @@ def test_strict_parser_rejects_what_the_lenient_one_accepts():
         strict_loads('{"a": NaN}')
     assert bench.sanitize({"a": float("nan"), "b": [float("-inf"), 1.5]}) == {"a": None, "b": [None, 1.5]}
     assert bench.sig(123456.789) == 123460.0 and bench.sig(896794624.0) == 896794624 and bench.sig(float("nan")) is None
+
+
+# ---- `python bench.py --gpus N` without a launcher starts its own ranks (bench.self_launch) ----
+
+_FAKE_RANKS = r"""
+import os, sys, time
+mode = sys.argv[1]
+if mode == "ok":
+    print("NCCL version banner that a library wrote to stdout")
+    sys.stderr.write("rank noise on stderr\n")
+    print('{"metric":"m","value":1.5,"n_gpus":2}')
+elif mode == "fail":
+    sys.stderr.write("bench.py needs a GPU\n")
+    sys.exit(7)
+elif mode == "silent":
+    pass
+elif mode == "hang":
+    import subprocess
+    child = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(600)"])
+    open(sys.argv[2], "w").write("%d %d" % (os.getpid(), child.pid))
+    time.sleep(600)
+"""
+
+
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    try:                                         # a zombie still answers kill(pid, 0)
+        with open("/proc/%d/stat" % pid) as fh:
+            return fh.read().split(")")[-1].split()[0] != "Z"
+    except OSError:
+        return False
+
+
+def test_launcher_argv_is_the_contracts_command():
+    cmd = bench.launcher_argv(8, 29555, ["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[4:10] == ["--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29555"]
+    assert cmd[10] == os.path.join(ROOT, "bench.py") and cmd[11:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert 1024 < bench.free_port() < 65536
+
+
+@pytest.mark.parametrize("mode,rc,line", [("ok", 0, True), ("fail", 7, False), ("silent", 5, False)])
+def test_self_launch_relays_one_line_and_the_exit_code(monkeypatch, capfd, mode, rc, line):
+    monkeypatch.setattr(bench, "launcher_argv", lambda n, port, argv: [sys.executable, "-c", _FAKE_RANKS, mode])
+    assert bench.self_launch(2, ["--gpus", "2"]) == rc
+    out, err = capfd.readouterr()
+    lines = [l for l in out.splitlines() if l.strip()]
+    if line:
+        assert lines == ['{"metric":"m","value":1.5,"n_gpus":2}']
+        assert "NCCL version banner" in err and "rank noise" in err      # the ranks' stdout noise is not ours
+    else:
+        assert lines == []
+
+
+def test_self_launch_kills_the_whole_child_tree_on_its_timeout(monkeypatch, tmp_path, capfd):
+    import time
+    pidfile = str(tmp_path / "pids")
+    monkeypatch.setattr(bench, "launcher_argv", lambda n, port, argv: [sys.executable, "-c", _FAKE_RANKS, "hang", pidfile])
+    t0 = time.time()
+    assert bench.self_launch(2, ["--gpus", "2"], timeout=3.0) == 124
+    assert time.time() - t0 < 30
+    pids = [int(p) for p in open(pidfile).read().split()]
+    time.sleep(0.5)
+    assert len(pids) == 2 and not any(_alive(p) for p in pids)
+    assert "did not finish" in capfd.readouterr().err
+
+
+def test_bare_gpus_2_starts_two_ranks_instead_of_a_usage_exit():
+    """Without a GPU the ranks stop at 'bench.py needs a GPU' - but they were started (round 5: exit 1 with a usage message)."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-also"], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert "starting" in out.stderr and "torch.distributed.run" in out.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert out.returncode != 0 and "needs a GPU" in out.stderr and out.stdout.strip() == ""

@@ -290,32 +290,47 @@ def test_long_random_action_rollouts_stay_finite_and_inside_the_limits(msj_robot
     sim.close()
 
 
-def test_consumers_behind_the_join_see_the_other_chains_writes(msj_robot):
+@pytest.mark.parametrize("case", ["graphs", "eager-head-graphs-tail", "upper-body"])
+def test_consumers_behind_the_join_see_the_other_chains_writes(msj_robot, case):
     """The chains' fork / join events carry no system-scope fence (RB_CHAIN_EVENT_FLAGS, csrc/roboy_sim.hip): what orders the other
-    chain's writes before the consumers behind the join is the kernels' own device-scope release / acquire.  A batch whose second
-    half starts at a block index that is not a multiple of 8, so that the kernel that reads the state right behind the join
-    (pack_state_kernel: another block -> XCD map than the range launches) runs on other XCDs than the writers - a stale line in an
-    XCD-private L2 would show against the same rollout stepped as one chain.  150 rollouts, bit for bit."""
+    chain's writes before the consumers behind the join is the packets' own agent-scope release / acquire
+    (profiles/r6_a/chain_fence_scopes.log).  A batch whose second half starts at a block index that is not a multiple of 8, so
+    that the kernel that reads the state right behind the join (pack_state_kernel: another block -> XCD map than the range
+    launches) runs on other XCDs than the writers - a stale line in an XCD-private L2 would show against the same rollout stepped
+    as one chain.  Bit for bit, in every shape a rollout call takes:
+      graphs                   8 steps: the chains' graphs alone (150 rollouts)
+      eager-head-graphs-tail   22 steps: one ring turn of plain launches on both chains, 16-step graphs, the join, two trailing
+                               whole-batch launches on the handle's stream (they read what the other chain wrote)
+      upper-body               the joint-tree chains (one wave per 64 envs, env-major rows) with a trailing partial turn"""
     import torch
     from gym_roboy_amd.envs.simulations import HipBatchSimulation
-    n = 262144 + 768
+    if case == "upper-body":
+        from gym_roboy_amd.envs.robots import UpperBodyRobot
+        robot, n, integrator, steps, iters = UpperBodyRobot(), 65536 + 192, "euler", 18, 25
+    else:
+        robot, n, integrator = msj_robot, 262144 + 768, "rk4"
+        steps, iters = (8, 150) if case == "graphs" else (22, 60)
+    n_t = robot.get_description().n_t
     st = torch.cuda.Stream()
     sims = []
     for chains in (2, 1):
-        s = HipBatchSimulation(msj_robot, n, integrator="rk4", seed=1)
+        s = HipBatchSimulation(robot, n, integrator=integrator, seed=1)
         s.set_stream(st.cuda_stream)
         s.set_rollout_chains(chains)
         sims.append(s)
     assert sims[0].rollout_chains() == 2 and sims[1].rollout_chains() == 1
-    ring = torch.empty(4 * n * 8, dtype=torch.float32, device="cuda")
+    ring = torch.empty(4 * n * n_t, dtype=torch.float32, device="cuda")
     for r in range(4):
-        sims[0].fill_actions_dev(ring.data_ptr() + 4 * r * n * 8, r)
-    for it in range(150):
+        sims[0].fill_actions_dev(ring.data_ptr() + 4 * r * n * n_t, r)
+    for it in range(iters):
         outs = []
         for s in sims:
-            s.rollout_dev(ring.data_ptr(), 4, 8, 0.3, use_graph=True)
+            s.rollout_dev(ring.data_ptr(), 4, steps, 0.3, use_graph=True)
             outs.append(s.read_state())
         for a, b in zip(*outs):
             assert np.array_equal(a, b), "rollout %d: the reader behind the join saw stale state" % it
+        if case == "upper-body" and it % 8 == 7:      # keep the trees inside their boxes: restart from the reset state
+            for s in sims:
+                s.forward_reset_command()
     for s in sims:
         s.close()

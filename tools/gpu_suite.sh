@@ -26,6 +26,6 @@ print('steps 20: value %.4g, ms_per_step %.5f (median %.5f), events %.2f us, fra
       % (d['value'], d['ms_per_step'], d['ms_per_step_median'], r['launch_us_events'], r['frac'], r['bound'], r['one_launch_us'] or 0))
 for w, row in r['configs'].items():
     print('   %-34s %s' % (w, row))
-print('   traffic/algorithmic', r['traffic_over_algorithmic'])
+print('   traffic/algorithmic', r['traffic_over_algorithmic'], r.get('traffic_over_algorithmic_rows'), 'frac_wall', r.get('frac_wall'))
 print('   cpu', d['cpu_baseline'])
 PY
