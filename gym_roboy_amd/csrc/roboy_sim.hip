@@ -688,17 +688,19 @@ void maybe_jit(rb_sim *s) {
 // (chain_count.log).  Envs are independent, so the results are those of one launch per step, bit for bit.
 // ROBOY_SIM_CHAINS = 1 switches it off (2-4 force a count).
 // Flags of the events that fork and join the chains.  Producer and consumer of such an event are kernels on the SAME device; the
-// event's own system-scope release (for the host and other devices) is a fixed cost of ~3 us per event: without it a 20-step rollout
-// of the headline batch takes 13.3-13.4 instead of 13.5-13.7 us per step (profiles/r5_a/event_flags_ab.log).  What the fence-free form
-// rests on is read off the packets, not inferred (profiles/r6_a/chain_fence_scopes.log, ROCm 7.2.0 / HIP 7.2, AMD_LOG_LEVEL=4): every
-// kernel dispatch packet of a chain - eager or replayed from a graph - is written with acquire and release fence scope >= agent, the
-// event's marker is a barrier packet whose own release scope drops from system to agent with the flag, and the waiting stream's
-// barrier packet acquires at agent scope: the XCD-private L2s are written back / invalidated at agent scope on both sides of the
-// join, which is all a same-device consumer needs.  Host visibility is not these events' job: every host-facing entry point
-// synchronises the handle's stream.  Guard tests with readers on other XCDs than the writers: tests/test_full_size_gpu.py
-// (..._see_the_other_chains_writes: graph chains, eager head + trailing partial turn, the upper body's chains).
-// ROBOY_SIM_EVENT_SYSTEM_FENCE=1 restores the system-scope events at run time (another ROCm, a doubt, an A/B); a HIP without the
-// flag builds the fenced form.
+// event's own system-scope release + acquire (for the host and other devices) is a fixed cost of ~3 us per event: without it a 20-step
+// rollout of the headline batch takes 13.3-13.4 instead of 13.5-13.7 us per step (profiles/r5_a/event_flags_ab.log).  What the
+// fence-free form rests on is read off the packets (profiles/r6_a/chain_fence_scopes.log: ROCclr's packet log of a two-chain rollout,
+// HIP 7.2.26015 / ROCm 7.2.0): EVERY kernel dispatch packet of a chain - eager or replayed from a graph, 75 of 75 - carries header
+// 0xb02 = barrier, acquire scope AGENT, release scope AGENT, with or without the flag; the event's marker is a barrier packet whose
+// header goes from 0x1500 (acquire / release scope system) to 0x100 (completion only) with the flag; the waiting stream's barrier
+// packet carries no fence in either mode.  So the join is: producer kernel (agent-scope release at its end) -> marker (completion
+// signal) -> wait -> consumer kernel (agent-scope acquire at its start) - the XCD-private L2s are written back / invalidated at agent
+// scope by the kernels' own packets, which is all a same-device consumer needs.  Host visibility is not these events' job: every
+// host-facing entry point ends in hipStreamSynchronize (its barrier packet keeps system scope).  Guard tests with readers on other XCDs
+// than the writers: tests/test_full_size_gpu.py::test_consumers_behind_the_join_see_the_other_chains_writes (graph chains; eager head +
+// graphs + trailing whole-batch launches; the upper body's chains).  ROBOY_SIM_EVENT_SYSTEM_FENCE=1 restores the system-scope events at
+// run time (another ROCm, a doubt, an A/B); a HIP without the flag builds the fenced form.
 #ifndef RB_CHAIN_EVENT_FLAGS
 #ifdef hipEventDisableSystemFence
 #define RB_CHAIN_EVENT_FLAGS (hipEventDisableTiming | hipEventDisableSystemFence)
