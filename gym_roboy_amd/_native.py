@@ -18,7 +18,13 @@ LIB_PATH = os.environ.get("ROBOY_SIM_LIB") or os.path.join(_HERE, "csrc", "libro
 RB_OK, RB_EINVAL, RB_EUNSUPPORTED, RB_EHIP, RB_ENOMEM = range(5)
 RB_EULER, RB_RK4 = 0, 1
 RB_KERNEL_AUTO, RB_KERNEL_ENV_PER_LANE, RB_KERNEL_TENDON_PER_LANE, RB_KERNEL_ENV_PER_WAVE = 0, 1, 2, 3
-RB_KERNEL_ENV_PER_LANE_SPLIT, RB_KERNEL_LANE_PAIR = 4, 5
+RB_KERNEL_ENV_PER_LANE_SPLIT, RB_KERNEL_LANE_PAIR, RB_KERNEL_ENV_PER_LANE_SPLIT2 = 4, 5, 6
+KERNEL_NAMES = {1: "env_per_lane", 2: "tendon_per_lane", 3: "env_per_wave", 4: "env_per_lane_split", 5: "lane_pair", 6: "env_per_lane_split2"}
+CLASS_NAMES = {0: "ball8", 1: "ballx", 2: "tree"}
+ENTRY_NAMES = {0: "step", 1: "env_step", 2: "fused_rollout"}
+ENTRIES = {v: k for k, v in ENTRY_NAMES.items()}
+CONSTANTS_NAMES = {0: "kernarg", 1: "table", 2: "jit"}
+RB_NEED_MIRROR, RB_NEED_NO_MIRROR, RB_NEED_SPLIT_TABLE, RB_NEED_SPLIT2_TABLE, RB_NEED_LANE = 1, 2, 4, 8, 16
 
 INTEGRATORS = {"euler": RB_EULER, "semi-implicit-euler": RB_EULER, "rk4": RB_RK4,
                RB_EULER: RB_EULER, RB_RK4: RB_RK4}
@@ -33,6 +39,31 @@ class SimInfo(ctypes.Structure):
                 ("kernel", ctypes.c_int32), ("device", ctypes.c_int32),
                 ("step_size", ctypes.c_double), ("bytes_per_env_step", ctypes.c_int64),
                 ("env_id_offset", ctypes.c_int64)]
+
+
+class DispatchRow(ctypes.Structure):
+    """One row of the library's dispatch table (include/roboy_sim.h: rb_dispatch_row)."""
+    _fields_ = [("robot_class", ctypes.c_int32), ("entry", ctypes.c_int32), ("kernel", ctypes.c_int32), ("integrator", ctypes.c_int32),
+                ("block", ctypes.c_int32), ("constants", ctypes.c_int32), ("variant", ctypes.c_int32), ("ranges", ctypes.c_int32)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+    def row_id(self):
+        """A stable, readable name: class/entry/form/integrator/b<block>/constants/v<variant>."""
+        return "%s/%s/%s/%s/b%d/%s/v%d" % (CLASS_NAMES[self.robot_class], ENTRY_NAMES[self.entry], KERNEL_NAMES[self.kernel],
+                                           "euler" if self.integrator == RB_EULER else "rk4", self.block, CONSTANTS_NAMES[self.constants],
+                                           self.variant)
+
+
+class AutoRule(ctypes.Structure):
+    _fields_ = [("robot_class", ctypes.c_int32), ("entry", ctypes.c_int32), ("integrator", ctypes.c_int32), ("needs", ctypes.c_int32),
+                ("min_envs_exclusive", ctypes.c_int64), ("max_envs", ctypes.c_int64), ("kernel", ctypes.c_int32), ("_pad", ctypes.c_int32)]
+
+
+class LaunchThresholds(ctypes.Structure):
+    _fields_ = [(name, ctypes.c_int64) for name in ("small_batch", "pair_small_batch", "chain_batch_rk4", "chain_batch_euler",
+                                                    "chain_batch_tree_rk4", "chain_batch_tree_euler", "eager_head_batch_rk4", "tree_jit_batch")]
 
 
 class EnvConfig(ctypes.Structure):
@@ -89,6 +120,10 @@ SIGNATURES = {
     "rb_env_step_dev": (ctypes.c_int, [_sim, _vp, _vp, _vp, _vp]),
     "rb_env_stats": (ctypes.c_int, [_sim, ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
     "rb_env_stats_dev": (ctypes.c_int, [_sim, _vp, ctypes.c_int]),
+    "rb_dispatch_rows": (ctypes.c_int, [ctypes.POINTER(ctypes.POINTER(DispatchRow))]),
+    "rb_auto_rules": (ctypes.c_int, [ctypes.POINTER(ctypes.POINTER(AutoRule))]),
+    "rb_get_launch_thresholds": (ctypes.c_int, [ctypes.POINTER(LaunchThresholds)]),
+    "rb_dispatch_current": (ctypes.c_int, [_sim, ctypes.c_int, ctypes.POINTER(DispatchRow)]),
     "rb_malloc": (ctypes.c_int, [_sim, ctypes.c_int64, ctypes.POINTER(_vp)]),
     "rb_free": (ctypes.c_int, [_sim, _vp]),
     "rb_memcpy_h2d": (ctypes.c_int, [_sim, _vp, _vp, ctypes.c_int64]),
@@ -149,6 +184,44 @@ def check(rc):
         if rc == RB_EINVAL:
             raise ValueError(msg)
         raise NativeError("libroboy_sim error %d: %s" % (rc, msg))
+
+
+def dispatch_rows():
+    """The library's dispatch table as a list of DispatchRow copies (static data: no GPU needed)."""
+    ptr = ctypes.POINTER(DispatchRow)()
+    n = load().rb_dispatch_rows(ctypes.byref(ptr))
+    rows = []
+    for i in range(n):
+        r = DispatchRow()
+        ctypes.pointer(r)[0] = ptr[i]
+        rows.append(r)
+    return rows
+
+
+def auto_rules():
+    """RB_KERNEL_AUTO's rules, in order (first match wins), as dicts."""
+    ptr = ctypes.POINTER(AutoRule)()
+    n = load().rb_auto_rules(ctypes.byref(ptr))
+    return [{name: getattr(ptr[i], name) for name, _ in AutoRule._fields_ if name != "_pad"} for i in range(n)]
+
+
+def launch_thresholds():
+    t = LaunchThresholds()
+    check(load().rb_get_launch_thresholds(ctypes.byref(t)))
+    return {name: getattr(t, name) for name, _ in LaunchThresholds._fields_}
+
+
+def auto_kernel(robot_class, entry, integrator, needs, n_envs):
+    """What RB_KERNEL_AUTO picks for a handle of this class / entry / integrator with these abilities (RB_NEED_* bits) and batch
+    size - evaluated from the library's exported rules, never restated."""
+    for r in auto_rules():
+        if r["robot_class"] != robot_class or r["entry"] not in (-1, entry) or r["integrator"] not in (-1, integrator):
+            continue
+        if (r["needs"] & needs) != r["needs"]:
+            continue
+        if r["min_envs_exclusive"] < n_envs <= r["max_envs"]:
+            return r["kernel"]
+    raise LookupError("no AUTO rule applies")
 
 
 def device_count():

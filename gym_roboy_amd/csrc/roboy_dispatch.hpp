@@ -307,14 +307,11 @@ const Row TABLE[] = {
     {{CLS_BALL8, ENTRY_STEP, F_PAIR, EU, 256, SRC_KERNARG, 1}, true, l_msj_step_pair<0, 256, 1, false>},
     {{CLS_BALL8, ENTRY_STEP, F_PAIR, RK, 256, SRC_KERNARG, 0}, true, l_msj_step_pair<1, 256, 0, false>},
     {{CLS_BALL8, ENTRY_STEP, F_PAIR, RK, 256, SRC_KERNARG, 1}, true, l_msj_step_pair<1, 256, 1, false>},
+    // (the ahead-of-time table is MsjRobot's, whose mirror plane is x-z: no table rows for the y-z variant)
     {{CLS_BALL8, ENTRY_STEP, F_PAIR, EU, 64, SRC_TABLE, 0}, true, l_msj_step_pair<0, 64, 0, true>},
-    {{CLS_BALL8, ENTRY_STEP, F_PAIR, EU, 64, SRC_TABLE, 1}, true, l_msj_step_pair<0, 64, 1, true>},
     {{CLS_BALL8, ENTRY_STEP, F_PAIR, RK, 64, SRC_TABLE, 0}, true, l_msj_step_pair<1, 64, 0, true>},
-    {{CLS_BALL8, ENTRY_STEP, F_PAIR, RK, 64, SRC_TABLE, 1}, true, l_msj_step_pair<1, 64, 1, true>},
     {{CLS_BALL8, ENTRY_STEP, F_PAIR, EU, 256, SRC_TABLE, 0}, true, l_msj_step_pair<0, 256, 0, true>},
-    {{CLS_BALL8, ENTRY_STEP, F_PAIR, EU, 256, SRC_TABLE, 1}, true, l_msj_step_pair<0, 256, 1, true>},
     {{CLS_BALL8, ENTRY_STEP, F_PAIR, RK, 256, SRC_TABLE, 0}, true, l_msj_step_pair<1, 256, 0, true>},
-    {{CLS_BALL8, ENTRY_STEP, F_PAIR, RK, 256, SRC_TABLE, 1}, true, l_msj_step_pair<1, 256, 1, true>},
     // ---- 8-tendon ball joints, fused env step
     {{CLS_BALL8, ENTRY_ENV, F_LANE, EU, 64, SRC_KERNARG, 0}, true, l_msj_env<0, 64, 8, false>},
     {{CLS_BALL8, ENTRY_ENV, F_LANE, RK, 64, SRC_KERNARG, 0}, true, l_msj_env<1, 64, 8, false>},
@@ -337,13 +334,9 @@ const Row TABLE[] = {
     {{CLS_BALL8, ENTRY_ENV, F_PAIR, RK, 256, SRC_KERNARG, 0}, true, l_msj_env_pair<1, 256, 0, false>},
     {{CLS_BALL8, ENTRY_ENV, F_PAIR, RK, 256, SRC_KERNARG, 1}, true, l_msj_env_pair<1, 256, 1, false>},
     {{CLS_BALL8, ENTRY_ENV, F_PAIR, EU, 64, SRC_TABLE, 0}, true, l_msj_env_pair<0, 64, 0, true>},
-    {{CLS_BALL8, ENTRY_ENV, F_PAIR, EU, 64, SRC_TABLE, 1}, true, l_msj_env_pair<0, 64, 1, true>},
     {{CLS_BALL8, ENTRY_ENV, F_PAIR, RK, 64, SRC_TABLE, 0}, true, l_msj_env_pair<1, 64, 0, true>},
-    {{CLS_BALL8, ENTRY_ENV, F_PAIR, RK, 64, SRC_TABLE, 1}, true, l_msj_env_pair<1, 64, 1, true>},
     {{CLS_BALL8, ENTRY_ENV, F_PAIR, EU, 256, SRC_TABLE, 0}, true, l_msj_env_pair<0, 256, 0, true>},
-    {{CLS_BALL8, ENTRY_ENV, F_PAIR, EU, 256, SRC_TABLE, 1}, true, l_msj_env_pair<0, 256, 1, true>},
     {{CLS_BALL8, ENTRY_ENV, F_PAIR, RK, 256, SRC_TABLE, 0}, true, l_msj_env_pair<1, 256, 0, true>},
-    {{CLS_BALL8, ENTRY_ENV, F_PAIR, RK, 256, SRC_TABLE, 1}, true, l_msj_env_pair<1, 256, 1, true>},
     // ---- 8-tendon ball joints, open-loop fused rollout (whole batches)
     {{CLS_BALL8, ENTRY_FUSED, F_LANE, EU, 64, SRC_KERNARG, 0}, false, l_msj_fused<0, 64, 8, false>},
     {{CLS_BALL8, ENTRY_FUSED, F_LANE, RK, 64, SRC_KERNARG, 0}, false, l_msj_fused<1, 64, 8, false>},
@@ -518,6 +511,7 @@ inline bool resolve(rb_sim *s, int entry, bool build, Key &k, std::string *why =
     }
     k.block = s->n <= RB_SMALL_BATCH ? 64 : 256;
     if (s->ntx) return true;
+    if (build) maybe_jit(s);                                             // (large batches of another 8-tendon robot: its own instances, once)
     if (s->baked) k.src = SRC_TABLE;
     else if (k.block == 256 && s->jit_state == 1) k.src = SRC_JIT;       // (hiprtc instances exist for the large-batch configuration only)
     return true;

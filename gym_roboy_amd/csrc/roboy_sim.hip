@@ -59,7 +59,7 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // AUTO picks the tendon-per-lane form up to this many envs (measured crossover,
 // profiles/r1_b/sweep.log: Euler 2.9 vs 3.5 us at 8 192 and a tie at 16 384; RK4
 // 6.2 vs 7.0 us at 16 384 and 10.2 vs 7.1 us at 32 768)
-// (round 4, robots with a mirror plane: the two-lanes-per-env form takes over from 4 096 / 12 288 envs - auto_kernel())
+// (round 4, robots with a mirror plane: the two-lanes-per-env form takes over from 4 096 / 12 288 envs - roboy_dispatch.hpp: AUTO_RULES)
 #ifndef RB_TENDON_LANE_BATCH_EULER
 #define RB_TENDON_LANE_BATCH_EULER 8192
 #endif
@@ -173,6 +173,21 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #endif
 #ifndef RB_PAIR_BATCH_RK4
 #define RB_PAIR_BATCH_RK4 32768
+#endif
+// The fused env layer of an 8-tendon ball-joint robot has its own AUTO thresholds (the accounting behind the step shifts the
+// crossovers): two lanes per env up to here where the robot has a mirror plane (profiles/r5_a/env_pairs_sweep.log) ...
+#ifndef RB_PAIR_ENV_BATCH_EULER
+#define RB_PAIR_ENV_BATCH_EULER 24576
+#endif
+#ifndef RB_PAIR_ENV_BATCH_RK4
+#define RB_PAIR_ENV_BATCH_RK4 32768
+#endif
+// ... and eight lanes per env below that (any 8-tendon ball-joint robot; profiles/r5_a/env_octets_sweep.log)
+#ifndef RB_OCTET_ENV_BATCH_EULER
+#define RB_OCTET_ENV_BATCH_EULER 8192
+#endif
+#ifndef RB_OCTET_ENV_BATCH_RK4
+#define RB_OCTET_ENV_BATCH_RK4 8192
 #endif
 using namespace rbk;    // the env-per-lane kernels (msj_kernels.hpp), EnvParams, GoalBox, ...
 
@@ -568,35 +583,27 @@ int jit_level() {      // ROBOY_SIM_JIT: 0 = never, 1 (default) = from the batch
     return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
 }
 
-// does this handle run the env-per-lane form of the joint-tree kernels?  (explicit choice, or AUTO with instances at hand /
-// worth building)
-bool tree_wants_lane(const rb_sim *s) {
-    if (!s->tree || !s->lane_ok || s->kernel_choice == RB_KERNEL_ENV_PER_WAVE) return false;
-    if (s->kernel_choice == RB_KERNEL_ENV_PER_LANE || s->lane_baked) return true;
+// AUTO's own condition for the one-wave-per-64-envs form of the joint-tree kernels: instances at hand, or worth building
+bool tree_wants_lane_auto(const rb_sim *s) {
+    if (!s->tree || !s->lane_ok) return false;
+    if (s->lane_baked) return true;
     const int lvl = jit_level();
     return s->lane_gen.max_live <= RB_TREE_LANE_MAX_LIVE && (lvl == 2 || (lvl == 1 && s->n >= RB_TREE_JIT_BATCH));
 }
-
-// does this handle run the split form (several waves per 64 envs) of the plain step?  An explicit choice, or AUTO with
-// ahead-of-time instances and a batch small enough that its waves still find a SIMD each
-bool tree_wants_split(const rb_sim *s) {
-    if (!s->tree || !s->split_ok) return false;
-    if (s->kernel_choice == RB_KERNEL_ENV_PER_LANE_SPLIT) return true;
-    return s->kernel_choice == RB_KERNEL_AUTO && s->split_baked && s->n <= RB_TREE_SPLIT_BATCH;
+// may this handle run that form?  (an explicit choice, AUTO's condition, or as what the split forms degrade to)
+bool tree_wants_lane(const rb_sim *s) {
+    if (!s->tree || !s->lane_ok || s->kernel_choice == RB_KERNEL_ENV_PER_WAVE) return false;
+    return s->kernel_choice == RB_KERNEL_ENV_PER_LANE || tree_wants_lane_auto(s);
 }
+
+bool tree_wants_split(const rb_sim *s);      // (defined behind the dispatch table: AUTO's rules decide)
+bool tree_wants_split2(const rb_sim *s);
 // the lean layout's formula (tree_lane_split.hpp, RBL_LEAN): q | qd | goal, the exchange area over the action / observation image, flags
 size_t split_lean_lds_bytes(const rblg::SplitGenerated &g) {
     const int img = 3 * g.n_q + (3 * g.n_q > g.n_t ? 3 * g.n_q : g.n_t);
     int shared = g.x_buffers * g.x_slots > img - 3 * g.n_q ? g.x_buffers * g.x_slots : img - 3 * g.n_q;
     if (shared < 4 * g.n_q) shared = 4 * g.n_q;
     return size_t(3 * g.n_q + shared + 3 * g.n_parts + 1) * 64 * 4;
-}
-// does this handle run the lean two-part split form?  An explicit choice (any robot with a split plan: hiprtc), or AUTO between the
-// five-wave form's batch and a wave on every SIMD where ahead-of-time instances exist
-bool tree_wants_split2(const rb_sim *s) {
-    if (!s->tree || !s->split2_ok) return false;
-    if (s->kernel_choice == RB_KERNEL_ENV_PER_LANE_SPLIT2) return true;      // (rb_select_kernel has built the kernels of a robot without instances)
-    return s->kernel_choice == RB_KERNEL_AUTO && s->split2_baked && s->n > RB_TREE_SPLIT_BATCH && s->n <= RB_TREE_SPLIT2_BATCH;
 }
 size_t split_lds_bytes(const rblg::SplitGenerated &g) {      // the formula of tree_lane_split.hpp: SP_LDS_BYTES
     const int img = 3 * g.n_q + (3 * g.n_q > g.n_t ? 3 * g.n_q : g.n_t);
@@ -658,14 +665,6 @@ rblj::Kernel *lane_kernel(rb_sim *s, int kind) {
     }
     return &k;
 }
-// true if this call runs the lane form (ahead-of-time or built instances)
-bool tree_use_lane(rb_sim *s, int kind) {
-    bool lane = tree_wants_lane(s);
-    if (lane && !s->lane_baked) lane = lane_kernel(s, kind)->state == 1;
-    s->kernel = lane ? RB_KERNEL_ENV_PER_LANE : RB_KERNEL_ENV_PER_WAVE;     // what rb_info reports
-    return lane;
-}
-
 void maybe_jit(rb_sim *s) {
     if (s->tree) { if (tree_wants_lane(s) && !s->lane_baked) (void)lane_kernel(s, 0); return; }
     if (s->jit_state != 0) return;
@@ -724,16 +723,28 @@ inline unsigned chain_event_flags() {
 #ifndef RB_CHAIN_BATCH_TREE_RK4
 #define RB_CHAIN_BATCH_TREE_RK4 65536
 #endif
-bool tree_use_lane(rb_sim *s, int which);
-// kernel forms that step a sub-range of the batch (shifted pointers, own env count): what chains and the rb_*_range_dev entry points need
+#include "roboy_dispatch.hpp"
+
+// does this handle run the split form (several waves per 64 envs)?  An explicit choice, or AUTO's rule (ahead-of-time instances
+// and a batch small enough that its waves still find a SIMD each) ...
+bool tree_wants_split(const rb_sim *s) {
+    if (!s->tree || !s->split_ok) return false;
+    if (s->kernel_choice == RB_KERNEL_ENV_PER_LANE_SPLIT) return true;
+    return s->kernel_choice == RB_KERNEL_AUTO && auto_form(s, ENTRY_STEP) == F_SPLIT;
+}
+// ... or the lean two-part split form?  An explicit choice (any robot with a split plan: hiprtc), or AUTO between the five-wave
+// form's batch and a wave on every SIMD where ahead-of-time instances exist
+bool tree_wants_split2(const rb_sim *s) {
+    if (!s->tree || !s->split2_ok) return false;
+    if (s->kernel_choice == RB_KERNEL_ENV_PER_LANE_SPLIT2) return true;      // (rb_select_kernel has built the kernels of a robot without instances)
+    return s->kernel_choice == RB_KERNEL_AUTO && auto_form(s, ENTRY_STEP) == F_SPLIT2;
+}
+
+// kernel forms that step a sub-range of the batch (shifted pointers, own env count): what chains and the rb_*_range_dev entry points
+// need.  A pure query: the row of what is at hand, no build (rb_rollout_dev / rb_step_range_dev / rb_range_capable build first).
 bool range_capable(const rb_sim *s) {
-    if (s->tree) {      // the one-wave-per-64-envs form (env-major rows), not the split form and not the octets
-        if (tree_wants_split2(s)) return false;
-        if (tree_wants_split(s) && (s->split_baked || s->split_step_k.state == 1)) return false;
-        // (asks again on every call: a lane kernel whose build a stream capture deferred becomes available afterwards)
-        return tree_use_lane(const_cast<rb_sim *>(s), 0);
-    }
-    return !s->ntx && s->kernel != RB_KERNEL_TENDON_PER_LANE;
+    const Row *r = row_for(const_cast<rb_sim *>(s), ENTRY_STEP, /*build=*/false);
+    return r && r->ranges;
 }
 bool chainable(const rb_sim *s) { return range_capable(s) && (s->tree || s->n > RB_SMALL_BATCH); }
 int rollout_chains(const rb_sim *s) {
@@ -745,232 +756,27 @@ int rollout_chains(const rb_sim *s) {
     return s->n >= (s->integrator == RB_EULER ? RB_CHAIN_BATCH_EULER : RB_CHAIN_BATCH_RK4) ? 2 : 1;
 }
 
-// the env-per-lane step on baked constants: U = RS is a kernel of its own (msj_step_env_per_lane_rs: the rolled-stages form)
-template <int INTEG, int B, int U>
-void launch_baked_step(unsigned blocks, hipStream_t stream, const Const8 &c8, float *q, float *qd, uint32_t *feas, const float *act,
-                       const Scale8 &us, long n, long cnt) {
-    if constexpr (U == RS) hipLaunchKernelGGL((msj_step_env_per_lane_rs<INTEG, B, true>), dim3(blocks), dim3(B), 0, stream, c8, q, qd, feas, act, us, n, cnt);
-    else hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U, true>), dim3(blocks), dim3(B), 0, stream, c8, q, qd, feas, act, us, n, cnt);
-}
-
 // does rb_rollout_dev put one ring turn of plain launches in front of its graphs?  Where a step kernel outlasts the host's
 // launches of a step (~3.5 us each, one per chain) with room to spare: ball joints, RK4, from 196 608 envs on (20-step rollouts
 // of the headline batch 13.7 -> 13.4 us per step; at 131 072 envs and for the joint trees it is a wash: head_sweep.log);
 // ROBOY_SIM_EAGER_HEAD=0 / 1 forces it off / on
+#ifndef RB_EAGER_HEAD_BATCH_RK4
+#define RB_EAGER_HEAD_BATCH_RK4 196608
+#endif
 bool rollout_eager_head(const rb_sim *s, int chains) {
     static const int forced = [] { const char *e = getenv("ROBOY_SIM_EAGER_HEAD"); return e ? atoi(e) : -1; }();
     if (forced >= 0) return forced != 0;
     if (s->tree) return false;
-    return !s->ntx && s->integrator == RB_RK4 && s->n >= 196608;
+    return !s->ntx && s->integrator == RB_RK4 && s->n >= RB_EAGER_HEAD_BATCH_RK4;
 }
 
-// envs [i0, i1) on `stream` (i1 < 0: the whole batch on the handle's stream).  Only the env-per-lane kernels of the ball-joint class
-// take a sub-range (rb_rollout_dev's chains ask for nothing else).
+// the physics step over envs [i0, i1) on `stream` (i1 < 0: the whole batch on the handle's stream): one row of the dispatch table
 int launch_step(rb_sim *s, const float *d_act, float act_scale, long i0 = 0, long i1 = -1, hipStream_t stream = nullptr) {
-    const long n = s->n;
-    const bool whole = i1 < 0;
-    if (whole) { i0 = 0; i1 = n; stream = s->stream; }
-    const long cnt = i1 - i0;
-    if (!whole && !range_capable(s)) return fail(RB_EINVAL, "this kernel form steps whole batches only");
-    // Small batches are latency-bound (a few waves per CU): one wave per
-    // workgroup spread over the CUs, tendon loop fully unrolled for ILP.
-    // Large batches are VALU-issue-bound: rolled tendon loop (one 16-dword
-    // scalar load per trip, 53 VGPRs, 8 waves/SIMD).  Measured: DESIGN.md §7.
-    Scale8 us;
-    for (int k = 0; k < NT8; ++k) us.v[k] = act_scale * s->c8.ten[k].ksg;
-    // (a sub-range is addressed by shifted pointers: the planes keep their stride n)
-    float *const rq = s->d_q + i0, *const rqd = s->d_qd + i0;
-    uint32_t *const rfeas = s->d_feas + i0;
-    const float *const ract = d_act + size_t(i0) * NT8;
-#define RB_STEP_LAUNCH(INTEG, B, U)                                                                   \
-    hipLaunchKernelGGL((msj_step_env_per_lane<INTEG, B, U>), dim3(blocks_for(cnt, B)), dim3(B), 0,    \
-                       stream, s->c8, rq, rqd, rfeas, ract, us, n, cnt)
-#define RB_STEP_LAUNCH_BK(INTEG, B, U)                                                                \
-    launch_baked_step<INTEG, B, U>(blocks_for(cnt, B), stream, s->c8, rq, rqd, rfeas, ract, us, n, cnt)
-
-    if (s->tree && tree_wants_split2(s)) {
-        // two part waves per 64 envs, two workgroups per CU (whole batches only)
-        s->kernel = RB_KERNEL_ENV_PER_LANE_SPLIT2;
-        if (s->split2_baked) {
-            rbs2::launch_step(s->integrator == RB_EULER ? 0 : 1, blocks_for(n, 64), s->stream, s->d_q, s->d_qd, s->d_feas, d_act, act_scale,
-                              s->tree_host.dev.h, s->tree_host.dev.nsub, n);
-        } else {
-            if (!build_split2_kernel(s, 0)) return fail(RB_EUNSUPPORTED, "lean split kernel not available: " + s->split2_step_k.why);
-            float *q = s->d_q, *qd = s->d_qd;
-            uint32_t *feas = s->d_feas;
-            float hh = s->tree_host.dev.h;
-            int ns = s->tree_host.dev.nsub;
-            long nn = n;
-            void *args[] = {&q, &qd, &feas, &d_act, &act_scale, &hh, &ns, &nn};
-            RB_HIP(hipModuleLaunchKernel(s->split2_step_k.fn, blocks_for(n, 64), 1, 1, 64u * unsigned(s->split2_gen.n_parts), 1, 1,
-                                         unsigned(split_lean_lds_bytes(s->split2_gen)), s->stream, args, nullptr));
-        }
-    } else if (s->tree && tree_wants_split(s) && (s->split_baked || s->split_step_k.state == 1)) {
-        // one workgroup of n_parts (+ helper) waves per 64 envs
-        const unsigned groups = blocks_for(n, 64);
-        const size_t lds = split_lds_bytes(s->split_gen);
-        const float h = s->tree_host.dev.h;
-        const int nsub = s->tree_host.dev.nsub;
-        const unsigned threads = 64u * unsigned(s->split_gen.n_parts + s->split_gen.n_helpers);
-        s->kernel = RB_KERNEL_ENV_PER_LANE_SPLIT;
-        if (s->split_baked) {
-            if (s->integrator == RB_EULER)
-                hipLaunchKernelGGL(rbl_split_baked::tree_split_step<0>, dim3(groups), dim3(threads), lds, s->stream, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, h, nsub, n);
-            else
-                hipLaunchKernelGGL(rbl_split_baked::tree_split_step<1>, dim3(groups), dim3(threads), lds, s->stream, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, h, nsub, n);
-        } else {
-            float *q = s->d_q, *qd = s->d_qd;
-            uint32_t *feas = s->d_feas;
-            float hh = h;
-            int ns = nsub;
-            long nn = n;
-            void *args[] = {&q, &qd, &feas, &d_act, &act_scale, &hh, &ns, &nn};
-            RB_HIP(hipModuleLaunchKernel(s->split_step_k.fn, groups, 1, 1, threads, 1, 1, unsigned(lds), s->stream, args, nullptr));
-        }
-    } else if (s->tree && tree_use_lane(s, 0)) {
-        // one wave (64 envs) per workgroup: the LDS regions admit four per CU, one per SIMD, and a small batch spreads over the CUs
-        // (rows are env-major: a sub-range is the same kernel on shifted pointers and its own env count)
-        const unsigned waves = blocks_for(cnt, 64);
-        const size_t lds = rblg::lane_lds_bytes_per_wave(s->lane_gen);
-        const float h = s->tree_host.dev.h;
-        const int nsub = s->tree_host.dev.nsub;
-        float *tq = s->d_q + size_t(i0) * s->n_q, *tqd = s->d_qd + size_t(i0) * s->n_q;
-        uint32_t *tfeas = s->d_feas + i0;
-        const float *tact = d_act + size_t(i0) * s->n_t;
-        if (s->lane_baked) {
-            if (s->integrator == RB_EULER)
-                hipLaunchKernelGGL(rbl_baked::tree_lane_step<0>, dim3(waves), dim3(64), lds, stream, tq, tqd, tfeas, tact, act_scale, h, nsub, cnt);
-            else
-                hipLaunchKernelGGL(rbl_baked::tree_lane_step<1>, dim3(waves), dim3(64), lds, stream, tq, tqd, tfeas, tact, act_scale, h, nsub, cnt);
-        } else {
-            float hh = h;
-            int ns = nsub;
-            long nn = cnt;
-            void *args[] = {&tq, &tqd, &tfeas, &tact, &act_scale, &hh, &ns, &nn};
-            RB_HIP(hipModuleLaunchKernel(s->lane_step_k.fn, waves, 1, 1, 64, 1, 1, unsigned(lds), stream, args, nullptr));
-        }
-    } else if (s->tree) {
-        const int wv = s->tree_waves;
-        const size_t lds = rbt::tree_lds_bytes(s->tree_host, wv);
-        const long per_block = long(wv) * rbt::TREE_E;
-        const unsigned tree_blocks = unsigned((n + per_block - 1) / per_block);
-#define RB_TREE_LAUNCH(INTEG, SP)                                                                                  \
-    hipLaunchKernelGGL((rbt::tree_step_aba<INTEG, rbt::TREE_E, SP>), dim3(tree_blocks), dim3(64 * wv), lds, s->stream, \
-                       s->tree_host.dev, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n)
-        const bool sp = s->tree_host.dev.single_pass != 0;
-        if (s->integrator == RB_EULER) { if (sp) RB_TREE_LAUNCH(0, true); else RB_TREE_LAUNCH(0, false); }
-        else                           { if (sp) RB_TREE_LAUNCH(1, true); else RB_TREE_LAUNCH(1, false); }
-#undef RB_TREE_LAUNCH
-    } else if (s->ntx) {
-#define RB_NT_LAUNCH(INTEG, B)                                                                          \
-    hipLaunchKernelGGL((msj_step_env_per_lane_nt<INTEG, B>), dim3(blocks_for(n, B)), dim3(B), 0,       \
-                       s->stream, s->cx, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n)
-        if (n <= RB_SMALL_BATCH) { if (s->integrator == RB_EULER) RB_NT_LAUNCH(0, 64); else RB_NT_LAUNCH(1, 64); }
-        else                     { if (s->integrator == RB_EULER) RB_NT_LAUNCH(0, 256); else RB_NT_LAUNCH(1, 256); }
-#undef RB_NT_LAUNCH
-    } else if (s->kernel == RB_KERNEL_LANE_PAIR) {
-        // two lanes per env: 128 envs per 256-thread workgroup (64-thread workgroups for small batches: spread over the CUs)
-        PairMap pm;
-        Scale4 us4;
-        for (int k = 0; k < 4; ++k) {
-            pm.a[k] = 4 * s->pair_half[k]; pm.d[k] = 4 * (s->pair_image[k] - s->pair_half[k]);
-            us4.v[k] = act_scale * s->c8.ten[s->pair_half[k]].ksg;
-        }
-#define RB_PAIR_LAUNCH(INTEG, B, M, BKF)                                                                          \
-    hipLaunchKernelGGL((msj_step_mirror_pairs<INTEG, B, M, BKF>), dim3(blocks_for(2 * cnt, B)), dim3(B), 0, stream, \
-                       s->c8p, pm, rq, rqd, rfeas, ract, us4, n, cnt)
-#define RB_PAIR_LAUNCH_B(INTEG, M, BKF)                                                                           \
-    do { if (n <= RB_PAIR_SMALL_BATCH) RB_PAIR_LAUNCH(INTEG, 64, M, BKF); else RB_PAIR_LAUNCH(INTEG, 256, M, BKF); } while (0)
-#define RB_PAIR_LAUNCH_M(INTEG, BKF)                                                                              \
-    do { if (s->pair_mirror == 0) RB_PAIR_LAUNCH_B(INTEG, 0, BKF); else RB_PAIR_LAUNCH_B(INTEG, 1, BKF); } while (0)
-        if (s->pair_baked) { if (s->integrator == RB_EULER) RB_PAIR_LAUNCH_M(0, true); else RB_PAIR_LAUNCH_M(1, true); }
-        else               { if (s->integrator == RB_EULER) RB_PAIR_LAUNCH_M(0, false); else RB_PAIR_LAUNCH_M(1, false); }
-#undef RB_PAIR_LAUNCH_M
-#undef RB_PAIR_LAUNCH_B
-#undef RB_PAIR_LAUNCH
-    } else if (s->kernel == RB_KERNEL_TENDON_PER_LANE) {
-        const unsigned g = blocks_for(n * NT8, 64);
-        if (s->integrator == RB_EULER)
-            hipLaunchKernelGGL((msj_step_tendon_per_lane<0>), dim3(g), dim3(64), 0, s->stream,
-                               s->c8, s->d_ten, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
-        else
-            hipLaunchKernelGGL((msj_step_tendon_per_lane<1>), dim3(g), dim3(64), 0, s->stream,
-                               s->c8, s->d_ten, s->d_q, s->d_qd, s->d_feas, d_act, act_scale, n);
-    } else if (n <= RB_SMALL_BATCH) {
-        if (s->baked) { if (s->integrator == RB_EULER) RB_STEP_LAUNCH_BK(0, 64, 8); else RB_STEP_LAUNCH_BK(1, 64, 8); }
-        else          { if (s->integrator == RB_EULER) RB_STEP_LAUNCH(0, 64, 8); else RB_STEP_LAUNCH(1, 64, 8); }
-    } else if (s->baked) {
-        if (s->integrator == RB_EULER) RB_STEP_LAUNCH_BK(0, RB_BIG_BLOCK_EULER, RB_BAKED_UNROLL_EULER);
-        else RB_STEP_LAUNCH_BK(1, RB_BIG_BLOCK_RK4, RB_BAKED_UNROLL_RK4);
-    } else if (s->jit_state == 1) {
-        // msj_step_env_per_lane<INTEG, 256, 4, true> of this robot's own module; same parameter list
-        Const8 c8 = s->c8;
-        float *q = rq, *qd = rqd;
-        uint32_t *feas = rfeas;
-        const float *a = ract;
-        long nn = n, cc = cnt;
-        void *args[] = {&c8, &q, &qd, &feas, &a, &us, &nn, &cc};
-        RB_HIP(hipModuleLaunchKernel(s->jit.step[s->integrator == RB_EULER ? 0 : 1], blocks_for(cnt, 256), 1, 1, 256, 1, 1, 0,
-                                     stream, args, nullptr));
-    } else {
-        if (s->integrator == RB_EULER) RB_STEP_LAUNCH(0, RB_BIG_BLOCK_EULER, RB_BIG_UNROLL_EULER);
-        else RB_STEP_LAUNCH(1, RB_BIG_BLOCK_RK4, RB_BIG_UNROLL_RK4);
-    }
-#undef RB_STEP_LAUNCH_BK
-#undef RB_STEP_LAUNCH
-    RB_HIP(hipGetLastError());
-    return RB_OK;
-}
-
-// AUTO for 8-tendon ball-joint robots: eight lanes per env for small batches (latency), then - if the robot has a mirror
-// plane - two lanes per env, one env per lane otherwise / beyond (thresholds measured: profiles/r4_a)
-int auto_kernel(const rb_sim *s) {
-    // measured (profiles/r4_a/mid_sweep.log, us per step, tendon per lane / two lanes per env / env per lane): RK4 8 192 envs
-    // 3.39 / 4.11 / 5.07, 16 384 envs 4.63 / 4.23 / 5.11, 32 768 envs 7.25 / 4.50 / 5.23, 49 152 envs 9.84 / 6.19 / 5.35; Euler
-    // 4 096 envs 2.21 / 2.22 / 2.43, 8 192 envs 2.34 / 2.25 / 2.45, 16 384 envs 2.79 / 2.38 / 2.49, 32 768 envs 3.58 / 2.68 / 2.62
-    const bool euler = s->integrator == RB_EULER;
-    if (s->pair_ok) {
-        if (s->n <= (euler ? RB_TENDON_LANE_BATCH_PAIR_EULER : RB_TENDON_LANE_BATCH_PAIR_RK4)) return RB_KERNEL_TENDON_PER_LANE;
-        if (s->n <= (euler ? RB_PAIR_BATCH_EULER : RB_PAIR_BATCH_RK4)) return RB_KERNEL_LANE_PAIR;
-        return RB_KERNEL_ENV_PER_LANE;
-    }
-    return s->n <= (euler ? RB_TENDON_LANE_BATCH_EULER : RB_TENDON_LANE_BATCH_RK4) ? RB_KERNEL_TENDON_PER_LANE : RB_KERNEL_ENV_PER_LANE;
-}
-
-// The form the fused env layer of an 8-tendon ball-joint robot takes: two lanes per env where the robot has a mirror plane and
-// the batch is small enough that the shorter instruction chain per wave is what counts (measured with a 50-step graph,
-// profiles/r5_a/env_pairs_sweep.log, us per env step, one env per lane -> two lanes per env: RK4 4 096 envs 5.49 -> 4.52,
-// 16 384 envs 5.69 -> 4.71, 32 768 envs 6.05 -> 5.17, 49 152 envs 6.44 -> 7.02; Euler 4 096 envs 2.90 -> 2.81, 16 384 envs
-// 3.07 -> 2.97, 32 768 envs 3.43 -> 3.46).  The env layer has no eight-lanes-per-env form, so - unlike the plain step -
-// the lower bound is the eight-lanes form's own (below).  An explicit rb_select_kernel decides otherwise: 5 = this form, 2 = eight
-// lanes per env, 1 = one env per lane.
-#ifndef RB_PAIR_ENV_BATCH_EULER
-#define RB_PAIR_ENV_BATCH_EULER 24576
-#endif
-#ifndef RB_PAIR_ENV_BATCH_RK4
-#define RB_PAIR_ENV_BATCH_RK4 32768
-#endif
-// ... and eight lanes per env below that (any 8-tendon ball-joint robot; rb_select_kernel(2) pins it).  Same kind of sweep
-// (profiles/r5_a/env_octets_sweep.log; eight lanes / two lanes / one lane per env): RK4 256 envs 3.38 / 4.39 / 5.36, 4 096 envs
-// 3.61 / 4.49 / 5.46, 8 192 envs 3.81 / 4.59 / 5.55, 12 288 envs 4.97 / 4.65 / 5.63; Euler 256 envs 2.35 / 2.70 / 2.80, 4 096 envs
-// 2.53 / 2.84 / 2.92, 8 192 envs 2.74 / 2.88 / 2.96, 12 288 envs 3.09 / 2.92 / 3.01
-#ifndef RB_OCTET_ENV_BATCH_EULER
-#define RB_OCTET_ENV_BATCH_EULER 8192
-#endif
-#ifndef RB_OCTET_ENV_BATCH_RK4
-#define RB_OCTET_ENV_BATCH_RK4 8192
-#endif
-bool env_uses_octets(const rb_sim *s) {
-    if (s->tree || s->ntx || !s->d_ten) return false;
-    if (s->kernel_choice == RB_KERNEL_TENDON_PER_LANE) return true;
-    if (s->kernel_choice != RB_KERNEL_AUTO) return false;
-    return s->n <= (s->integrator == RB_EULER ? RB_OCTET_ENV_BATCH_EULER : RB_OCTET_ENV_BATCH_RK4);
-}
-bool env_uses_pairs(const rb_sim *s) {
-    if (s->tree || s->ntx || !s->pair_ok || env_uses_octets(s)) return false;
-    if (s->kernel_choice == RB_KERNEL_LANE_PAIR) return true;
-    if (s->kernel_choice != RB_KERNEL_AUTO) return false;
-    return s->n <= (s->integrator == RB_EULER ? RB_PAIR_ENV_BATCH_EULER : RB_PAIR_ENV_BATCH_RK4);
+    Launch L;
+    if (i1 < 0) { L.i0 = 0; L.cnt = s->n; L.stream = s->stream; }
+    else        { L.i0 = i0; L.cnt = i1 - i0; L.stream = stream; }
+    L.act = d_act; L.act_scale = act_scale;
+    return dispatch(s, ENTRY_STEP, L);
 }
 
 int check(const rb_sim *s) {
@@ -1360,8 +1166,7 @@ int rb_select_kernel(rb_sim *s, int kernel) {
         }
         int rc = drop_graphs(s);             // graphs captured with another variant must not be replayed
         if (rc) { s->kernel_choice = before; return rc; }
-        s->kernel = tree_wants_split2(s) ? RB_KERNEL_ENV_PER_LANE_SPLIT2
-                  : tree_wants_split(s) ? RB_KERNEL_ENV_PER_LANE_SPLIT : (tree_wants_lane(s) ? RB_KERNEL_ENV_PER_LANE : RB_KERNEL_ENV_PER_WAVE);
+        { const int form = resolve_form(s, ENTRY_STEP, /*build=*/false, nullptr); s->kernel = form > 0 ? form : RB_KERNEL_ENV_PER_WAVE; }
         return RB_OK;
     }
     if (kernel == RB_KERNEL_ENV_PER_WAVE) return fail(RB_EUNSUPPORTED, "ball-joint robots have no env-per-wave kernel");
@@ -1371,7 +1176,7 @@ int rb_select_kernel(rb_sim *s, int kernel) {
     if (rc) return rc;
     s->kernel_choice = kernel;
     if (s->ntx) { s->kernel = RB_KERNEL_ENV_PER_LANE; return RB_OK; }
-    s->kernel = kernel != RB_KERNEL_AUTO ? kernel : auto_kernel(s);
+    s->kernel = kernel != RB_KERNEL_AUTO ? kernel : auto_form(s, ENTRY_STEP);
     return RB_OK;
 }
 
@@ -1542,7 +1347,7 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
         if (chunk < 8) break;
         rb_sim::GraphKey key;
         std::memset(&key, 0, sizeof(key));
-        key.ring_ptr = d_ring; key.ring = ring; key.chunk = chunk; key.scale = act_scale; key.kernel = s->kernel | (chains << 8);
+        key.ring_ptr = d_ring; key.ring = ring; key.chunk = chunk; key.scale = act_scale; { const Row *row = row_for(s, ENTRY_STEP, true); key.kernel = (row ? int(row - TABLE) : 0xffff) | (chains << 16); }
         auto it = s->graphs.find(key);
         if (it == s->graphs.end()) {
             { int rc = fork(); if (rc) return rc; }     // creates the chain streams
@@ -1597,6 +1402,7 @@ int rb_rollout_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, float 
 
 int rb_rollout_chains(rb_sim *s) {
     if (check(s)) return -1;
+    maybe_jit(s);                    // (what rb_rollout_dev would build first)
     return rollout_chains(s);
 }
 
@@ -1615,32 +1421,10 @@ int rb_rollout_fused_dev(rb_sim *s, const float *d_ring, int ring, int n_steps, 
     if (s->tree || s->ntx) return fail(RB_EUNSUPPORTED, "fused rollout is built for 8-tendon ball-joint robots");
     if (n_steps == 0) return RB_OK;
     const long n = s->n;
-    Scale8 us;
-    for (int k = 0; k < NT8; ++k) us.v[k] = act_scale * s->c8.ten[k].ksg;
-#define RB_FUSED_LAUNCH(INTEG, B, U)                                                                  \
-    hipLaunchKernelGGL((msj_rollout_fused<INTEG, B, U>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream, \
-                       s->c8, s->d_q, s->d_qd, s->d_feas, d_ring, ring, n_steps, us, n)
-#define RB_FUSED_LAUNCH_BK(INTEG, B, U)                                                               \
-    hipLaunchKernelGGL((msj_rollout_fused<INTEG, B, U, true>), dim3(blocks_for(n, B)), dim3(B), 0, s->stream, \
-                       s->c8, s->d_q, s->d_qd, s->d_feas, d_ring, ring, n_steps, us, n)
-    const bool euler = s->integrator == RB_EULER;
     maybe_jit(s);
-    if (s->jit_state == 1) {
-        // msj_rollout_fused<INTEG, 256, 4, true> of this robot's own module (the same instance family as its step kernel)
-        Const8 c8 = s->c8;
-        long nn = n;
-        void *args[] = {&c8, &s->d_q, &s->d_qd, &s->d_feas, &d_ring, &ring, &n_steps, &us, &nn};
-        RB_HIP(hipModuleLaunchKernel(s->jit.rollout[euler ? 0 : 1], blocks_for(n, 256), 1, 1, 256, 1, 1, 0, s->stream, args, nullptr));
-    } else
-    if (s->baked) {
-        if (n <= RB_SMALL_BATCH) { if (euler) RB_FUSED_LAUNCH_BK(0, 64, 8); else RB_FUSED_LAUNCH_BK(1, 64, 8); }
-        else                     { if (euler) RB_FUSED_LAUNCH_BK(0, RB_BIG_BLOCK_EULER, RB_BAKED_UNROLL_EULER); else RB_FUSED_LAUNCH_BK(1, RB_BIG_BLOCK_RK4, RB_BAKED_UNROLL_RK4); }
-    } else
-    if (n <= RB_SMALL_BATCH) { if (euler) RB_FUSED_LAUNCH(0, 64, 8); else RB_FUSED_LAUNCH(1, 64, 8); }
-    else                     { if (euler) RB_FUSED_LAUNCH(0, RB_BIG_BLOCK_EULER, RB_BIG_UNROLL_EULER); else RB_FUSED_LAUNCH(1, RB_BIG_BLOCK_RK4, RB_BIG_UNROLL_RK4); }
-#undef RB_FUSED_LAUNCH_BK
-#undef RB_FUSED_LAUNCH
-    RB_HIP(hipGetLastError());
+    Launch L;
+    L.i0 = 0; L.cnt = n; L.stream = s->stream; L.act = d_ring; L.act_scale = act_scale; L.ring = ring; L.n_steps = n_steps;
+    { int rc = dispatch(s, ENTRY_FUSED, L); if (rc) return rc; }
     s->env_steps += double(n) * n_steps;
     return RB_OK;
 }
@@ -1730,159 +1514,12 @@ int rb_env_set_goal(rb_sim *s, const float *goal_q, const uint32_t *step_num) {
     return RB_OK;
 }
 
-// RoboyEnv.step for envs [i0, i0 + cnt) on `stream`; the array arguments are those of the whole batch (offsets are applied here).
-// Sub-ranges: the env-per-lane kernels of the ball-joint class and the joint trees' one-wave-per-64-envs form.
+// RoboyEnv.step for envs [i0, i0 + cnt) on `stream`; the array arguments are those of the whole batch (the launchers apply the
+// offsets).  Sub-ranges: every ball-joint form and the joint trees' one-wave-per-64-envs form (Row::ranges).
 static int env_step_launch(rb_sim *s, long i0, long cnt, hipStream_t stream, const float *d_act, float *d_obs, float *d_reward, uint32_t *d_done) {
-    const long n = s->n;
-    const bool whole = i0 == 0 && cnt == n;
-    if (s->tree && tree_wants_split2(s)) {
-        if (!whole) return fail(RB_EUNSUPPORTED, "the split forms of the joint-tree kernels step whole batches only");
-        rbe::TreeEnvArgs ka{s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, s->d_ep_ret, s->d_goal_count, d_act,
-                            d_obs, d_reward, d_done, s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, s->tree_host.dev.h, s->tree_host.dev.nsub, n,
-                            s->seed, uint64_t(s->env0), n};
-        s->kernel = RB_KERNEL_ENV_PER_LANE_SPLIT2;
-        if (s->split2_baked) {
-            rbs2::launch_env_step(s->integrator == RB_EULER ? 0 : 1, blocks_for(n, 64), stream, ka);
-        } else {
-            if (!build_split2_kernel(s, 1)) return fail(RB_EUNSUPPORTED, "lean split env kernel not available: " + s->split2_env_k.why);
-            void *args[] = {&ka};
-            RB_HIP(hipModuleLaunchKernel(s->split2_env_k.fn, blocks_for(n, 64), 1, 1, 64u * unsigned(s->split2_gen.n_parts), 1, 1,
-                                         unsigned(split_lean_lds_bytes(s->split2_gen)), stream, args, nullptr));
-        }
-        RB_HIP(hipGetLastError());
-        return RB_OK;
-    }
-    if (s->tree && tree_wants_split(s) && (s->split_baked || build_split_kernel(s, 1))) {
-        if (!whole) return fail(RB_EUNSUPPORTED, "the split form of the joint-tree kernels steps whole batches only");
-        const unsigned groups = blocks_for(n, 64);
-        const size_t lds = split_lds_bytes(s->split_gen);
-        const float h = s->tree_host.dev.h;
-        const int nsub = s->tree_host.dev.nsub;
-        const unsigned threads = 64u * unsigned(s->split_gen.n_parts + s->split_gen.n_helpers);
-        // (one struct argument: the kernel reads most of it behind the step - env_common.hpp, TreeEnvArgs)
-        rbe::TreeEnvArgs ka{s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, s->d_ep_ret, s->d_goal_count, d_act,
-                            d_obs, d_reward, d_done, s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, h, nsub, n, s->seed, uint64_t(s->env0), n};
-        if (s->split_baked) {
-            if (s->integrator == RB_EULER) hipLaunchKernelGGL(rbl_split_baked::tree_split_env_step<0>, dim3(groups), dim3(threads), lds, stream, ka);
-            else hipLaunchKernelGGL(rbl_split_baked::tree_split_env_step<1>, dim3(groups), dim3(threads), lds, stream, ka);
-        } else {
-            void *args[] = {&ka};
-            RB_HIP(hipModuleLaunchKernel(s->split_env_k.fn, groups, 1, 1, threads, 1, 1, unsigned(lds), stream, args, nullptr));
-        }
-        RB_HIP(hipGetLastError());
-        return RB_OK;
-    }
-    if (s->tree && tree_use_lane(s, 1)) {
-        // env-major rows: a sub-range is the same kernel on shifted pointers and its own env count; the per-env statistics
-        // planes keep their stride n
-        const unsigned waves = blocks_for(cnt, 64);
-        const size_t lds = rblg::lane_lds_bytes_per_wave(s->lane_gen);
-        const float h = s->tree_host.dev.h;
-        const int nsub = s->tree_host.dev.nsub;
-        const size_t nq = size_t(s->n_q), nt = size_t(s->n_t);
-        float *tq = s->d_q + i0 * nq, *tqd = s->d_qd + i0 * nq, *tgoal = s->d_goal + i0 * nq, *tret = s->d_ep_ret + i0, *tobs = d_obs + i0 * 3 * nq, *trew = d_reward + i0;
-        uint32_t *tfeas = s->d_feas + i0, *tsn = s->d_step_num + i0, *tgc = s->d_goal_count + i0, *tdone = d_done + i0, *tcnt = s->d_ep_cnt + i0, *tinf = s->d_infeas_n + i0;
-        const float *tact = d_act + i0 * nt;
-        double *tsum = s->d_ep_sum + i0;
-        const uint64_t e0 = uint64_t(s->env0) + uint64_t(i0);
-        // (one struct argument: the kernel reads most of it behind the step - env_common.hpp, TreeEnvArgs)
-        rbe::TreeEnvArgs ka{s->env, s->box, tq, tqd, tfeas, tgoal, tsn, tret, tgc, tact, tobs, trew, tdone, tsum, tcnt, tinf, h, nsub, cnt, s->seed, e0, n};
-        if (s->lane_baked) {
-            if (s->integrator == RB_EULER) hipLaunchKernelGGL(rbl_baked::tree_lane_env_step<0>, dim3(waves), dim3(64), lds, stream, ka);
-            else hipLaunchKernelGGL(rbl_baked::tree_lane_env_step<1>, dim3(waves), dim3(64), lds, stream, ka);
-        } else {
-            void *args[] = {&ka};
-            RB_HIP(hipModuleLaunchKernel(s->lane_env_k.fn, waves, 1, 1, 64, 1, 1, unsigned(lds), stream, args, nullptr));
-        }
-        RB_HIP(hipGetLastError());
-        return RB_OK;
-    }
-    if (s->tree) {
-        if (!whole) return fail(RB_EUNSUPPORTED, "the octet form of the joint-tree kernels steps whole batches only");
-        const int wv = s->tree_waves;
-        const size_t lds = rbt::tree_lds_bytes(s->tree_host, wv);
-        const long per_block = long(wv) * rbt::TREE_E;
-#define RB_TREE_ENV_LAUNCH(INTEG, SP)                                                                        \
-    hipLaunchKernelGGL((rbt::tree_env_step_aba<INTEG, rbt::TREE_E, SP>), dim3(unsigned((n + per_block - 1) / per_block)), dim3(64 * wv), lds, stream, \
-                       s->tree_host.dev, s->env, s->box, s->d_q, s->d_qd, s->d_feas, s->d_goal, s->d_step_num, \
-                       s->d_ep_ret, s->d_goal_count, d_act, d_obs, d_reward, d_done, s->d_ep_sum, s->d_ep_cnt, s->d_infeas_n, \
-                       n, s->seed, uint64_t(s->env0))
-        const bool sp = s->tree_host.dev.single_pass != 0;
-        if (s->integrator == RB_EULER) { if (sp) RB_TREE_ENV_LAUNCH(0, true); else RB_TREE_ENV_LAUNCH(0, false); }
-        else                           { if (sp) RB_TREE_ENV_LAUNCH(1, true); else RB_TREE_ENV_LAUNCH(1, false); }
-#undef RB_TREE_ENV_LAUNCH
-        RB_HIP(hipGetLastError());
-        return RB_OK;
-    }
-    // ball joints: SoA planes keep their stride n; everything else is indexed by env and shifted
-    const int nt = s->n_t;
-    float *rq = s->d_q + i0, *rqd = s->d_qd + i0, *rgoal = s->d_goal + i0, *rret = s->d_ep_ret + i0, *robs = d_obs + i0 * 9, *rrew = d_reward + i0;
-    uint32_t *rfeas = s->d_feas + i0, *rsn = s->d_step_num + i0, *rgc = s->d_goal_count + i0, *rdone = d_done + i0, *rcnt = s->d_ep_cnt + i0, *rinf = s->d_infeas_n + i0;
-    const float *ract = d_act + i0 * nt;
-    double *rsum = s->d_ep_sum + i0;
-    const uint64_t e0 = uint64_t(s->env0) + uint64_t(i0);
-#define RB_ENV_ARGS s->env, s->box, rq, rqd, rfeas, rgoal, rsn, rret, rgc, ract, robs, rrew, rdone, rsum, rcnt, rinf, n, cnt, s->seed, e0
-#define RB_ENV_LAUNCH(INTEG, B, U)                                                                       \
-    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, U>), dim3(blocks_for(cnt, B)), dim3(B), 0, stream, s->c8, RB_ENV_ARGS)
-#define RB_ENV_LAUNCH_NT(INTEG, B)                                                                       \
-    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, 0, ConstX>), dim3(blocks_for(cnt, B)), dim3(B), 0, stream, s->cx, RB_ENV_ARGS)
-#define RB_ENV_LAUNCH_BK(INTEG, B, U)                                                                    \
-    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, U, Const8, true>), dim3(blocks_for(cnt, B)), dim3(B), 0, stream, s->c8, RB_ENV_ARGS)
-    if (env_uses_octets(s)) {
-        // eight lanes per env (small batches, or rb_select_kernel(2))
-        const unsigned g = blocks_for(cnt * NT8, 64);
-        if (s->integrator == RB_EULER) hipLaunchKernelGGL((msj_env_step_tendon_per_lane<0>), dim3(g), dim3(64), 0, stream, s->c8, s->d_ten, RB_ENV_ARGS);
-        else hipLaunchKernelGGL((msj_env_step_tendon_per_lane<1>), dim3(g), dim3(64), 0, stream, s->c8, s->d_ten, RB_ENV_ARGS);
-        RB_HIP(hipGetLastError());
-        return RB_OK;
-    }
-    if (env_uses_pairs(s)) {
-        // two lanes per env (robots with a mirror plane: the library's choice up to mid-size batches, or rb_select_kernel)
-        PairMap pm;
-        for (int k = 0; k < 4; ++k) { pm.a[k] = 4 * s->pair_half[k]; pm.d[k] = 4 * (s->pair_image[k] - s->pair_half[k]); }
-#define RB_PAIR_ENV_LAUNCH(INTEG, B, M, BKF)                                                                          \
-    hipLaunchKernelGGL((msj_env_step_mirror_pairs<INTEG, B, M, BKF>), dim3(blocks_for(2 * cnt, B)), dim3(B), 0, stream, s->c8p, pm, RB_ENV_ARGS)
-#define RB_PAIR_ENV_LAUNCH_B(INTEG, M, BKF)                                                                           \
-    do { if (n <= RB_PAIR_SMALL_BATCH) RB_PAIR_ENV_LAUNCH(INTEG, 64, M, BKF); else RB_PAIR_ENV_LAUNCH(INTEG, 256, M, BKF); } while (0)
-#define RB_PAIR_ENV_LAUNCH_M(INTEG, BKF)                                                                              \
-    do { if (s->pair_mirror == 0) RB_PAIR_ENV_LAUNCH_B(INTEG, 0, BKF); else RB_PAIR_ENV_LAUNCH_B(INTEG, 1, BKF); } while (0)
-        if (s->pair_baked) { if (s->integrator == RB_EULER) RB_PAIR_ENV_LAUNCH_M(0, true); else RB_PAIR_ENV_LAUNCH_M(1, true); }
-        else               { if (s->integrator == RB_EULER) RB_PAIR_ENV_LAUNCH_M(0, false); else RB_PAIR_ENV_LAUNCH_M(1, false); }
-#undef RB_PAIR_ENV_LAUNCH_M
-#undef RB_PAIR_ENV_LAUNCH_B
-#undef RB_PAIR_ENV_LAUNCH
-        RB_HIP(hipGetLastError());
-        return RB_OK;
-    }
-    maybe_jit(s);
-    if (s->jit_state == 1) {
-        // msj_env_step_kernel<INTEG, 256, 8 / RS, Const8, true> of this robot's own module; same parameter list
-        Const8 c8 = s->c8;
-        EnvParams ep = s->env;
-        GoalBox box = s->box;
-        long nn = n, cc = cnt;
-        uint64_t seed = s->seed, env0 = e0;
-        void *args[] = {&c8, &ep, &box, &rq, &rqd, &rfeas, &rgoal, &rsn, &rret, &rgc,
-                        &ract, &robs, &rrew, &rdone, &rsum, &rcnt, &rinf, &nn, &cc, &seed, &env0};
-        RB_HIP(hipModuleLaunchKernel(s->jit.env[s->integrator == RB_EULER ? 0 : 1], blocks_for(cnt, 256), 1, 1, 256, 1, 1, 0,
-                                     stream, args, nullptr));
-    } else
-    if (s->baked) {
-        if (n <= RB_SMALL_BATCH) { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_BK(0, 64, 8); else RB_ENV_LAUNCH_BK(1, 64, 8); }
-        else                     { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_BK(0, RB_BIG_BLOCK_EULER, RB_BAKED_UNROLL_EULER); else RB_ENV_LAUNCH_BK(1, RB_BIG_BLOCK_RK4, RB_BAKED_UNROLL_RK4); }
-    } else
-    if (s->ntx) {
-        if (n <= RB_SMALL_BATCH) { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_NT(0, 64); else RB_ENV_LAUNCH_NT(1, 64); }
-        else                     { if (s->integrator == RB_EULER) RB_ENV_LAUNCH_NT(0, 256); else RB_ENV_LAUNCH_NT(1, 256); }
-    } else
-    if (n <= RB_SMALL_BATCH) { if (s->integrator == RB_EULER) RB_ENV_LAUNCH(0, 64, 8); else RB_ENV_LAUNCH(1, 64, 8); }
-    else                     { if (s->integrator == RB_EULER) RB_ENV_LAUNCH(0, RB_BIG_BLOCK_EULER, RB_BIG_UNROLL_EULER); else RB_ENV_LAUNCH(1, RB_BIG_BLOCK_RK4, RB_BIG_UNROLL_RK4); }
-#undef RB_ENV_LAUNCH_NT
-#undef RB_ENV_LAUNCH_BK
-#undef RB_ENV_LAUNCH
-#undef RB_ENV_ARGS
-    RB_HIP(hipGetLastError());
-    return RB_OK;
+    Launch L;
+    L.i0 = i0; L.cnt = cnt; L.stream = stream; L.act = d_act; L.obs = d_obs; L.reward = d_reward; L.done = d_done;
+    return dispatch(s, ENTRY_ENV, L);
 }
 
 int rb_env_step_dev(rb_sim *s, const float *d_act, float *d_obs, float *d_reward, uint32_t *d_done) {
@@ -1921,18 +1558,17 @@ int rb_step_range_dev(rb_sim *s, int64_t first_env, int64_t n_envs, void *hip_st
     hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
     CallStreamScope scope(s, st);          // a first call captured on the caller's stream defers the run-time builds (capturing())
     maybe_jit(s);
-    const bool whole = first_env == 0 && n_envs == s->n;
-    if (!whole && !range_capable(s)) return fail(RB_EUNSUPPORTED, "this kernel form steps whole batches only (rb_range_capable)");
-    int rc = whole && st == s->stream ? launch_step(s, d_act, act_scale) : launch_step(s, d_act, act_scale, long(first_env), long(first_env + n_envs), st);
+    // (a whole batch is taken by every form, on the caller's stream too; sub-ranges by the forms of rb_range_capable - dispatch() refuses others)
+    int rc = launch_step(s, d_act, act_scale, long(first_env), long(first_env + n_envs), st);
     if (rc == RB_OK) { s->env_steps += double(n_envs); rc = note_caller_stream(s, st); }
     return rc;
 }
 int rb_range_capable(rb_sim *s) {
     if (check(s)) return -1;
-    // the fused env layer of the ball-joint class is always an env-per-lane kernel (whatever form the plain step takes);
-    // joint trees: the one-wave-per-64-envs form, not the split form and not the octets
-    const bool env = s->tree ? (!tree_wants_split2(s) && !tree_wants_split(s) && tree_use_lane(s, 1)) : true;
-    return (range_capable(s) ? 1 : 0) | (env ? 2 : 0);
+    // builds what a launch would build (outside captures), then asks the table: bit 0 = the step's row takes sub-ranges, bit 1 = the env step's
+    maybe_jit(s);
+    const Row *step = row_for(s, ENTRY_STEP, true), *env = row_for(s, ENTRY_ENV, s->env_ready);
+    return (step && step->ranges ? 1 : 0) | (env && env->ranges ? 2 : 0);
 }
 
 static int stats_launch(rb_sim *s, double *d_out2) {
@@ -1975,6 +1611,39 @@ int rb_env_stats(rb_sim *s, double *stats8, int reset) {
     RB_HIP(hipMemcpyAsync(stats8, s->d_stats, sizeof(double) * 8, hipMemcpyDeviceToHost, s->stream));
     RB_HIP(hipStreamSynchronize(s->stream));
     return reset ? stats_reset(s) : RB_OK;
+}
+
+static rb_dispatch_row g_rows[N_ROWS];
+static rb_dispatch_row public_row(const Row &r) {
+    return rb_dispatch_row{r.key.cls, r.key.entry, r.key.form, r.key.integ, r.key.block, r.key.src, r.key.variant, r.ranges ? 1 : 0};
+}
+int rb_dispatch_rows(const rb_dispatch_row **rows) {
+    static const bool filled = [] { for (int i = 0; i < N_ROWS; ++i) g_rows[i] = public_row(TABLE[i]); return true; }();
+    (void)filled;
+    if (rows) *rows = g_rows;
+    return N_ROWS;
+}
+int rb_auto_rules(const rb_auto_rule **rules) {
+    if (rules) *rules = AUTO_RULES;
+    return N_AUTO_RULES;
+}
+int rb_get_launch_thresholds(rb_launch_thresholds *out) {
+    if (!out) return fail(RB_EINVAL, "null argument");
+    *out = rb_launch_thresholds{RB_SMALL_BATCH, RB_PAIR_SMALL_BATCH, RB_CHAIN_BATCH_RK4, RB_CHAIN_BATCH_EULER, RB_CHAIN_BATCH_TREE_RK4,
+                                RB_CHAIN_BATCH_TREE_EULER, RB_EAGER_HEAD_BATCH_RK4, RB_TREE_JIT_BATCH};
+    return RB_OK;
+}
+int rb_dispatch_current(rb_sim *s, int entry, rb_dispatch_row *out) {
+    if (check(s) || !out) return fail(RB_EINVAL, "null argument");
+    if (entry < ENTRY_STEP || entry > ENTRY_FUSED) return fail(RB_EINVAL, "unknown entry kind");
+    if (entry == ENTRY_FUSED && (s->tree || s->ntx)) return fail(RB_EUNSUPPORTED, "fused rollout is built for 8-tendon ball-joint robots");
+    RB_HIP(hipSetDevice(s->device));
+    if (entry != ENTRY_ENV || s->env_ready) maybe_jit(s);
+    std::string why;
+    const Row *r = row_for(s, entry, /*build=*/entry != ENTRY_ENV || s->env_ready, &why);
+    if (!r) return fail(RB_EUNSUPPORTED, why);
+    *out = public_row(*r);
+    return RB_OK;
 }
 
 int rb_malloc(rb_sim *s, int64_t bytes, void **d_ptr) {

@@ -63,6 +63,13 @@ class HipBatchSimulation:
         nat.check(self._lib.rb_info(self._h, ctypes.byref(info)))
         return {name: getattr(info, name) for name, _ in nat.SimInfo._fields_}
 
+    def dispatch(self, entry="step") -> dict:
+        """The row of the library's dispatch table the next launch of `entry` ('step', 'env_step', 'fused_rollout') takes on this
+        handle: ``{'id': 'ball8/step/env_per_lane/rk4/b256/table/v0', 'kernel': 1, 'block': 256, ...}``."""
+        row = nat.DispatchRow()
+        nat.check(self._lib.rb_dispatch_current(self._h, nat.ENTRIES[entry] if isinstance(entry, str) else int(entry), ctypes.byref(row)))
+        return dict(row.as_dict(), id=row.row_id())
+
     def specialization(self) -> str:
         """'kernarg', 'table' (MsjRobot's ahead-of-time instances) or 'jit' (hiprtc instances on this robot's constants)."""
         return {0: "kernarg", 1: "table", 2: "jit"}[self._lib.rb_specialization(self._h)]

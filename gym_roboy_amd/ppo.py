@@ -294,13 +294,17 @@ def adam_state_torch_to_flat(sd, policy, layout, m, v):
         raise ValueError("optimiser state of another module: %d parameters, this policy has %d" % (len(order), len(slices)))
     # every parameter or none: moments of some parameters under ONE step count would resume the others with zero moments and a
     # bias correction that assumes they have been stepping all along
-    missing = [idx for idx in order if state.get(idx) is None]
+    # (a parameter with requires_grad = False is never stepped by torch.optim.Adam and has no state: zero moments are exact for it)
+    frozen = {idx for idx, p in zip(order, policy.parameters()) if not p.requires_grad}
+    missing = [idx for idx in order if state.get(idx) is None and idx not in frozen]
     if missing:
         raise ValueError("partial optimiser state: %d of %d parameters carry no moments (a torch.optim.Adam that stepped only some of "
                          "its parameters cannot be converted to the flat form)" % (len(missing), len(order)))
     t = 0
     for idx, (off, shape) in zip(order, slices):
-        st = state[idx]
+        st = state.get(idx)
+        if st is None:                                       # frozen: leave its (zero) moments alone
+            continue
         if tuple(st["exp_avg"].shape) != tuple(shape):
             raise ValueError("optimiser state of another policy layout: %r against %r" % (tuple(st["exp_avg"].shape), tuple(shape)))
         n = int(st["exp_avg"].numel())

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define RB_ABI_VERSION 4
+#define RB_ABI_VERSION 5
 
 enum rb_status {
     RB_OK = 0,
@@ -274,6 +274,59 @@ int rb_env_step_range_dev(rb_sim *sim, int64_t first_env, int64_t n_envs, void *
  * torch tensor that is then all-reduced over RCCL); the host form synchronises. */
 int rb_env_stats(rb_sim *sim, double *stats8, int reset);
 int rb_env_stats_dev(rb_sim *sim, double *d_stats8, int reset);
+
+/* ---- which kernel instance a call launches: the library's dispatch table, readable (ABI 5) ----
+ * Every launch of the three entry kinds goes through ONE table of kernel instances keyed by (robot class, entry kind, kernel form,
+ * integrator, workgroup size, constants source, variant); RB_KERNEL_AUTO's thresholds are a list of rules (first match wins).  Both
+ * are static data of the library: readable without a GPU, so tests enumerate them instead of restating them. */
+enum rb_robot_class { RB_CLASS_BALL8 = 0,   /* one body on an x-y-z ball joint, 8 tendons (MsjRobot's class)         */
+                      RB_CLASS_BALLX = 1,   /* the same with 1..16 tendons (run-time count)                           */
+                      RB_CLASS_TREE = 2 };  /* any other joint tree                                                   */
+enum rb_entry_kind { RB_ENTRY_STEP = 0,           /* rb_step, rb_step_dev, rb_step_range_dev, rb_rollout_dev         */
+                     RB_ENTRY_ENV_STEP = 1,       /* rb_env_step_dev, rb_env_step_range_dev                          */
+                     RB_ENTRY_FUSED_ROLLOUT = 2 };/* rb_rollout_fused_dev                                            */
+typedef struct rb_dispatch_row {
+    int32_t robot_class;   /* rb_robot_class                                                                          */
+    int32_t entry;         /* rb_entry_kind                                                                           */
+    int32_t kernel;        /* an rb_kernel value, never RB_KERNEL_AUTO                                                      */
+    int32_t integrator;    /* rb_integrator                                                                           */
+    int32_t block;         /* threads per workgroup; 0 = decided by the robot (octet waves, split parts)              */
+    int32_t constants;     /* RB_SPEC_NONE (kernarg) / RB_SPEC_TABLE (ahead-of-time instances) / RB_SPEC_JIT (hiprtc) */
+    int32_t variant;       /* two lanes per env: mirror plane (0 x-z, 1 y-z); octet joint-tree kernels: single-pass tables; else 0 */
+    int32_t ranges;        /* 1: takes sub-ranges of the batch (rb_*_range_dev, rollout chains); 0: whole batches only */
+} rb_dispatch_row;
+/* what a handle must offer for an AUTO rule to apply (rb_auto_rule.needs, a bit set) */
+enum { RB_NEED_MIRROR = 1,        /* ball joints: the robot has a mirror plane (two-lanes-per-env form possible)       */
+       RB_NEED_NO_MIRROR = 2,     /* ball joints: it has none                                                          */
+       RB_NEED_SPLIT_TABLE = 4,   /* joint trees: ahead-of-time instances of the five-wave split form (the committed upper body) */
+       RB_NEED_SPLIT2_TABLE = 8,  /* ... of the lean two-part split form                                               */
+       RB_NEED_LANE = 16 };       /* joint trees: one-wave-per-64-envs kernels at hand (ahead of time) or worth building (hiprtc: batch
+                                     >= 16 384 envs, generated code within the register file; ROBOY_SIM_JIT) */
+typedef struct rb_auto_rule {
+    int32_t robot_class;          /* rb_robot_class                                                                    */
+    int32_t entry;                /* rb_entry_kind, -1 = any                                                           */
+    int32_t integrator;           /* rb_integrator, -1 = any                                                           */
+    int32_t needs;                /* RB_NEED_* bits that must all be set                                               */
+    int64_t min_envs_exclusive;   /* applies to handles with min_envs_exclusive < n_envs <= max_envs                   */
+    int64_t max_envs;
+    int32_t kernel;               /* the rb_kernel AUTO picks                                                          */
+    int32_t _pad;
+} rb_auto_rule;
+/* batch-size thresholds of the launch configuration that are not kernel forms */
+typedef struct rb_launch_thresholds {
+    int64_t small_batch;          /* ball joints, one env per lane: 64-thread workgroups up to here, 256 above (and hiprtc / baked large-batch instances) */
+    int64_t pair_small_batch;     /* two lanes per env: the same switch                                                */
+    int64_t chain_batch_rk4, chain_batch_euler;             /* rb_rollout_dev: two chains from here on (ball joints)  */
+    int64_t chain_batch_tree_rk4, chain_batch_tree_euler;   /* ... joint trees in the one-wave form                   */
+    int64_t eager_head_batch_rk4; /* rb_rollout_dev: one ring turn of plain launches in front of the graphs (ball joints, RK4) */
+    int64_t tree_jit_batch;       /* joint trees without ahead-of-time instances: AUTO builds the one-wave kernels from here on */
+} rb_launch_thresholds;
+int rb_dispatch_rows(const rb_dispatch_row **rows);     /* returns the row count; *rows = the library's static table */
+int rb_auto_rules(const rb_auto_rule **rules);          /* returns the rule count; first match wins               */
+int rb_get_launch_thresholds(rb_launch_thresholds *out);
+/* The row the NEXT launch of `entry` over the whole batch takes on this handle (RB_EUNSUPPORTED + message if none).  Builds the
+ * run-time kernels that launch would build (hiprtc; never inside a stream capture - then the row of what is at hand). */
+int rb_dispatch_current(rb_sim *sim, int entry, rb_dispatch_row *out);
 
 /* device memory helpers so a ctypes caller needs no HIP binding of its own */
 int rb_malloc(rb_sim *sim, int64_t bytes, void **d_ptr);

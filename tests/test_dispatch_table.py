@@ -1,0 +1,295 @@
+"""The library's dispatch table (csrc/roboy_dispatch.hpp, exported through rb_dispatch_rows / rb_auto_rules / rb_dispatch_current).
+
+CPU: the table and RB_KERNEL_AUTO's rules are consistent static data (unique keys, every rule lands on rows, this file knows how to
+reach every row).  GPU: EVERY row is reached by name - a handle is built so that the next launch of the row's entry kind takes exactly
+that row (asserted through rb_dispatch_current) - and the launch is checked against the fp64 oracle (steps), against the reference's
+reward arithmetic on top of the oracle-checked state (env steps) or bit for bit against single steps (fused rollouts).  A kernel
+instance that no test reaches cannot exist: the parametrisation IS the table.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import random_states
+from gym_roboy_amd import _native as nat
+
+ROWS = nat.dispatch_rows()
+IDS = [r.row_id() for r in ROWS]
+BALL8, BALLX, TREE = 0, 1, 2
+STEP, ENV, FUSED = 0, 1, 2
+SMALL = 4097          # a ragged batch on the 64-thread side of every block-size switch
+LARGE = 66819         # ... and one on the 256-thread side (rb_launch_thresholds: small_batch = pair_small_batch = 65 536)
+
+
+def _kernarg_msj():
+    """MsjRobot with every muscle 2 % stronger: the same mirror plane (x-z), constants that are not the ahead-of-time table's."""
+    from gym_roboy_amd.envs.robots import MsjRobot, RobotDescription, msj_platform_spec
+    spec = msj_platform_spec()
+    for t in spec["tendons"]:
+        t["f_max"] = 1.02 * t["f_max"]
+    desc = RobotDescription(spec)
+
+    class StrongerMsj(MsjRobot):
+        @classmethod
+        def get_description(cls):
+            return desc
+    return StrongerMsj()
+
+
+def _turned_msj():
+    """MsjRobot turned by 90 degrees about z: mirror plane y-z (variant 1), kernarg constants."""
+    from gym_roboy_amd.envs.robots import MsjRobot
+    from test_mirror_pairs import _rotated_msj
+    desc = _rotated_msj()
+
+    class Turned(MsjRobot):
+        @classmethod
+        def get_description(cls):
+            return desc
+    return Turned()
+
+
+def recipe(row):
+    """How to make a handle whose next launch of row.entry takes this row: (robot name, n_envs, kernel to select, environment).
+    None = this file does not know (the CPU test below fails then)."""
+    cls, form, src, block, variant = row.robot_class, row.kernel, row.constants, row.block, row.variant
+    env = {}
+    if cls == BALL8:
+        n = SMALL if block == 64 else LARGE
+        if src == 1:
+            robot = "msj"
+            if variant != 0:
+                return None
+        else:
+            robot = "msj-turned" if variant == 1 else "msj-kernarg"
+            if form == 1 and block == 256:
+                env["ROBOY_SIM_JIT"] = "1" if src == 2 else "0"       # large batches of another robot: its own hiprtc instances, or kernarg
+            elif src == 2:
+                return None
+        return robot, n, form, env
+    if cls == BALLX:
+        return "ball-5-tendons", (777 if block == 64 else LARGE), 0, env
+    if cls == TREE:
+        if form == 3:                                                  # octets: variant = single-pass tables
+            return ("tree-single-pass" if variant == 1 else "tree-multi-pass"), 70, 3, env
+        return ("upper-body" if src == 1 else "tree-random-5"), 130, form, env
+    return None
+
+
+_ROBOTS = {}
+
+
+def _robot(name):
+    if name not in _ROBOTS:
+        from gym_roboy_amd.envs.robots import MsjRobot, UpperBodyRobot
+        from random_robots import random_ball_joint_robot, random_tree_robot
+        if name == "msj":
+            _ROBOTS[name] = MsjRobot()
+        elif name == "msj-kernarg":
+            _ROBOTS[name] = _kernarg_msj()
+        elif name == "msj-turned":
+            _ROBOTS[name] = _turned_msj()
+        elif name == "ball-5-tendons":
+            _ROBOTS[name] = random_ball_joint_robot(3, n_t=5)[0]
+        elif name == "upper-body":
+            _ROBOTS[name] = UpperBodyRobot()
+        elif name == "tree-random-5":
+            _ROBOTS[name] = random_tree_robot(5)[0]
+        elif name in ("tree-single-pass", "tree-multi-pass"):
+            # whichever random trees have / lack single-pass tables (a level of the tree fits one pass of the wave): ask the library
+            from gym_roboy_amd.envs.simulations import HipBatchSimulation
+            want = 1 if name == "tree-single-pass" else 0
+            for seed in range(40):
+                robot = random_tree_robot(seed)[0]
+                sim = HipBatchSimulation(robot, 8)
+                sim.select_kernel(3)
+                got = sim.dispatch("step")["variant"]
+                sim.close()
+                if got == want:
+                    _ROBOTS[name] = robot
+                    break
+            else:
+                raise LookupError("no random tree with variant %d among 40 seeds" % want)
+    return _ROBOTS[name]
+
+
+# ------------------------------------------------------------------------------------------------------------------ CPU
+def test_table_keys_are_unique_and_well_formed():
+    assert len(ROWS) == len(set(IDS)) >= 90
+    for r in ROWS:
+        assert r.robot_class in (BALL8, BALLX, TREE) and r.entry in (STEP, ENV, FUSED) and r.integrator in (0, 1)
+        assert r.kernel in nat.KERNEL_NAMES and r.constants in (0, 1, 2) and r.block in (0, 64, 256) and r.ranges in (0, 1)
+    # every (class, entry, form, block, constants, variant) exists for both integrators
+    half = {(r.robot_class, r.entry, r.kernel, r.block, r.constants, r.variant, r.integrator) for r in ROWS}
+    assert all((c, e, k, b, s, v, 1 - i) in half for (c, e, k, b, s, v, i) in half)
+    # the headline kernel's row
+    assert "ball8/step/env_per_lane/rk4/b256/table/v0" in IDS
+
+
+def test_every_auto_rule_lands_on_rows_and_every_class_has_a_catch_all():
+    rules = nat.auto_rules()
+    forms = {(r.robot_class, r.entry, r.kernel, r.integrator) for r in ROWS}
+    for rule in rules:
+        for entry in ([rule["entry"]] if rule["entry"] >= 0 else [STEP, ENV]):
+            for integ in ([rule["integrator"]] if rule["integrator"] >= 0 else [0, 1]):
+                assert (rule["robot_class"], entry, rule["kernel"], integ) in forms, rule
+        assert rule["min_envs_exclusive"] < rule["max_envs"]
+    for cls, entries in ((BALL8, (STEP, ENV, FUSED)), (BALLX, (STEP, ENV)), (TREE, (STEP, ENV))):
+        for entry in entries:
+            for integ in (0, 1):
+                for needs in (0, 1, 2, 4 | 8 | 16, 16):
+                    for n in (1, 4096, 4097, 8192, 8193, 12288, 16384, 16385, 24576, 32768, 32769, 65536, 65537, 1 << 21, 1 << 30):
+                        assert nat.auto_kernel(cls, entry, integ, needs, n) in nat.KERNEL_NAMES      # never "no rule applies"
+
+
+def test_auto_rules_say_what_the_header_documents():
+    """include/roboy_sim.h (rb_select_kernel) states the thresholds in prose: the exported rules are those numbers."""
+    M, NM = nat.RB_NEED_MIRROR, nat.RB_NEED_NO_MIRROR
+    ak = nat.auto_kernel
+    assert [ak(BALL8, STEP, 0, M, n) for n in (4096, 4097, 16384, 16385)] == [2, 5, 5, 1]
+    assert [ak(BALL8, STEP, 1, M, n) for n in (12288, 12289, 32768, 32769)] == [2, 5, 5, 1]
+    assert [ak(BALL8, STEP, 0, NM, n) for n in (8192, 8193)] == [2, 1] and [ak(BALL8, STEP, 1, NM, n) for n in (16384, 16385)] == [2, 1]
+    assert [ak(BALL8, ENV, 0, M, n) for n in (8192, 8193, 24576, 24577)] == [2, 5, 5, 1]
+    assert [ak(BALL8, ENV, 1, M, n) for n in (8192, 8193, 32768, 32769)] == [2, 5, 5, 1]
+    assert [ak(BALL8, ENV, 1, NM, n) for n in (8192, 8193)] == [2, 1]
+    everything = 4 | 8 | 16
+    assert [ak(TREE, STEP, 0, everything, n) for n in (16384, 16385, 32768, 32769)] == [4, 6, 6, 1]
+    assert ak(TREE, ENV, 1, 16, 100) == 1 and ak(TREE, STEP, 0, 0, 100) == 3
+    t = nat.launch_thresholds()
+    assert t["small_batch"] == 65536 and t["chain_batch_rk4"] == 98304 and t["chain_batch_euler"] == 262144 and t["eager_head_batch_rk4"] == 196608
+
+
+def test_this_file_knows_how_to_reach_every_row():
+    unknown = [r.row_id() for r in ROWS if recipe(r) is None]
+    assert not unknown, "rows without a recipe (unreachable instances, or a new form this test has not learnt): %s" % unknown
+
+
+def test_the_golden_env_tests_name_every_form_the_env_step_of_a_mirror_robot_takes():
+    """tests/test_env_golden_gpu.py runs the reference's vectors through the fused env kernels BY FORM NAME: its list must be what
+    the table holds for an 8-tendon ball-joint robot's env step (a new form without the reference's vectors fails here)."""
+    import test_env_golden_gpu as g
+    assert set(g.ENV_FORMS) == {r.kernel for r in ROWS if r.robot_class == BALL8 and r.entry == ENV}
+
+
+# ------------------------------------------------------------------------------------------------------------------ GPU
+def _tolerance(desc, q, qd, sp):
+    if desc.n_q == 3:
+        return 2e-5
+    from test_random_robots_gpu import tolerance
+    return tolerance(desc, q, qd, sp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("row_id", IDS)
+def test_every_row_is_reached_by_name_and_agrees_with_the_oracle(row_id, monkeypatch):
+    from gym_roboy_amd.envs import reward as rw
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    from oracle.c_oracle import COracle
+    row = ROWS[IDS.index(row_id)]
+    robot_name, n, kernel, env = recipe(row)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    robot = _robot(robot_name)
+    desc = robot.get_description()
+    integrator = "euler" if row.integrator == 0 else "rk4"
+    integ = row.integrator
+    entry = nat.ENTRY_NAMES[row.entry]
+    q, qd, sp = random_states(desc, n, 17 + IDS.index(row_id))
+    oracle = COracle(desc, "f64")
+    sample = slice(None) if n <= 8192 else np.arange(0, n, 97)          # the oracle on every 97th env of a large batch
+
+    def check_state(q1, qd1, f1, sp_used):
+        qo, qdo, fo = oracle.step(q[sample], qd[sample], sp_used[sample], integrator=integ)
+        tol = _tolerance(desc, q[sample], qd[sample], sp_used[sample])
+        assert np.all(np.abs(q1[sample] - qo) < tol), np.abs(q1[sample] - qo).max()
+        assert np.all(np.abs(qd1[sample] - qdo) < tol), np.abs(qd1[sample] - qdo).max()
+        near = np.minimum(np.abs(qo - desc.q_lo), np.abs(qo - desc.q_hi)).min(axis=1) < 1e-5
+        assert not np.any((f1[sample] != fo) & ~near)
+
+    if entry == "step":
+        sim = HipBatchSimulation(robot, n, integrator=integrator)
+        sim.select_kernel(kernel)
+        assert sim.dispatch("step")["id"] == row_id
+        assert sim.dispatch("step")["ranges"] == (1 if sim.range_capable() & 1 else 0)
+        sim.set_state(q, qd)
+        q1, qd1, f1 = sim.forward_step_command(sp)
+        assert sim.dispatch("step")["id"] == row_id and sim.info()["kernel"] == row.kernel
+        check_state(q1, qd1, f1, sp)
+        sim.close()
+    elif entry == "env_step":
+        from gym_roboy_amd.envs.vec_env import RoboyVecEnv
+        vec = RoboyVecEnv(robot, n, seed=3, integrator=integrator, auto_reset=False, joint_vel_penalty=True)
+        vec.sim.select_kernel(kernel)
+        assert vec.sim.dispatch("env_step")["id"] == row_id
+        obs0 = vec.reset()
+        vec.sim.set_state(q, qd)
+        a = (sp / np.float32(0.3)).astype(np.float32)                  # actions in [-1, 1]; the kernel rescales them to set-points
+        one = np.ones(desc.n_t, np.float32)
+        box = robot.get_action_space()
+        sp_used = rw.rescale_between_boxes(a, -one, one, box.low, box.high).astype(np.float32)
+        obs, rew, done, _ = vec.step(a)
+        assert vec.sim.dispatch("env_step")["id"] == row_id
+        nq = desc.n_q
+        q1, qd1 = obs[:, :nq], obs[:, nq:2 * nq]
+        _, _, f1 = vec.sim.read_state()
+        check_state(q1, qd1, f1, sp_used)
+        assert np.array_equal(obs[:, 2 * nq:], obs0[:, 2 * nq:])       # the goal in effect during the step (roboy_env.py:62)
+        # reward / done: the reference's arithmetic (gym_roboy_amd/envs/reward.py, pinned by tests/golden) on the kernel's own state
+        angles, vels = robot.get_joint_angles_space(), robot.get_joint_vels_space()
+        max_da, max_dv = rw.l2_distance(angles.low, angles.high), rw.l2_distance(vels.low, vels.high)
+        q64, qd64, g64 = q1.astype(np.float64), qd1.astype(np.float64), obs[:, 2 * nq:].astype(np.float64)
+        want = rw.compute_reward(q64, qd64, f1, g64, np.zeros_like(qd64), (angles.low, angles.high), (vels.low, vels.high), max_da, max_dv, True, True)
+        np.testing.assert_allclose(rew, want, rtol=3e-5, atol=3e-4)
+        da, dv = rw.l2_distance(q64, g64), rw.l2_distance(qd64, np.zeros_like(qd64))
+        clear = np.minimum(np.abs(da - max_da / 200), np.abs(dv - max_dv / 5)) > 1e-5
+        assert np.array_equal(done[clear], ((da < max_da / 200) & (dv < max_dv / 5))[clear])
+        vec.close()
+    else:
+        import torch
+        sims = [HipBatchSimulation(robot, n, integrator=integrator) for _ in range(2)]
+        for s in sims:
+            s.select_kernel(1)
+            s.set_state(q, qd)
+        assert sims[0].dispatch("fused_rollout")["id"] == row_id
+        ring = (torch.rand((3, n, desc.n_t), device="cuda") * 2 - 1).contiguous()
+        sims[0].rollout_fused_dev(ring.data_ptr(), 3, 5, 0.3)
+        for t in range(5):
+            sims[1].step_dev(ring[t % 3].data_ptr(), 0.3)
+        a, b = sims[0].read_state(), sims[1].read_state()
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))         # the step row of the same key is oracle-checked above
+        assert sims[1].dispatch("step")["id"] == row_id.replace("fused_rollout", "step")
+        for s in sims:
+            s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot_name,kernel", [("upper-body", 6), ("upper-body", 4), ("upper-body", 3), ("msj", 2), ("ball-5-tendons", 0)])
+def test_a_whole_batch_on_a_callers_stream_is_taken_by_the_whole_batch_forms_and_a_sub_range_is_refused(robot_name, kernel):
+    """ADVICE (round 5): rb_step_range_dev(0, n, caller_stream) is a WHOLE batch - the forms that step whole batches only (split,
+    lean split, octets, eight lanes per env, run-time tendon count) take it, on the caller's stream, bit-identical to rb_step_dev; a
+    true sub-range is refused with RB_EUNSUPPORTED ('... whole batches only'), as include/roboy_sim.h promises."""
+    import torch
+    from gym_roboy_amd.envs.simulations import HipBatchSimulation
+    robot = _robot(robot_name)
+    desc = robot.get_description()
+    n = 1024
+    q, qd, sp = random_states(desc, n, 5)
+    act = torch.tensor(sp, device="cuda")
+    sims = [HipBatchSimulation(robot, n, integrator="euler") for _ in range(2)]
+    for s in sims:
+        s.select_kernel(kernel)
+        s.set_state(q, qd)
+    row = sims[0].dispatch("step")
+    assert row["ranges"] == 0 and not sims[0].range_capable()
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    sims[0].step_range_dev(0, n, st.cuda_stream, act.data_ptr(), 1.0)
+    st.synchronize()
+    sims[1].step_dev(act.data_ptr(), 1.0)
+    a, b = sims[0].read_state(), sims[1].read_state()
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    with pytest.raises(nat.NativeError, match="whole batches only"):
+        sims[0].step_range_dev(0, 512, st.cuda_stream, act.data_ptr(), 1.0)
+    for s in sims:
+        s.close()

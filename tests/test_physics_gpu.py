@@ -24,14 +24,13 @@ KERNELS = {"env_per_lane": 1, "tendon_per_lane": 2, "lane_pair": 5}
 
 
 def _auto_kernel(robot, n, integrator):
-    """RB_KERNEL_AUTO's table for ball-joint robots (csrc/roboy_sim.hip: auto_kernel): eight lanes per env for small batches;
-    robots with a mirror plane (MsjRobot) then two lanes per env; one env per lane above / otherwise."""
+    """What RB_KERNEL_AUTO picks for the plain step of a ball-joint robot - evaluated from the rules the library exports
+    (rb_auto_rules; csrc/roboy_dispatch.hpp: AUTO_RULES), not restated here."""
+    from gym_roboy_amd import _native as nat
     if robot.get_description().n_t != 8:
         return 1
-    euler = integrator == "euler"
-    if type(robot).__name__ in ("MsjRobot", "Turned"):
-        return 2 if n <= (4096 if euler else 12288) else 5 if n <= (16384 if euler else 32768) else 1
-    return 2 if n <= (8192 if euler else 16384) else 1
+    mirror = type(robot).__name__ in ("MsjRobot", "Turned")
+    return nat.auto_kernel(0, 0, 0 if integrator == "euler" else 1, nat.RB_NEED_MIRROR if mirror else nat.RB_NEED_NO_MIRROR, n)
 
 
 def _check_step(robot, oracle, n, integrator, nsub, seed, kernel=0):

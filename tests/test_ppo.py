@@ -124,6 +124,19 @@ def test_adam_state_moves_between_the_two_optimiser_forms():
     del partial["state"][0]
     with pytest.raises(ValueError, match="partial optimiser state"):
         adam_state_torch_to_flat(partial, policy, layout, m, v)
+    # ADVICE (round 5): ... but a FROZEN parameter (requires_grad = False: torch.optim.Adam never creates state for it) is not a
+    # partial state - a checkpoint of a policy with a fixed log_std converts, its moments stay zero
+    frozen = MlpPolicy(9, 8)
+    frozen.log_std.requires_grad_(False)
+    opt3 = torch.optim.Adam(frozen.parameters(), lr=1e-3)
+    opt3.zero_grad()
+    (frozen.dist(torch.randn(16, 9)).log_prob(torch.randn(16, 8)).sum() + frozen.value(torch.randn(16, 9)).sum()).backward()
+    opt3.step()
+    assert frozen.log_std not in opt3.state
+    m3, v3 = torch.zeros(n), torch.zeros(n)
+    assert adam_state_torch_to_flat(opt3.state_dict(), frozen, layout, m3, v3) == 1
+    off, shape = layout["log_std"]
+    assert not m3[off:off + 8].any() and not v3[off:off + 8].any() and m3.abs().sum() > 0
 
 
 def test_an_explicit_chain_request_that_cannot_be_honoured_warns():
