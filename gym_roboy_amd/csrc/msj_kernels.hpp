@@ -275,21 +275,68 @@ msj_rollout_fused(const Const8 c_arg, float *__restrict__ q, float *__restrict__
 // plus the reset the reference's SubprocVecEnv workers apply on done
 // (train_parallel.py:29) when auto_reset is set.  DESIGN.md §6.
 // obs/goal helper: draw goal number `draw` of env `gid`
-__device__ __forceinline__ void draw_goal3(const GoalBox &box, uint64_t seed, uint64_t gid, uint32_t draw, float g[3]) {
+__device__ __forceinline__ void draw_goal3(const float (&lo)[3], const float (&hi)[3], uint64_t seed, uint64_t gid, uint32_t draw, float g[3]) {
     const rb::Philox4 r = rb::philox_draw(seed, gid, draw, rb::STREAM_GOALS, 0u);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) g[j] = goal_value(box.lo[j], box.hi[j], r.v[j]);
+    for (int j = 0; j < 3; ++j) g[j] = goal_value(lo[j], hi[j], r.v[j]);
+}
+__device__ __forceinline__ void draw_goal3(const GoalBox &box, uint64_t seed, uint64_t gid, uint32_t draw, float g[3]) {
+    const float lo[3] = {box.lo[0], box.lo[1], box.lo[2]}, hi[3] = {box.hi[0], box.hi[1], box.hi[2]};
+    draw_goal3(lo, hi, seed, gid, draw, g);
+}
+
+// Everything the fused env kernels of the ball-joint class take besides the robot's constants, as ONE kernel argument (the LAST
+// one).  The step in front needs a handful of it (state, goal and action pointers, the rescale's two numbers, the counts); the
+// accounting behind the step needs the rest.  Kernels whose robot constants come through the kernarg (BK = false: 64 scalar registers
+// held across the step) read that rest LATE, through a pointer into the kernel-argument segment that the compiler cannot trace back
+// across the step (late_env_args): loaded up front like any other argument, the ~40 dwords of it were kept alive in scalar registers
+// beside the constants - 38-86 scalar spills into vector-register lanes and a private segment of 36-52 bytes per lane in every
+// kernarg instance (rounds 4-5; a dispatch with a private segment has the runtime set up scratch for it).  The baked / hiprtc
+// instances (BK = true) have the registers and read the argument directly.
+struct MsjEnvArgs {
+    EnvParams e;
+    float box_lo[3], box_hi[3];      // the goal box of the three joints (rbe::GoalBox holds 32: a kernarg of 256 bytes for six values)
+    float *q, *qd;
+    uint32_t *feas;
+    float *goal;
+    uint32_t *step_num;
+    float *ep_ret;
+    uint32_t *goal_count;
+    const float *act;
+    float *obs, *reward;
+    uint32_t *done;
+    double *ep_sum;
+    uint32_t *ep_cnt, *infeas_n;
+    long n, cnt;                     // n: the handle's envs = the stride of the state / goal / statistics planes; cnt: the envs of THIS launch
+    uint64_t seed, env0;             // env0: global id of the launch's first env (a sub-range arrives on shifted pointers)
+};
+// byte offset of the MsjEnvArgs argument in the kernel-argument segment: behind `lead` bytes of leading arguments, at its own alignment
+// (checked against the code objects' metadata by tests/test_code_objects.py)
+__host__ __device__ constexpr int msj_env_args_offset(int lead) { return (lead + int(alignof(MsjEnvArgs)) - 1) / int(alignof(MsjEnvArgs)) * int(alignof(MsjEnvArgs)); }
+typedef const __attribute__((address_space(4))) MsjEnvArgs *msj_env_kernarg_ptr;
+__device__ __forceinline__ msj_env_kernarg_ptr late_env_args(int offset) {
+    const __attribute__((address_space(4))) char *p = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));                      // (loads through p stay behind this point)
+    return (msj_env_kernarg_ptr)(p + offset);
 }
 
 // What RoboyEnv.step does around the simulator's answer for env i of this launch (qq, vv: the new state; gg: the env's goal; ok:
 // feasible): reward, done, episode accounting, goal redraw / reset on done, and every row back.  Shared by the env-per-lane
 // kernel and the two-lanes-per-env kernel (whose even lanes call it).
-__device__ __forceinline__ void env_account(const EnvParams &e, const GoalBox &box, long i, long n, float (&qq)[3], float (&vv)[3], float (&gg)[3], bool ok,
-                                            float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
-                                            float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
-                                            uint32_t *__restrict__ goal_count, float *__restrict__ obs, float *__restrict__ reward,
-                                            uint32_t *__restrict__ done, double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt,
-                                            uint32_t *__restrict__ infeas_n, uint64_t seed, uint64_t env0) {
+template <typename ARGS>      // const MsjEnvArgs * (the argument itself) or msj_env_kernarg_ptr (the late view of it)
+__device__ __forceinline__ void env_account(ARGS a, long i, float (&qq)[3], float (&vv)[3], float (&gg)[3], bool ok) {
+    EnvParams e;                  // (field by field: the source may live in the constant address space)
+    e.vel_penalty = a->e.vel_penalty; e.bonus = a->e.bonus; e.max_len = a->e.max_len; e.auto_reset = a->e.auto_reset;
+    e.penalty = a->e.penalty; e.bonus_val = a->e.bonus_val;
+    e.a_lo = a->e.a_lo; e.a_hi = a->e.a_hi; e.v_lo = a->e.v_lo; e.v_hi = a->e.v_hi;
+    e.act_hi = a->e.act_hi; e.slope = a->e.slope; e.tol_a2 = a->e.tol_a2; e.tol_v2 = a->e.tol_v2;
+    e.a_scale = a->e.a_scale; e.v_scale = a->e.v_scale;
+    const long n = a->n;
+    float *__restrict__ q = a->q, *__restrict__ qd = a->qd, *__restrict__ goal = a->goal, *__restrict__ ep_ret = a->ep_ret;
+    float *__restrict__ obs = a->obs, *__restrict__ reward = a->reward;
+    uint32_t *__restrict__ feas = a->feas, *__restrict__ step_num = a->step_num, *__restrict__ goal_count = a->goal_count;
+    uint32_t *__restrict__ done = a->done, *__restrict__ ep_cnt = a->ep_cnt, *__restrict__ infeas_n = a->infeas_n;
+    double *__restrict__ ep_sum = a->ep_sum;
     uint32_t sn = step_num[i] + 1u;
 
     // reward (roboy_env.py:92-112), fp32.  The normalisation (2v - hi - lo)/(hi - lo)
@@ -318,11 +365,13 @@ __device__ __forceinline__ void env_account(const EnvParams &e, const GoalBox &b
         // after a few episodes), counts as integers (fp32 counters stop at 2^24)
         rbe::stat_add(&ep_sum[i], double(ret)); rbe::stat_add(&ep_sum[n + i], double(ret) * double(ret));
         rbe::stat_add(&ep_cnt[i], 1u); rbe::stat_add(&ep_cnt[n + i], sn - 1u); rbe::stat_add(&ep_cnt[2 * n + i], reached ? 1u : 0u);
-        const uint64_t gid = env0 + uint64_t(i);
+        const uint64_t gid = a->env0 + uint64_t(i);
+        const uint64_t seed = a->seed;
+        const float lo[3] = {a->box_lo[0], a->box_lo[1], a->box_lo[2]}, hi[3] = {a->box_hi[0], a->box_hi[1], a->box_hi[2]};
         uint32_t draw = goal_count[i];
         // RoboyEnv.step draws a goal (_set_new_goal, :67-68); the VecEnv worker's env.reset() (:82-87) then draws another one, which
         // replaces it before anybody saw it: the counter advances by two, only the SECOND draw is evaluated
-        draw_goal3(box, seed, gid, draw + (e.auto_reset ? 1u : 0u), gg);
+        draw_goal3(lo, hi, seed, gid, draw + (e.auto_reset ? 1u : 0u), gg);
         draw += e.auto_reset ? 2u : 1u;
         if (e.auto_reset) {
 #pragma unroll
@@ -350,15 +399,12 @@ __device__ __forceinline__ void env_account(const EnvParams &e, const GoalBox &b
 // UNROLL = 0: run-time tendon count (ConstX, c.nt tendons, action rows of c.nt floats)
 template <int INTEG, int BLOCK, int UNROLL, typename CONST = Const8, bool BK = false>
 __global__ void __launch_bounds__(BLOCK)
-msj_env_step_kernel(const CONST c_arg, const EnvParams e, const GoalBox box,
-                    float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
-                    float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
-                    uint32_t *__restrict__ goal_count, const float *__restrict__ act,
-                    float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
-                    double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt, uint32_t *__restrict__ infeas_n,
-                    long n, long cnt, uint64_t seed, uint64_t env0) {
-    // n: the handle's envs = the stride of the state / goal / statistics planes; cnt: the envs of THIS launch - all of them, or a
-    // sub-range (rb_env_step_range_dev: every pointer then points at the range's first env, env0 is its global id)
+msj_env_step_kernel(const CONST c_arg, const MsjEnvArgs a) {
+    // a.n: the handle's envs = the stride of the state / goal / statistics planes; a.cnt: the envs of THIS launch - all of them, or a
+    // sub-range (rb_env_step_range_dev: every pointer then points at the range's first env, a.env0 is its global id)
+    const float *__restrict__ q = a.q, *__restrict__ qd = a.qd, *__restrict__ goal = a.goal, *__restrict__ act = a.act;
+    const long n = a.n, cnt = a.cnt;
+    const float slope = a.e.slope, act_hi = a.e.act_hi;
     const CONST &c = robot_consts<BK>(c_arg);
     const long i = long(blockIdx.x) * BLOCK + threadIdx.x;
     if (i >= cnt) return;
@@ -368,7 +414,7 @@ msj_env_step_kernel(const CONST c_arg, const EnvParams e, const GoalBox box,
     // the reference asserts the action lies in [-1,1] (roboy_env.py:52); a batched kernel
     // cannot raise, so it clamps.  Then slope * (x - in_high) + out_high, each op rounded
     // (roboy_env.py:157-158)
-    auto rescale = [&](float a) { return mul_then_add(e.slope, fminf(fmaxf(a, -1.0f), 1.0f) - 1.0f, e.act_hi); };
+    auto rescale = [&](float x) { return mul_then_add(slope, fminf(fmaxf(x, -1.0f), 1.0f) - 1.0f, act_hi); };
     bool ok;
     if constexpr (UNROLL == 0) {
         __shared__ float lds_sp[NTX][BLOCK];
@@ -380,9 +426,9 @@ msj_env_step_kernel(const CONST c_arg, const EnvParams e, const GoalBox box,
     float sp[NT8];
     const float4 a0 = reinterpret_cast<const float4 *>(act)[2 * i];
     const float4 a1 = reinterpret_cast<const float4 *>(act)[2 * i + 1];
-    const float a[NT8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float av[NT8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-    for (int k = 0; k < NT8; ++k) sp[k] = rescale(a[k]) * c.ten[k].ksg;   // set-point -> activation offset
+    for (int k = 0; k < NT8; ++k) sp[k] = rescale(av[k]) * c.ten[k].ksg;   // set-point -> activation offset
     if (UNROLL == RS) {
         ok = rb::MsjModel<float, NT8>::template step_rs<INTEG>(c, qq, vv, sp);
     } else if (UNROLL >= NT8) {
@@ -396,7 +442,8 @@ msj_env_step_kernel(const CONST c_arg, const EnvParams e, const GoalBox box,
         ok = rb::MsjModel<float, NT8>::template step_sp<INTEG, UNROLL>(c, qq, vv, SpLds{&lds_sp[0][threadIdx.x], BLOCK});
     }
     }
-    env_account(e, box, i, n, qq, vv, gg, ok, q, qd, feas, goal, step_num, ep_ret, goal_count, obs, reward, done, ep_sum, ep_cnt, infeas_n, seed, env0);
+    if constexpr (BK) env_account(&a, i, qq, vv, gg, ok);
+    else env_account(late_env_args(msj_env_args_offset(int(sizeof(CONST)))), i, qq, vv, gg, ok);
 }
 
 
@@ -407,13 +454,10 @@ msj_env_step_kernel(const CONST c_arg, const EnvParams e, const GoalBox box,
 // 5.2 for one env per lane (profiles/r4_a/mid_sweep.log) and the env layer used to be an env-per-lane kernel whatever the step was.
 template <int INTEG, int BLOCK, int MIRROR, bool BK = false>
 __global__ void __launch_bounds__(BLOCK)
-msj_env_step_mirror_pairs(const Const8 c_arg, const PairMap pm, const EnvParams e, const GoalBox box,
-                          float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
-                          float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
-                          uint32_t *__restrict__ goal_count, const float *__restrict__ act,
-                          float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
-                          double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt, uint32_t *__restrict__ infeas_n,
-                          long n, long cnt, uint64_t seed, uint64_t env0) {
+msj_env_step_mirror_pairs(const Const8 c_arg, const PairMap pm, const MsjEnvArgs a) {
+    const float *__restrict__ q = a.q, *__restrict__ qd = a.qd, *__restrict__ goal = a.goal, *__restrict__ act = a.act;
+    const long n = a.n, cnt = a.cnt;
+    const float slope = a.e.slope, act_hi = a.e.act_hi;
     const Const8 &c = robot_consts<BK>(c_arg);
     const long wg0 = long(blockIdx.x) * (BLOCK / 2);
     const long left = cnt - wg0;
@@ -428,8 +472,8 @@ msj_env_step_mirror_pairs(const Const8 c_arg, const PairMap pm, const EnvParams 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         // clamp, slope * (x - in_high) + out_high with two roundings (roboy_env.py:157-158), then set-point -> activation offset
-        const float a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, off * NT8 + pm.a[k] + oddi * pm.d[k], 0, 0));
-        u[k] = mul_then_add(e.slope, fminf(fmaxf(a, -1.0f), 1.0f) - 1.0f, e.act_hi) * c.ten[k].ksg;
+        const float x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, off * NT8 + pm.a[k] + oddi * pm.d[k], 0, 0));
+        u[k] = mul_then_add(slope, fminf(fmaxf(x, -1.0f), 1.0f) - 1.0f, act_hi) * c.ten[k].ksg;
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -443,7 +487,8 @@ msj_env_step_mirror_pairs(const Const8 c_arg, const PairMap pm, const EnvParams 
     qq[F1] = __uint_as_float(__float_as_uint(qq[F1]) ^ flip); vv[F1] = __uint_as_float(__float_as_uint(vv[F1]) ^ flip);
     const bool ok = rb::MsjModel<float, NT8>::template integrate_acc<INTEG>(c, qq, vv, AccelMirrorHalf<MIRROR>{c, u});
     if (odd) return;                           // the even lane holds the env itself
-    env_account(e, box, i, n, qq, vv, gg, ok, q, qd, feas, goal, step_num, ep_ret, goal_count, obs, reward, done, ep_sum, ep_cnt, infeas_n, seed, env0);
+    if constexpr (BK) env_account(&a, i, qq, vv, gg, ok);
+    else env_account(late_env_args(msj_env_args_offset(int(sizeof(Const8) + sizeof(PairMap)))), i, qq, vv, gg, ok);
 }
 
 

@@ -127,58 +127,47 @@ int l_msj_fused_jit(rb_sim *s, const Launch &L) {
     return RB_OK;
 }
 
-// fused env layer, ball joints: SoA planes keep their stride n; everything else is indexed by env and shifted
-struct MsjEnvPtrs {
-    float *q, *qd, *goal, *ret, *obs, *rew;
-    uint32_t *feas, *sn, *gc, *done, *cnt, *inf;
-    const float *act;
-    double *sum;
-    uint64_t e0;
-};
-inline MsjEnvPtrs msj_env_ptrs(rb_sim *s, const Launch &L) {
+// fused env layer, ball joints: ONE argument behind the constants (msj_kernels.hpp: MsjEnvArgs).  SoA planes keep their stride n;
+// everything else is indexed by env and shifted for a sub-range
+inline MsjEnvArgs msj_env_args(rb_sim *s, const Launch &L) {
     const long i0 = L.i0;
-    return {s->d_q + i0, s->d_qd + i0, s->d_goal + i0, s->d_ep_ret + i0, L.obs + i0 * 9, L.reward + i0,
-            s->d_feas + i0, s->d_step_num + i0, s->d_goal_count + i0, L.done + i0, s->d_ep_cnt + i0, s->d_infeas_n + i0,
-            L.act + i0 * s->n_t, s->d_ep_sum + i0, uint64_t(s->env0) + uint64_t(i0)};
+    MsjEnvArgs a;
+    a.e = s->env;
+    for (int j = 0; j < 3; ++j) { a.box_lo[j] = s->box.lo[j]; a.box_hi[j] = s->box.hi[j]; }
+    a.q = s->d_q + i0; a.qd = s->d_qd + i0; a.feas = s->d_feas + i0; a.goal = s->d_goal + i0; a.step_num = s->d_step_num + i0;
+    a.ep_ret = s->d_ep_ret + i0; a.goal_count = s->d_goal_count + i0; a.act = L.act + i0 * s->n_t;
+    a.obs = L.obs + i0 * 9; a.reward = L.reward + i0; a.done = L.done + i0;
+    a.ep_sum = s->d_ep_sum + i0; a.ep_cnt = s->d_ep_cnt + i0; a.infeas_n = s->d_infeas_n + i0;
+    a.n = s->n; a.cnt = L.cnt; a.seed = s->seed; a.env0 = uint64_t(s->env0) + uint64_t(i0);
+    return a;
 }
-#define RB_MSJ_ENV_ARGS(p) s->env, s->box, p.q, p.qd, p.feas, p.goal, p.sn, p.ret, p.gc, p.act, p.obs, p.rew, p.done, p.sum, p.cnt, p.inf, s->n, L.cnt, s->seed, p.e0
 template <int INTEG, int B, int U, bool BK>
 int l_msj_env(rb_sim *s, const Launch &L) {
-    const MsjEnvPtrs p = msj_env_ptrs(s, L);
-    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, U, Const8, BK>), dim3(blocks_for(L.cnt, B)), dim3(B), 0, L.stream, s->c8, RB_MSJ_ENV_ARGS(p));
+    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, U, Const8, BK>), dim3(blocks_for(L.cnt, B)), dim3(B), 0, L.stream, s->c8, msj_env_args(s, L));
     return RB_OK;
 }
 template <int INTEG, int B>
 int l_msj_env_nt(rb_sim *s, const Launch &L) {
-    const MsjEnvPtrs p = msj_env_ptrs(s, L);
-    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, 0, ConstX>), dim3(blocks_for(L.cnt, B)), dim3(B), 0, L.stream, s->cx, RB_MSJ_ENV_ARGS(p));
+    hipLaunchKernelGGL((msj_env_step_kernel<INTEG, B, 0, ConstX>), dim3(blocks_for(L.cnt, B)), dim3(B), 0, L.stream, s->cx, msj_env_args(s, L));
     return RB_OK;
 }
 int l_msj_env_jit(rb_sim *s, const Launch &L) {
-    MsjEnvPtrs p = msj_env_ptrs(s, L);
     Const8 c8 = s->c8;
-    EnvParams ep = s->env;
-    GoalBox box = s->box;
-    long nn = s->n, cc = L.cnt;
-    uint64_t seed = s->seed;
-    void *args[] = {&c8, &ep, &box, &p.q, &p.qd, &p.feas, &p.goal, &p.sn, &p.ret, &p.gc, &p.act, &p.obs, &p.rew, &p.done, &p.sum, &p.cnt, &p.inf, &nn, &cc, &seed, &p.e0};
+    MsjEnvArgs a = msj_env_args(s, L);
+    void *args[] = {&c8, &a};
     RB_HIP(hipModuleLaunchKernel(s->jit.env[s->integrator == RB_EULER ? 0 : 1], blocks_for(L.cnt, 256), 1, 1, 256, 1, 1, 0, L.stream, args, nullptr));
     return RB_OK;
 }
 template <int INTEG, int B, int M, bool BK>
 int l_msj_env_pair(rb_sim *s, const Launch &L) {
-    const MsjEnvPtrs p = msj_env_ptrs(s, L);
-    const PairMap pm = pair_map(s);
-    hipLaunchKernelGGL((msj_env_step_mirror_pairs<INTEG, B, M, BK>), dim3(blocks_for(2 * L.cnt, B)), dim3(B), 0, L.stream, s->c8p, pm, RB_MSJ_ENV_ARGS(p));
+    hipLaunchKernelGGL((msj_env_step_mirror_pairs<INTEG, B, M, BK>), dim3(blocks_for(2 * L.cnt, B)), dim3(B), 0, L.stream, s->c8p, pair_map(s), msj_env_args(s, L));
     return RB_OK;
 }
 template <int INTEG>
 int l_msj_env_octet(rb_sim *s, const Launch &L) {
-    const MsjEnvPtrs p = msj_env_ptrs(s, L);
-    hipLaunchKernelGGL((msj_env_step_tendon_per_lane<INTEG>), dim3(blocks_for(L.cnt * NT8, 64)), dim3(64), 0, L.stream, s->c8, s->d_ten, RB_MSJ_ENV_ARGS(p));
+    hipLaunchKernelGGL((msj_env_step_tendon_per_lane<INTEG>), dim3(blocks_for(L.cnt * NT8, 64)), dim3(64), 0, L.stream, s->c8, s->d_ten, msj_env_args(s, L));
     return RB_OK;
 }
-#undef RB_MSJ_ENV_ARGS
 
 // ---------------------------------------------------------------------------------------------------- launchers: joint trees
 // (one struct argument for the env kernels: they read most of it behind the step - env_common.hpp, TreeEnvArgs; env-major rows: a

@@ -292,13 +292,10 @@ msj_step_tendon_per_lane(const Const8 c, const rb::MsjTendon<float> *__restrict_
 // n: the handle's envs (plane stride); cnt: the envs of this launch (a sub-range arrives on shifted pointers, env0 = its global id).
 template <int INTEG>
 __global__ void __launch_bounds__(64)
-msj_env_step_tendon_per_lane(const Const8 c, const rb::MsjTendon<float> *__restrict__ ten, const EnvParams ep, const GoalBox box,
-                             float *__restrict__ q, float *__restrict__ qd, uint32_t *__restrict__ feas,
-                             float *__restrict__ goal, uint32_t *__restrict__ step_num, float *__restrict__ ep_ret,
-                             uint32_t *__restrict__ goal_count, const float *__restrict__ act,
-                             float *__restrict__ obs, float *__restrict__ reward, uint32_t *__restrict__ done,
-                             double *__restrict__ ep_sum, uint32_t *__restrict__ ep_cnt, uint32_t *__restrict__ infeas_n,
-                             long n, long cnt, uint64_t seed, uint64_t env0) {
+msj_env_step_tendon_per_lane(const Const8 c, const rb::MsjTendon<float> *__restrict__ ten, const MsjEnvArgs a) {
+    const float *__restrict__ q = a.q, *__restrict__ qd = a.qd, *__restrict__ goal = a.goal, *__restrict__ act = a.act;
+    const long n = a.n, cnt = a.cnt;
+    const float slope = a.e.slope, act_hi = a.e.act_hi;
     const unsigned nb = gridDim.x, xcd = blockIdx.x & 7u, qn = nb >> 3, rn = nb & 7u;      // XCD-aware block -> env-group map (above)
     const unsigned blk = (xcd < rn ? xcd * (qn + 1u) : rn * (qn + 1u) + (xcd - rn) * qn) + (blockIdx.x >> 3);
     const long t = long(blk) * 64 + threadIdx.x;
@@ -308,14 +305,14 @@ msj_env_step_tendon_per_lane(const Const8 c, const rb::MsjTendon<float> *__restr
     if (!live) e = cnt - 1;           // dead groups shadow the last env so every DPP partner is active
     const rb::MsjTendon<float> rec = ten[k];
     // clamp, slope * (x - in_high) + out_high with two roundings (roboy_env.py:157-158), then set-point -> activation offset
-    const float a = act[e * NT8 + k];
-    const float spk = rbk::mul_then_add(ep.slope, fminf(fmaxf(a, -1.0f), 1.0f) - 1.0f, ep.act_hi) * rec.ksg;
+    const float x = act[e * NT8 + k];
+    const float spk = rbk::mul_then_add(slope, fminf(fmaxf(x, -1.0f), 1.0f) - 1.0f, act_hi) * rec.ksg;
     float qq[3], vv[3], gg[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { qq[j] = q[j * n + e]; vv[j] = qd[j * n + e]; gg[j] = goal[j * n + e]; }
     const bool ok = rb::MsjModel<float, NT8>::template integrate<INTEG>(c, qq, vv, AccelOneTendon{c, rec, spk});
-    if (live && k == 0)
-        rbk::env_account(ep, box, e, n, qq, vv, gg, ok, q, qd, feas, goal, step_num, ep_ret, goal_count, obs, reward, done, ep_sum, ep_cnt, infeas_n, seed, env0);
+    // (kernarg constants: the accounting reads its arguments late - msj_kernels.hpp, MsjEnvArgs)
+    if (live && k == 0) rbk::env_account(rbk::late_env_args(rbk::msj_env_args_offset(int(sizeof(Const8) + sizeof(void *)))), e, qq, vv, gg, ok);
 }
 
 

@@ -81,6 +81,23 @@ __device__ __forceinline__ void store_rows(float *__restrict__ g, long env0, int
     lane_wave_sync();
 }
 
+// rows [64][W] of a wave, env-major in HBM -> out[W] of each lane (the inverse of store_rows; lanes past the batch read the last live row)
+template <int W>
+__device__ __forceinline__ void load_rows(const float *__restrict__ g, long env0, int live, float *region, int lane_, float (&out)[W]) {
+    const int lane = opaque(lane_);
+    const __amdgpu_buffer_rsrc_t r = rows_rsrc(g, env0, W, live);
+    float t[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) t[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, k * 256, 0));
+#pragma unroll
+    for (int k = 0; k < W; ++k) region[k * 64 + lane] = t[k];
+    lane_wave_sync();
+    const int row = lane < live ? lane : live - 1;
+#pragma unroll
+    for (int j = 0; j < W; ++j) out[j] = region[row * W + j];
+    lane_wave_sync();
+}
+
 __device__ __forceinline__ float sat(float v, int j) { return __builtin_amdgcn_fmed3f(v, -VMAX[j], VMAX[j]); }
 
 // One env step of this lane's env: n_sub integrator substeps with the activation offsets held; velocity saturation
@@ -278,15 +295,29 @@ tree_lane_env_step(const rbe::TreeEnvArgs a) {
     float *region = lds_lane;
     const LaneLds L{region + lane};
     float qq[RBL_NQ], vv[RBL_NQ], spu[RBL_NT], gg[RBL_NQ];
+    // What the accounting needs of the env's OLD state - its goal row and three counters - is fetched in front of the step (one batch of
+    // loads with the state rows: their latency passes behind the acceleration) where the register file can carry n_q + 3 more values
+    // across the step: Euler.  RK4 holds q0, v0 and the stage state beside the acceleration's live set - with the goal on top the
+    // compiler put 13 values into scratch (56 bytes per lane, stored in front of the step and reloaded behind it: a private segment,
+    // and a memory round trip anyway): there the goal rows and the counters are fetched BEHIND the step (RBL_LATE_GOAL bit 1; bit 0 =
+    // Euler too).  Same values either way - nobody writes them during the step.
+#ifndef RBL_LATE_GOAL
+#define RBL_LATE_GOAL 2
+#endif
+    constexpr bool LATE_GOAL = ((RBL_LATE_GOAL >> INTEG) & 1) != 0;
     RBL_LANE_STAMP(0);
-    load_inputs<true>(q, qd, act, goal, env0, live, region, lane, qq, vv, spu, gg);
+    load_inputs<!LATE_GOAL>(q, qd, act, goal, env0, live, region, lane, qq, vv, spu, gg);
     RBL_LANE_STAMP(1);
-    // the env's counters, requested now as well (their latency passes behind the acceleration)
     const bool mine = lane < live;
     const long me = env0 + (mine ? lane : live - 1);
-    const uint32_t sn_old = step_num[me];
-    const float ret_old = ep_ret[me];
-    const uint32_t draw_old = goal_count[me];       // (needed when the episode ends only - but then it would be a memory latency of its own)
+    uint32_t sn_old = 0u, draw_old = 0u;
+    float ret_old = 0.0f;
+    if constexpr (!LATE_GOAL) {
+        // the env's counters, requested now as well (their latency passes behind the acceleration)
+        sn_old = step_num[me];
+        ret_old = ep_ret[me];
+        draw_old = goal_count[me];       // (needed when the episode ends only - but then it would be a memory latency of its own)
+    }
 #pragma unroll
     for (int k = 0; k < RBL_NT; ++k) {
         // clamp to the action box, then slope * (x - in_high) + out_high with two roundings (roboy_env.py:157-158)
@@ -299,6 +330,12 @@ tree_lane_env_step(const rbe::TreeEnvArgs a) {
     const rbe::EnvParams ep = rbe::late_env_params(late);
     const uint64_t seed = late->seed, env_id0 = late->env_id0;
     const long stat_stride = late->stat_stride;
+    if constexpr (LATE_GOAL) {
+        sn_old = late->step_num[me];
+        ret_old = late->ep_ret[me];
+        draw_old = late->goal_count[me];
+        load_rows<RBL_NQ>(late->goal, env0, live, region, lane, gg);      // (the region is idle again)
+    }
     // observation [q | qd | goal], reward, done; goal redraw (and reset) on done
     float o[3 * RBL_NQ];
 #pragma unroll

@@ -94,7 +94,7 @@ def kernel_metadata(lib_path=None):
 
 def short(name):
     """`void rbk::msj_step_env_per_lane_rs<1, 256, true>(rb::MsjConst<...>, ...)` -> `rbk::msj_step_env_per_lane_rs<1, 256, true>`"""
-    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     depth = 0
     for i, ch in enumerate(name):
         if ch == "<":

@@ -22,8 +22,30 @@ tag = sys.argv[1]
 SRC = os.path.join(ROOT, "gpurun_out", tag)
 DST = os.path.join(ROOT, "profiles", sys.argv[2] if len(sys.argv) > 2 else tag)       # (raw run directory, committed directory)
 os.makedirs(DST, exist_ok=True)
-STEP_KERNELS = ("msj_step_env_per_lane", "msj_step_tendon_per_lane", "msj_step_mirror_pairs", "msj_env_step_mirror_pairs", "tree_step_aba", "msj_env_step_kernel",
+STEP_KERNELS = ("msj_step_env_per_lane", "msj_step_tendon_per_lane", "msj_step_mirror_pairs", "msj_env_step_mirror_pairs", "msj_env_step_tendon_per_lane", "tree_step_aba", "msj_env_step_kernel",
                 "tree_lane_step", "tree_lane_env_step", "tree_env_step_aba", "tree_split_step", "tree_split_env_step")
+
+
+# the kernel sources the counters were collected on (gpu_profile_round.sh writes the hash on the GPU box): every row carries it, and
+# bench.py marks a row whose stamp differs from the tree's hash as stale
+try:
+    with open(os.path.join(SRC, "csrc_hash.txt")) as fh:
+        CSRC_HASH = fh.read().split()[0]
+except Exception:
+    CSRC_HASH = None
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import bench  # noqa: E402
+import code_object_meta  # noqa: E402
+if CSRC_HASH != bench.csrc_hash():
+    print("WARNING: the raw run was collected on kernel sources %s, this tree has %s: rows will read as stale" % (CSRC_HASH, bench.csrc_hash()))
+try:
+    # registers / scratch / static LDS as the CODE OBJECTS state them (rocprofv3's own trace columns are the dispatch packet's granulated
+    # values: 'VGPR 236' for a kernel whose metadata says 470); only meaningful when the library in the tree is the one that was profiled
+    CO_META = {code_object_meta.short(k): v for k, v in code_object_meta.kernel_metadata().items()}
+except Exception as exc:
+    print("no code-object metadata (%s): resource columns left empty" % exc)
+    CO_META = {}
 
 
 def counters(dirname):
@@ -62,17 +84,21 @@ for f in glob.glob(os.path.join(SRC, "prof_stats", "**", "*kernel_trace.csv"), r
             continue
         key = (name, int(row["Grid_Size_X"]), int(row["Workgroup_Size_X"]))
         by_grid[key].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
-        meta[key] = (row["VGPR_Count"], row["Accum_VGPR_Count"], row["SGPR_Count"], row["Scratch_Size"], row["LDS_Block_Size"])
+        meta[key] = (row["LDS_Block_Size"],)            # the dispatch's LDS (static + dynamic): a launch argument, not in the code object
 if by_grid:
     with open(os.path.join(DST, "kernel_stats_by_grid.csv"), "w") as fh:
         w = csv.writer(fh)
-        w.writerow(["Name", "Grid_Size_X", "Workgroup_Size_X", "Envs", "Calls", "AverageNs", "MinNs", "MaxNs", "VGPR", "AGPR", "SGPR", "Scratch", "LDS"])
+        w.writerow(["Name", "Grid_Size_X", "Workgroup_Size_X", "Envs", "Calls", "AverageNs", "MinNs", "MaxNs", "VGPR", "AGPR", "SGPR", "ScratchBytesPerLane",
+                    "VGPRSpills", "SGPRSpills", "StaticLDSBytes", "DispatchLDSBytes", "csrc_hash"])
         for key in sorted(by_grid, key=lambda k: (k[0], k[1])):
             v = by_grid[key]
             tail = v[10:] if len(v) > 20 else v
             # threads per env: 8 in the tendon-per-lane form, 32 in the octet kernels (2 envs per wave), 1 otherwise
             per_env = 8 if "tendon_per_lane" in key[0] else 2 if "mirror_pairs" in key[0] else (32 if "_aba" in key[0] else (key[2] // 64 if "tree_split" in key[0] else 1))
-            w.writerow([key[0], key[1], key[2], key[1] // per_env, len(v), "%.1f" % (sum(tail) / len(tail)), min(tail), max(tail)] + list(meta[key]))
+            co = CO_META.get(code_object_meta.short(key[0])) or {}
+            w.writerow([key[0], key[1], key[2], key[1] // per_env, len(v), "%.1f" % (sum(tail) / len(tail)), min(tail), max(tail),
+                        co.get("vgpr_count", ""), co.get("agpr_count", ""), co.get("sgpr_count", ""), co.get("private_segment_fixed_size", ""),
+                        co.get("vgpr_spill_count", ""), co.get("sgpr_spill_count", ""), co.get("group_segment_fixed_size", ""), meta[key][0], CSRC_HASH])
 
 traffic = {}
 for d in sorted(glob.glob(os.path.join(SRC, "pmc_*_FETCH_SIZE"))):
@@ -86,7 +112,7 @@ for d in sorted(glob.glob(os.path.join(SRC, "pmc_*_FETCH_SIZE"))):
     fm, fn = mean_tail(fetch[kern]["FETCH_SIZE"])
     wm, wn = mean_tail(write[kern]["WRITE_SIZE"])
     traffic[w] = {"FETCH_SIZE": {"dispatches": fn, "mean_KiB": fm}, "WRITE_SIZE": {"dispatches": wn, "mean_KiB": wm},
-                  "kernel": kern, "hbm_bytes_per_launch": (2.0 * fm + wm) * 1024.0,
+                  "kernel": kern, "hbm_bytes_per_launch": (2.0 * fm + wm) * 1024.0, "csrc_hash": CSRC_HASH,
                   "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md HBM section); "
                                 "WRITE_SIZE as reported; KiB -> bytes"}
 with open(os.path.join(DST, "hbm_traffic_pmc.json"), "w") as fh:
@@ -111,7 +137,7 @@ for d in sorted(glob.glob(os.path.join(SRC, "pmc_*_SQ1"))):
             if k in c and c.get("SQ_WAVE_CYCLES")}
     if c.get("SQ_LDS_IDX_ACTIVE"):
         frac["lds_bank_conflict_of_lds_active"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
-    sq[w] = {"kernel": kern, "per_launch": dict(c), "per_wave": per_wave, "fraction_of_wave_cycles": frac,
+    sq[w] = {"kernel": kern, "csrc_hash": CSRC_HASH, "per_launch": dict(c), "per_wave": per_wave, "fraction_of_wave_cycles": frac,
              "note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, cycle constants)"}
 with open(os.path.join(DST, "sq_counters.json"), "w") as fh:
     json.dump(sq, fh, indent=1, sort_keys=True)
