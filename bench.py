@@ -27,14 +27,20 @@ repeats, ms_per_step, higher_is_better, scaling, vs_baseline, dtype, data,
 config, roofline, cpu_baseline, collective, sanity); a longer line is a bug and
 the exit code says so (4).  Strict JSON: non-finite numbers are written as null.
 
-Timing (``timing_protocol`` 2): W untimed warm-up steps, then the K-step region -
-bracketed by a barrier and a device synchronisation on both sides - is timed R
-times (R chosen so that the repeats cover >= 50 ms of device time, so a small K
-does not turn the number into a measurement of launch latency); ``ms_per_step``
-is the MEAN over the repeats of (max over ranks of the region's wall time) / K
-(``ms_per_step_median`` beside it; rounds 1-3 = protocol 1 printed the median and
-reduced the statistics in every region) and ``value`` the env steps of all ranks
-in one region divided by that time.
+Timing (``timing_protocol`` 3): W untimed warm-up steps, then the K-step region -
+bracketed by a barrier and a device synchronisation on both sides - is timed 2 R
+times (R chosen so that R repeats cover >= 50 ms of device time, so a small K
+does not turn the number into a measurement of launch latency).  The regions
+alternate: R are timed by the wall clock alone, R carry two HIP events on the
+launch stream around their K launches as well.  ``ms_per_step`` is the MEAN over
+the event-free repeats of (max over ranks of the region's wall time) / K
+(``ms_per_step_median`` beside it, ``ms_per_step_with_events`` = the same mean
+over the other R) and ``value`` the env steps of all ranks in one region divided
+by that time; ``roofline`` is built from the events (median).  (Protocol 2,
+rounds 4-5, recorded the events in every region: the two records - markers with
+a system-scope fence - cost a 20-step region 5-10 us of its wall time, which is
+instrumentation, not the workload.  Protocol 1, rounds 1-3, printed the median
+and reduced the statistics in every region.)
 
 N > 1: one rank per GPU under torch.distributed.run - started by the caller (WORLD_SIZE set: behave as a rank) or, when
 `python bench.py --gpus N` is run bare, by bench.py itself as a fresh child process tree before any GPU call
@@ -269,18 +275,24 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
                 reduce_stats()
                 state["since"] = 0
 
-    def timed_region():
-        """One K-step region between barrier + synchronize pairs.  Returns (wall seconds
-        = max over ranks, device seconds between two events on the launch stream that
-        bracket the K launches and nothing else)."""
+    def timed_region(with_events=True):
+        """One K-step region between barrier + synchronize pairs.  Returns (wall seconds = max over ranks, device seconds between
+        two events on the launch stream that bracket the K launches and nothing else - None for a region timed by the wall clock
+        alone).  The two event records are instrumentation with a price of their own - markers with a system-scope fence in front
+        of the first launch and behind the last: the empty bracket (record, record, synchronize) takes 17 us of wall time on this
+        stack, profiles/r6_a/rollout_call_overhead.log - so the regions alternate: the wall clock of the event-free ones makes
+        `ms_per_step` / `value`, the events of the others make `roofline`."""
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0 = ev1 = None
+        if with_events:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record(stream)
-        advance(steps, before_reduce=lambda: ev1.record(stream))
+        if with_events:
+            ev0.record(stream)
+        advance(steps, before_reduce=(lambda: ev1.record(stream)) if with_events else None)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0          # this rank: start of the region -> its work is complete
         if dist is not None:
@@ -290,7 +302,7 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
             t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
-        return wall, ev0.elapsed_time(ev1) * 1e-3
+        return wall, (ev0.elapsed_time(ev1) * 1e-3 if with_events else None)
 
     # 16 untimed steps from the reset state decorrelate the envs, then warm-up
     advance(16)
@@ -303,11 +315,15 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
         # >= MIN_TIMED_S of device time; same R on every rank (the region's wall time is the max over ranks)
         est_wall, _ = timed_region()
         repeats = max(3, min(MAX_REPEATS, int(np.ceil(1.05 * MIN_TIMED_S / max(est_wall, 1e-6)))))
-    walls, devs = [], []
-    for _ in range(repeats):
-        w, d = timed_region()
-        walls.append(w)
-        devs.append(d)
+    # 2 R regions, alternating: R timed by the wall clock alone (-> ms_per_step, value), R with the two events as well (-> roofline)
+    walls, walls_ev, devs = [], [], []
+    for i in range(2 * repeats):
+        w, d = timed_region(with_events=(i % 2 == 1))
+        if d is None:
+            walls.append(w)
+        else:
+            walls_ev.append(w)
+            devs.append(d)
     # The statistics reduction (+ all-reduce at N > 1) falls into one region in every STATS_EVERY / K: the MEAN over the repeats
     # carries its amortised cost (a median would hide it whenever fewer than half of the regions contain one).
     wall = statistics.fmean(walls)
@@ -339,6 +355,7 @@ def run_workload(torch, robot, name, steps, warmup, envs, use_graph, rank, world
         "value": world * n_envs * steps / wall, "ms_per_step": wall * 1e3 / steps,
         "ms_per_step_min": min(walls) * 1e3 / steps, "ms_per_step_max": max(walls) * 1e3 / steps,
         "ms_per_step_median": statistics.median(walls) * 1e3 / steps,
+        "ms_per_step_with_events": statistics.fmean(walls_ev) * 1e3 / steps, "event_repeats": len(devs),
         "timed_device_ms": sum(devs) * 1e3,
         "launch_us_events": launch_s * 1e6,
         "roofline": roofline(robot_name, integrator, nsub, n_envs, info["bytes_per_env_step"], launch_s,
@@ -593,8 +610,10 @@ def brief(r):
 
 
 LINE_CAP = 4096            # bytes: the contract line on stdout never exceeds this (the driver keeps a bounded tail of stdout)
-TIMING_PROTOCOL = 2        # 1 (rounds 1-3): statistics reduction at the end of every region, ms_per_step = median of the region walls
-                           # 2 (round 4 on): reduction every STATS_EVERY steps counted across regions, ms_per_step = mean; the median rides along
+TIMING_PROTOCOL = 3        # 1 (rounds 1-3): statistics reduction at the end of every region, ms_per_step = median of the region walls
+                           # 2 (rounds 4-5): reduction every STATS_EVERY steps counted across regions, ms_per_step = mean; the median rides along
+                           # 3 (round 6): as 2, and the regions alternate - wall clock alone (-> ms_per_step, value) / wall clock + the two
+                           #   HIP events (-> roofline; their wall time rides along as ms_per_step_with_events)
 # the secondary workloads whose compact rows ride in roofline.configs (everything else: bench_also.json / stderr)
 CONFIG_ROWS = ("msj-4096-euler", "upper-body-8192-euler", "upper-body-8192-rk4", "msj-262144-euler", "msj-2097152-euler",
                "fused-env-2097152", "upper-body-65536-euler", "fused-env-UpperBodyRobot-65536", "fused-env-UpperBodyRobot-65536-chains")
@@ -704,10 +723,11 @@ def build_line(head, also, one_launch, cpu, world, robot_name, use_graph):
                               if use_graph else "eager per-step launches"),
                    "parallelism": ("env shards x%d, RCCL all-reduce of episode statistics every %d steps" % (world, STATS_EVERY))
                                   if world > 1 else "single GPU",
-                   "timing": "mean of the repeats of the K-step region (barrier + synchronize both sides, max over ranks); %.0f ms of device time"
-                             % head["timed_device_ms"]},
+                   "timing": "mean wall time of the event-free repeats of the K-step region (barrier + synchronize both sides, max over ranks); "
+                             "roofline from HIP events in alternate repeats (%.0f ms of device time)" % head["timed_device_ms"]},
         "timing_protocol": TIMING_PROTOCOL,
         "ms_per_step_median": head["ms_per_step_median"], "ms_per_step_spread": [head["ms_per_step_min"], head["ms_per_step_max"]],
+        "ms_per_step_with_events": head.get("ms_per_step_with_events"), "event_repeats": head.get("event_repeats"),
         "roofline": roof,
         "cpu_baseline": cpu_c,
         "collective": ({k: coll[k] for k in ("backend", "world_size", "allreduce_calls", "payload_bytes", "every_steps",

@@ -66,10 +66,11 @@ def test_the_drivers_exact_command_prints_one_capped_line():
     d = _run(["--gpus", "1", "--steps", "20", "--warmup", "5"])
     assert d["unit"] == "env-steps/s" and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["timing_protocol"] == 2
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["timing_protocol"] == 3
     assert "workload" in d["config"] and "model" not in d["config"] and "262 144" in d["config"]["workload"]
     assert d["config"]["envs_per_gpu"] == 262144 and d["config"]["integrator"] == "rk4"
-    assert d["repeats"] >= 3 and d["repeats"] * 20 * d["ms_per_step"] >= 40.0      # >= ~50 ms timed in all
+    assert d["repeats"] >= 3 and d["repeats"] * 20 * d["ms_per_step"] >= 40.0      # >= ~50 ms timed by the wall clock alone
+    assert d["event_repeats"] == d["repeats"] and d["ms_per_step"] < d["ms_per_step_with_events"] < 1.15 * d["ms_per_step"]   # (the events' own price)
     # value = envs * steps / time
     assert abs(d["value"] - d["config"]["total_envs"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-6
     r = d["roofline"]
@@ -141,7 +142,7 @@ def test_bench_collective_path_with_one_rccl_rank():
     assert d["n_gpus"] == 1 and d["steps"] == 20
     c = d["collective"]
     assert c["ok"] and c["world_size"] == 1 and c["backend"].startswith("rccl")
-    total = 16 + 5 + 20 * (d["repeats"] + 2)                   # decorrelation + warm-up + the regions (rehearsal and sizing region included)
+    total = 16 + 5 + 20 * (2 * d["repeats"] + 2)               # decorrelation + warm-up + the regions (R by the wall clock, R with events; rehearsal and sizing region)
     assert c["allreduce_calls"] == total // 100 + 1            # every 100 steps across the regions, + the closing one for the audit
     assert c["n_env_steps_allreduced"] == c["expected"] == 262144.0 * total
     assert d["roofline"]["one_launch"]["us_events"] > d["roofline"]["launch_us_events"]      # the one-launch form beside the chains
@@ -156,8 +157,8 @@ def test_bench_collective_with_full_chunks():
     d = _run(["--gpus", "1", "--steps", "250", "--warmup", "10", "--no-also", "--no-cpu-baseline",
               "--workload", "msj-4096-euler", "--repeats", "3"], env=env)
     c = d["collective"]
-    assert c["ok"] and c["allreduce_calls"] == (16 + 10 + 250 * 4) // 100 + 1 and c["every_steps"] == 100     # --repeats given: no sizing region
-    assert c["expected"] == 4096.0 * (16 + 10 + 250 * 4)
+    assert c["ok"] and c["allreduce_calls"] == (16 + 10 + 250 * 7) // 100 + 1 and c["every_steps"] == 100     # --repeats 3: 3 + 3 regions + the rehearsal, no sizing region
+    assert c["expected"] == 4096.0 * (16 + 10 + 250 * 7)
 
 
 def test_bench_two_ranks_share_the_gpu_over_gloo():
@@ -174,8 +175,8 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 2 * 262144 and d["scaling"] == "weak"
     c = d["collective"]
     assert c["ok"] and c["world_size"] == 2 and c["backend"] == "gloo"
-    assert c["allreduce_calls"] == (16 + 5 + 20 * 4) // 100 + 1       # three timed regions + the rehearsal (--repeats given: no sizing region)
-    assert c["n_env_steps_allreduced"] == 2 * 262144.0 * (16 + 5 + 20 * 4)
+    assert c["allreduce_calls"] == (16 + 5 + 20 * 7) // 100 + 1       # 3 + 3 timed regions + the rehearsal (--repeats given: no sizing region)
+    assert c["n_env_steps_allreduced"] == 2 * 262144.0 * (16 + 5 + 20 * 7)
     assert d["cpu_baseline"] is None and d["roofline"]["configs"] == {}
     assert d["roofline"]["one_launch"] is None          # N > 1: the one-launch leg runs with --one-launch only
 
@@ -193,5 +194,5 @@ def test_bare_gpus_2_starts_its_own_ranks_over_gloo():
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["config"]["total_envs"] == 2 * 262144
     c = d["collective"]
     assert c["ok"] and c["world_size"] == 2 and c["backend"] == "gloo"
-    assert c["n_env_steps_allreduced"] == c["expected"] == 2 * 262144.0 * (16 + 5 + 20 * (d["repeats"] + 2))
+    assert c["n_env_steps_allreduced"] == c["expected"] == 2 * 262144.0 * (16 + 5 + 20 * (2 * d["repeats"] + 2))
     assert d["cpu_baseline"] is None and "starting" in out.stderr

@@ -40,6 +40,7 @@ def worst_case(world=8, nan=False):
     head = {"workload": "msj-262144-rk4", "label": bench.WORKLOADS["msj-262144-rk4"][5], "envs_per_gpu": n, "integrator": "rk4",
             "substeps": 1, "steps": 20, "warmup": 5, "repeats": 256, "value": LONG * 10, "ms_per_step": LONG / 1e11,
             "ms_per_step_min": LONG / 1e11, "ms_per_step_max": LONG / 1e11, "ms_per_step_median": LONG / 1e11,
+            "ms_per_step_with_events": LONG / 1e11, "event_repeats": 256,
             "timed_device_ms": LONG / 1e7, "launch_us_events": LONG / 1e8, "roofline": _roofline(n, LONG / 1e8, 2),
             "kernel": "msj_step_env_per_lane", "stats": [-LONG * 1e3, LONG * 1e6, 896794624.0, LONG, LONG, LONG, 8.0 * n * 3421, LONG],
             "collective": {"backend": "rccl (torch.distributed 'nccl')", "world_size": world, "allreduce_calls": 1234,
@@ -91,7 +92,7 @@ def test_worst_case_line_stays_under_the_cap_and_parses_strictly(nan):
     # value and ms_per_step survive unrounded (the driver recomputes one from the other); counts survive exactly
     assert d["value"] == head["value"] and d["ms_per_step"] == head["ms_per_step"]
     assert d["collective"]["n_env_steps_allreduced"] == 8 * 262144 * 3421 == d["sanity"]["allreduced_stats"][6]
-    assert d["timing_protocol"] == 2 and d["ms_per_step_median"] > 0
+    assert d["timing_protocol"] == 3 and d["ms_per_step_median"] > 0 and d["ms_per_step_with_events"] > 0 and d["event_repeats"] == 256
     assert len(d["cpu_baseline"]["by_threads"]) == 3 and all(isinstance(v, float) for v in d["cpu_baseline"]["by_threads"].values())
     if nan:
         assert r["traffic"] is None and d["sanity"]["feasible_frac"] is None and d["sanity"]["allreduced_stats"][0] is None
