@@ -48,6 +48,15 @@ except Exception as exc:
     CO_META = {}
 
 
+# Dynamic LDS is a launch argument (neither in the code object nor in rocprofv3's trace columns, which read 0 for it): what the library's
+# launches pass for the committed upper body's ahead-of-time kernels (tree_lane.hpp: LDS_BYTES_PER_WAVE = (107 + 2 * 20) slots * 256 B;
+# tree_lane_split.hpp: SP_LDS_BYTES of the five-wave form = 145.5 KB, of the lean two-part form = 55.5 KB; the host's formulas are
+# static_assert'ed against the kernels' in csrc/)
+DYNAMIC_LDS = {"rbl_baked::tree_lane_step": 37632, "rbl_baked::tree_lane_env_step": 37632,
+               "rbl_split_baked::tree_split_step": 148992, "rbl_split_baked::tree_split_env_step": 148992,
+               "rbl_split2_baked::tree_split_step": 56832, "rbl_split2_baked::tree_split_env_step": 56832}
+
+
 def counters(dirname):
     """{kernel name: {counter: [values per dispatch]}} of one pass, step kernels only"""
     out = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -89,7 +98,7 @@ if by_grid:
     with open(os.path.join(DST, "kernel_stats_by_grid.csv"), "w") as fh:
         w = csv.writer(fh)
         w.writerow(["Name", "Grid_Size_X", "Workgroup_Size_X", "Envs", "Calls", "AverageNs", "MinNs", "MaxNs", "VGPR", "AGPR", "SGPR", "ScratchBytesPerLane",
-                    "VGPRSpills", "SGPRSpills", "StaticLDSBytes", "DispatchLDSBytes", "csrc_hash"])
+                    "VGPRSpills", "SGPRSpills", "StaticLDSBytes", "DynamicLDSBytesOfTheLaunch", "csrc_hash"])
         for key in sorted(by_grid, key=lambda k: (k[0], k[1])):
             v = by_grid[key]
             tail = v[10:] if len(v) > 20 else v
@@ -98,7 +107,8 @@ if by_grid:
             co = CO_META.get(code_object_meta.short(key[0])) or {}
             w.writerow([key[0], key[1], key[2], key[1] // per_env, len(v), "%.1f" % (sum(tail) / len(tail)), min(tail), max(tail),
                         co.get("vgpr_count", ""), co.get("agpr_count", ""), co.get("sgpr_count", ""), co.get("private_segment_fixed_size", ""),
-                        co.get("vgpr_spill_count", ""), co.get("sgpr_spill_count", ""), co.get("group_segment_fixed_size", ""), meta[key][0], CSRC_HASH])
+                        co.get("vgpr_spill_count", ""), co.get("sgpr_spill_count", ""), co.get("group_segment_fixed_size", ""),
+                        DYNAMIC_LDS.get(code_object_meta.short(key[0]).split("<")[0], 0), CSRC_HASH])
 
 traffic = {}
 for d in sorted(glob.glob(os.path.join(SRC, "pmc_*_FETCH_SIZE"))):
