@@ -46,7 +46,29 @@ RBL_FN float rbl_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c)
 // as ONE instruction stream): arithmetic on rbl_f2 becomes v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, a plain float
 // operand is broadcast through op_sel (no move); the transcendentals and min / max have no packed form and run per half.
 typedef float rbl_f2 __attribute__((ext_vector_type(2)));
+// A pair CONSTANT (two different literals) cannot ride in one packed instruction: as an rbl_f2 operand the compiler builds it in a scalar
+// register pair with two s_mov_b32 in front of the v_pk_* that reads it (271 of them in the upper body's step; on a lone wave the pair
+// costs up to 3.3 ns on top of the instruction's 3.8 - tools/pk_const_probe.hip).  RBL_K2_SPLIT = 1 makes the constant a type of its own
+// whose products and fused multiply-adds are written per half - two plain instructions with a literal operand each, the same vector-pipe
+// time as the packed one (8 cycles), no scalar instructions - with the same arithmetic per component (bit-identical results).
+#ifndef RBL_K2_SPLIT
+#define RBL_K2_SPLIT 0
+#endif
+#if RBL_K2_SPLIT
+struct rbl_k2 {
+    float a, b;
+    RBL_FN operator rbl_f2() const { return rbl_f2{a, b}; }
+};
+#define RBL_K2(a, b) (rbl_k2{a, b})
+RBL_FN rbl_f2 operator*(rbl_f2 v, rbl_k2 k) { return rbl_f2{v.x * k.a, v.y * k.b}; }
+RBL_FN rbl_f2 operator*(rbl_k2 k, rbl_f2 v) { return rbl_f2{k.a * v.x, k.b * v.y}; }
+RBL_FN rbl_f2 operator+(rbl_f2 v, rbl_k2 k) { return rbl_f2{v.x + k.a, v.y + k.b}; }
+RBL_FN rbl_f2 rbl_fma(rbl_f2 x, rbl_k2 k, rbl_f2 c) { return rbl_f2{__builtin_fmaf(x.x, k.a, c.x), __builtin_fmaf(x.y, k.b, c.y)}; }
+RBL_FN rbl_f2 rbl_fma(rbl_k2 k, rbl_f2 x, rbl_f2 c) { return rbl_f2{__builtin_fmaf(k.a, x.x, c.x), __builtin_fmaf(k.b, x.y, c.y)}; }
+RBL_FN rbl_f2 rbl_fma(rbl_f2 x, rbl_k2 k, rbl_k2 c) { return rbl_f2{__builtin_fmaf(x.x, k.a, c.a), __builtin_fmaf(x.y, k.b, c.b)}; }
+#else
 #define RBL_K2(a, b) (rbl_f2{a, b})
+#endif
 #define RBL_MK2(a, b) (rbl_f2{a, b})
 RBL_FN float rbl_lo(rbl_f2 v) { return v.x; }
 RBL_FN float rbl_hi(rbl_f2 v) { return v.y; }
