@@ -60,13 +60,24 @@
 
 namespace RBL_NS {
 
-struct SplitLds {
+// K2S: how the generated part functions instantiated with this accessor write their pair constants (tree_lane_defs.hpp: RBL_K2) -
+// per half (true: the straight-line Euler step gains 1-2 %) or packed (false: RK4's stage loop keeps the pairs resident)
+#ifndef RBL_K2_SPLIT_EULER
+#define RBL_K2_SPLIT_EULER 1
+#endif
+constexpr bool sp_k2_split(int integ) { return integ == 0 && RBL_K2_SPLIT_EULER != 0; }
+template <bool K2S>
+struct SplitLdsT {
     float *p;   // the wave's private region + lane
+    static constexpr bool k2_split = K2S;
     __device__ __forceinline__ float &operator()(int slot) const { return p[slot * 64]; }
 };
+using SplitLds = SplitLdsT<false>;      // (the exchange area's accessor: RBL_XA - the mode rides on RBL_L)
 // the lean layout's parking "slots": a local array of the wave (slot indices are literals in the generated text: registers)
-struct SplitRegs {
+template <bool K2S>
+struct SplitRegsT {
     float *p;
+    static constexpr bool k2_split = K2S;
     __device__ __forceinline__ float &operator()(int slot) const { return p[slot]; }
 };
 
@@ -314,11 +325,11 @@ __device__ __forceinline__ void split_wave(float *lds, int lane, int live, float
         // the exchange area lies over the action image: nobody writes it before everybody has read its actions ...
         RBL_PART_BARRIER;
         float park[RBL_PART_LDS > 0 ? RBL_PART_LDS : 1];
-        ok = split_step<INTEG, PART>(SplitRegs{park}, lds + SP_X_OFF * 64, lane, spu, h, nsub, q, v);
+        ok = split_step<INTEG, PART>(SplitRegsT<sp_k2_split(INTEG)>{park}, lds + SP_X_OFF * 64, lane, spu, h, nsub, q, v);
         // ... and over the observation image: nobody writes that before everybody has read the last acceleration's exchange
         RBL_PART_BARRIER;
     } else {
-        const SplitLds L{lds + (SP_WAVE_OFF + PART * SP_WAVE_SLOTS) * 64 + lane};
+        const SplitLdsT<sp_k2_split(INTEG)> L{lds + (SP_WAVE_OFF + PART * SP_WAVE_SLOTS) * 64 + lane};
         ok = split_step<INTEG, PART>(L, lds + SP_X_OFF * 64, lane, spu, h, nsub, q, v);
     }
     // (the accelerations' barriers lie between every wave's reads of the input image above and these writes)
@@ -367,7 +378,7 @@ __device__ __forceinline__ void split_helper(float *lds, int lane, int live, flo
 #if !defined(RB_SPLIT_NO_HELPER_PRIO)
     __builtin_amdgcn_s_setprio(2);                      // a helper that shares a SIMD goes first: the wave beside it is the one with slack
 #endif
-    const SplitLds L{lds + lane};                       // (unused: a helper parks nothing)
+    const SplitLdsT<sp_k2_split(INTEG)> L{lds + lane};  // (unused: a helper parks nothing; its type carries the pair-constant mode)
     const SplitLds X{lds + SP_X_OFF * 64 + lane};
     const int n_acc = nsub * (INTEG == 0 ? 1 : 4);
     // env layer: the goal counters of the group's envs, requested now (used behind the step)

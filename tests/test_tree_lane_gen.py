@@ -449,3 +449,25 @@ def test_star_robot_splits_into_the_maximum_number_of_parts():
     assert info["n_parts"] == 4 and info["part_of_joint"][0] == -1
     info = check_split(RobotDescription(spec), "star9h", n=6, tol=5e-4, max_helpers=3)
     assert info["n_parts"] == 4 and 1 <= info["n_helpers"] <= 3
+
+
+@pytest.mark.parametrize("seed", [0, 2])
+def test_device_definitions_accept_every_pair_constant_shape_the_generator_writes(seed):
+    """Robots with two structurally identical branches are written as ONE stream of pair values; a pair CONSTANT in that stream is a
+    type of its own on the device (tree_lane_defs.hpp: rbl_k2c - packed or per half, by the accessor the function is instantiated
+    with) and must combine with pair values and plain floats in every shape the generator emits (`K2 - t`, `t * K2`,
+    `rbl_fma(t, K2, K2)`, ...).  The generated text of the mirrored random robots the GPU tests build at run time, compiled here for
+    gfx950 by hiprtc in BOTH modes (-DRBL_K2_SPLIT=0 / 1; round 6: a shape without an overload failed on the GPU box only)."""
+    import gen_tree_lane_baked as gen
+    from gym_roboy_amd.envs.robots import RobotDescription
+    from random_robots import random_mirrored_spec
+    hdr = os.path.join(BUILD, "lane_rtc_mirrored_%d.hpp" % seed)
+    gen.generate(RobotDescription(random_mirrored_spec(seed, n_branch=3 + seed, n_t_branch=3 + seed)), hdr)
+    text = open(hdr).read()
+    assert "RBL_K2(" in text and "rbl_f2" in text
+    text = text[:text.rindex("#define RBL_TEXT_HASH")]
+    for mode in (0, 1):
+        src = '#define RBL_K2_SPLIT %d\n#include "tree_lane_defs.hpp"\n#define RBL_NS rbl_jit\n' % mode + text + '#include "tree_lane.hpp"\n'
+        rc, log, size = _hiprtc_compile(src, "roboy_tree_lane_jit.hip", ["rbl_jit::tree_lane_step<0>"])
+        assert rc == 0, log[:3000]
+        assert size > 10000
