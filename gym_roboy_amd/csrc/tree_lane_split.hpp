@@ -65,7 +65,13 @@ namespace RBL_NS {
 #ifndef RBL_K2_SPLIT_EULER
 #define RBL_K2_SPLIT_EULER 1
 #endif
-constexpr bool sp_k2_split(int integ) { return integ == 0 && RBL_K2_SPLIT_EULER != 0; }
+// (RK4: per half in the part waves / the helper waves only - RBL_K2_SPLIT_RK4 bit 0 / bit 1 - was measured too: k2split_rk4_ab.log)
+#ifndef RBL_K2_SPLIT_RK4
+#define RBL_K2_SPLIT_RK4 0
+#endif
+constexpr bool sp_k2_split(int integ, bool helper = false) {
+    return integ == 0 ? RBL_K2_SPLIT_EULER != 0 : ((RBL_K2_SPLIT_RK4 >> (helper ? 1 : 0)) & 1) != 0;
+}
 template <bool K2S>
 struct SplitLdsT {
     float *p;   // the wave's private region + lane
@@ -378,7 +384,7 @@ __device__ __forceinline__ void split_helper(float *lds, int lane, int live, flo
 #if !defined(RB_SPLIT_NO_HELPER_PRIO)
     __builtin_amdgcn_s_setprio(2);                      // a helper that shares a SIMD goes first: the wave beside it is the one with slack
 #endif
-    const SplitLdsT<sp_k2_split(INTEG)> L{lds + lane};  // (unused: a helper parks nothing; its type carries the pair-constant mode)
+    const SplitLdsT<sp_k2_split(INTEG, true)> L{lds + lane};  // (unused: a helper parks nothing; its type carries the pair-constant mode)
     const SplitLds X{lds + SP_X_OFF * 64 + lane};
     const int n_acc = nsub * (INTEG == 0 ? 1 : 4);
     // env layer: the goal counters of the group's envs, requested now (used behind the step)
