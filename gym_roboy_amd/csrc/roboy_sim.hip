@@ -12,6 +12,9 @@
 // for the robot (tree_lane_gen.hpp, tree_lane.hpp: the committed upper body ahead of
 // time, other robots by hiprtc) or, without that specialisation, two envs per wave,
 // eight lanes per link, working set in LDS (tree_aba.hpp).  DESIGN.md §4-§5.
+// Which kernel instance a call launches is ONE table (roboy_dispatch.hpp, included below): 98 rows keyed by robot class / entry kind /
+// kernel form / integrator / workgroup size / constants source / variant, RB_KERNEL_AUTO's thresholds as a list of rules; this file
+// holds the kernels that are not in a header of their own, the handle, the availability predicates and the C ABI.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>

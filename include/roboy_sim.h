@@ -254,7 +254,9 @@ int rb_env_step_dev(rb_sim *sim, const float *d_act /* [n_envs][n_t] in [-1,1] *
  * WHOLE batch (the library applies the offsets); first_env is a multiple of 256; hip_stream NULL = the handle's stream.
  * rb_range_capable(): bit 0 = rb_step_range_dev takes sub-ranges with the handle's kernel form (ball joints with 8 tendons
  * except the tendon-per-lane form; joint trees in the one-wave-per-64-envs form), bit 1 = rb_env_step_range_dev does (ball
- * joints always; joint trees in that form); a clear bit = whole batches only (RB_EUNSUPPORTED otherwise).
+ * joints always; joint trees in that form); a clear bit = whole batches only: a WHOLE batch (first_env = 0, n_envs = all) is taken
+ * by every form on the caller's stream, a true sub-range is refused with RB_EUNSUPPORTED.  (The `ranges` field of the dispatch
+ * table's rows, below, says the same per kernel instance.)
  * Lifetime: the handle remembers every distinct caller stream it has launched a range on (an event behind the last launch;
  * 8 entries, least recently used reused after a wait), and rb_destroy / rb_select_kernel / rb_set_stream wait for that work
  * like for the handle's own streams - the caller need not join before closing.  The caller's stream may already be
