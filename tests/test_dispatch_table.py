@@ -293,3 +293,12 @@ def test_a_whole_batch_on_a_callers_stream_is_taken_by_the_whole_batch_forms_and
         sims[0].step_range_dev(0, 512, st.cuda_stream, act.data_ptr(), 1.0)
     for s in sims:
         s.close()
+
+
+def test_the_committed_table_listing_is_current():
+    """docs/dispatch_table.md is written from the library's exported rows and rules (tools/gen_dispatch_doc.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_dispatch_doc.py"), "--check"]).returncode == 0, \
+        "docs/dispatch_table.md is stale: run python tools/gen_dispatch_doc.py"
