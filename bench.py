@@ -685,6 +685,9 @@ def build_line(head, also, one_launch, cpu, world, robot_name, use_graph):
             "frac_wall": valu_wall if rf["bound"] == "valu" else hbm_wall,
             "hbm_frac": rf["hbm"]["frac"], "valu_frac": (rf.get("valu") or {}).get("frac"),
             "hbm_frac_wall": hbm_wall, "valu_frac_wall": valu_wall,
+            # against what an all-FMA fp32 stream reaches on this chip (109 TFLOP/s: 1.20 ns per wave-instruction and SIMD at 8 waves,
+            # profiles/r1_b/microbench_valu.log; packed fp32 moves the same flops per cycle) - the spec peak above is the contract's roof
+            "valu_frac_of_measured_fma_rate": (rf.get("valu") or {}).get("frac_of_measured_fma_rate_109TFLOPs"),
             "one_launch_frac": (one_launch or {}).get("frac"), "one_launch_hbm_frac": (one_launch or {}).get("hbm_frac"),
             "euler_262144_hbm_frac": row_frac("msj-262144-euler", 1), "euler_2097152_hbm_frac": row_frac("msj-2097152-euler", 1),
             "fused_env_2097152_hbm_frac": row_frac("fused-env-2097152", 1),

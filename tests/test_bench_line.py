@@ -82,7 +82,8 @@ def test_worst_case_line_stays_under_the_cap_and_parses_strictly(nan):
     assert set(r["traffic_over_algorithmic_rows"]) == set(bench.TRAFFIC_ROWS)
     # the scalars the driver's record keeps: north_star's claims readable without the nested objects
     for key in ("frac", "frac_wall", "hbm_frac", "valu_frac", "hbm_frac_wall", "valu_frac_wall", "one_launch_frac", "one_launch_hbm_frac",
-                "euler_262144_hbm_frac", "euler_2097152_hbm_frac", "fused_env_2097152_hbm_frac", "traffic_over_algorithmic", "traffic_stale"):
+                "euler_262144_hbm_frac", "euler_2097152_hbm_frac", "fused_env_2097152_hbm_frac", "traffic_over_algorithmic", "traffic_stale",
+                "valu_frac_of_measured_fma_rate"):
         assert key in r and not isinstance(r[key], (dict, list)), key
     assert r["euler_262144_hbm_frac"] == r["configs"]["msj-262144-euler"][1] and r["fused_env_2097152_hbm_frac"] == r["configs"]["fused-env-2097152"][1]
     assert abs(r["frac_wall"] - 3036 * 262144 / (head["ms_per_step"] * 1e-3) / 157.3e12) < 1e-4 * r["frac_wall"]
