@@ -810,7 +810,9 @@ def self_launch(n, argv, timeout=None):
     finally:
         for s, h in previous.items():
             signal.signal(s, h)
-        kill_group()                           # nothing of the child tree outlives this call
+        if proc.returncode is None or proc.returncode != 0:
+            kill_group()                       # a launcher that failed or was cut short: none of its ranks outlives this call
+                                               # (after a clean exit the group is gone and its id is not ours to signal any more)
     lines = [l for l in (out or "").splitlines() if l.strip()]
     contract = [l for l in lines if l.lstrip().startswith("{")]
     for l in lines:                            # anything else a library wrote to the ranks' stdout: not on ours
